@@ -245,7 +245,8 @@ def artanh(x: Tensor) -> Tensor:
 
 
 def _norm(x: Tensor) -> Tensor:
-    return torch.sqrt((x * x).sum(dim=-1, keepdim=True))
+    # torch's 2-norm: sub-gradient 0 at x == 0 (what hyper_math's x.norm(...) gives), not sqrt's NaN
+    return torch.linalg.vector_norm(x, ord=2, dim=-1, keepdim=True)
 
 
 def expmap0(u: Tensor, c: float = 1.0) -> Tensor:
@@ -276,13 +277,13 @@ def dist(x: Tensor, y: Tensor, c: float = 1.0) -> Tensor:
     """hyper_math.py:207-210."""
     sc = math.sqrt(c)
     m = mobius_add(-x, y, c)
-    return artanh(sc * torch.sqrt((m * m).sum(-1))) * 2 / sc
+    return artanh(sc * _norm(m)[..., 0]) * 2 / sc
 
 
 def dist0(x: Tensor, c: float = 1.0) -> Tensor:
     """hyper_math.py:233-236."""
     sc = math.sqrt(c)
-    return artanh(sc * torch.sqrt((x * x).sum(-1))) * 2 / sc
+    return artanh(sc * _norm(x)[..., 0]) * 2 / sc
 
 
 def logmap0(y: Tensor, c: float = 1.0) -> Tensor:
