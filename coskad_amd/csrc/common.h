@@ -1,0 +1,62 @@
+// Shared host/device helpers for the COSKAD gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#define COSKAD_ABI_VERSION 1
+
+// error codes returned through the C ABI (0 = ok)
+#define COSKAD_OK 0
+#define COSKAD_ERR_ARG (-1)      // bad argument (null pointer, non-positive size)
+#define COSKAD_ERR_SHAPE (-2)    // unsupported (T,V) / channel count
+#define COSKAD_ERR_LAUNCH (-3)   // HIP launch failure
+#define COSKAD_ERR_WORKSPACE (-4)// workspace too small
+
+namespace coskad {
+
+// thread-local last-error text, read through coskad_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+constexpr int kBlock = 256;          // every tile kernel runs 4 waves of 64
+constexpr int kMaxLdsBytes = 160 * 1024;
+constexpr float kBnEps = 1e-5f;      // nn.BatchNorm2d default (reference stsgcn.py:65,76)
+
+template <int T, int V>
+struct Geo {
+  static constexpr int TV = T * V;
+  // LDS row stride in floats: odd, so that lanes<->rows (stride LD) and lanes<->positions
+  // (stride 1) are both bank-conflict-free for ds_read_b32/ds_write_b32 (32 banks).
+  static constexpr int LD = (TV % 2 == 0) ? TV + 1 : TV;
+};
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+__device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
+
+// wave-uniform value -> SGPR (lets hipcc use s_load for everything indexed by it)
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// (T,V) geometries the kernels are instantiated for.  17 = COCO joints (default),
+// 25 = NTU layout (BASELINE config 4), 14 = headless, 18 = kp18 (wrappers, staticCenter.py:70-75).
+#define COSKAD_DISPATCH_TV(T_, V_, CALL)                                   \
+  do {                                                                      \
+    if ((T_) == 12 && (V_) == 17) { CALL(12, 17); }                         \
+    else if ((T_) == 12 && (V_) == 25) { CALL(12, 25); }                    \
+    else if ((T_) == 12 && (V_) == 14) { CALL(12, 14); }                    \
+    else if ((T_) == 12 && (V_) == 18) { CALL(12, 18); }                    \
+    else return coskad::fail(COSKAD_ERR_SHAPE,                              \
+        "unsupported (n_frames=%d, n_joints=%d): built for T=12, V in {14,17,18,25}", (T_), (V_)); \
+  } while (0)
+
+}  // namespace coskad

@@ -1,0 +1,268 @@
+// Device building blocks shared by the STS-GCN tile kernels (gfx950).
+//
+// A *tile* is NB consecutive clips x C channels of one activation tensor
+// [N, C, T, V] (contiguous, fp32).  In HBM a tile is one contiguous run of
+// NB*C*T*V floats, so staging is a pure streaming copy.  In LDS a tile is
+// `rows = NB*C` rows of LD = T*V (+1 if even) floats: row = (clip, channel),
+// column = position p = t*V + v.
+//
+// Two thread mappings alternate on the same LDS image:
+//   * row phase   (the learned space/time mixing, reference stsgcn.py:154-155):
+//     lane <-> row, wave <-> a wave-uniform slice of joints (temporal mix) or
+//     frames (spatial mix).  The mixing weights T[v,:,:] / A[t,:,:] are then
+//     wave-uniform: they stream through SGPRs (s_load) and every FMA is
+//     v_fma(vgpr, sgpr, vgpr) -- no LDS or VGPR traffic for weights.
+//   * position phase (1x1 convolutions / epilogues): lane <-> position,
+//     channel loop inside the thread, conv weights wave-uniform in SGPRs.
+#pragma once
+#include "common.h"
+
+namespace coskad {
+
+// Stream `nfloats` contiguous floats (whole rows of TV) from HBM into the LDS row image,
+// optionally applying PReLU on the way (the producer layer stores pre-activations).
+template <int T, int V>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* lds, int nfloats,
+                                           bool do_prelu, float slope) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  if constexpr (TV % 4 == 0) {
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const int n4 = nfloats >> 2;
+    for (int i = threadIdx.x; i < n4; i += kBlock) {
+      float4 v = g4[i];
+      const int e = i << 2;
+      const int row = e / TV;
+      const int col = e - row * TV;
+      if (do_prelu) {
+        v.x = prelu_f(v.x, slope); v.y = prelu_f(v.y, slope);
+        v.z = prelu_f(v.z, slope); v.w = prelu_f(v.w, slope);
+      }
+      float* d = lds + row * LD + col;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int e = threadIdx.x; e < nfloats; e += kBlock) {
+      float v = g[e];
+      const int row = e / TV;
+      const int col = e - row * TV;
+      if (do_prelu) v = prelu_f(v, slope);
+      lds[row * LD + col] = v;
+    }
+  }
+}
+
+// Write the LDS row image back to a contiguous HBM tile.
+template <int T, int V>
+__device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* lds, int nfloats) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  for (int e = threadIdx.x; e < nfloats; e += kBlock) {
+    const int row = e / TV;
+    const int col = e - row * TV;
+    g[e] = lds[row * LD + col];
+  }
+}
+
+// ---- row phase ------------------------------------------------------------------------
+// Temporal mix of one joint column v of one row, in place.
+//   forward : y[q] = sum_t x[t] * Tw[v][t][q]        (einsum 'nctv,vtq->ncqv', stsgcn.py:154)
+//   adjoint : x'[t] = sum_q y'[q] * Tw[v][t][q]
+template <int T, int V, bool ADJ>
+__device__ __forceinline__ void temporal_col(float* r, int v, const float* __restrict__ Tw) {
+  float x[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) x[t] = r[t * V + v];
+  const float* w = Tw + v * T * T;  // wave-uniform -> SGPR stream
+  float y[T];
+  if constexpr (!ADJ) {
+#pragma unroll
+    for (int q = 0; q < T; ++q) y[q] = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int q = 0; q < T; ++q) y[q] = fmaf(x[t], w[t * T + q], y[q]);
+  } else {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < T; ++q) s = fmaf(x[q], w[t * T + q], s);
+      y[t] = s;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < T; ++q) r[q * V + v] = y[q];
+}
+
+// Spatial mix of one frame t of one row, in place.
+//   forward : z[w] = sum_v y[v] * Aw[t][v][w]        (einsum 'nctv,tvw->nctw', stsgcn.py:155)
+//   adjoint : y'[v] = sum_w z'[w] * Aw[t][v][w]
+template <int T, int V, bool ADJ>
+__device__ __forceinline__ void spatial_row(float* r, int t, const float* __restrict__ Aw) {
+  float y[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) y[v] = r[t * V + v];
+  const float* w = Aw + t * V * V;  // wave-uniform -> SGPR stream
+  float z[V];
+  if constexpr (!ADJ) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) z[j] = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int j = 0; j < V; ++j) z[j] = fmaf(y[v], w[v * V + j], z[j]);
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) s = fmaf(y[j], w[v * V + j], s);
+      z[v] = s;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) r[t * V + j] = z[j];
+}
+
+// One half of the separable mixing over all rows of the LDS image, in place.
+//   TEMPORAL=true : every row's joint columns;  TEMPORAL=false : every row's frames.
+// Work split: lane <-> row (64 rows per batch), wave <-> slice of v (or t).
+template <int T, int V, bool TEMPORAL, bool ADJ>
+__device__ __forceinline__ void mix_rows(float* lds, int rows, const float* __restrict__ W) {
+  constexpr int LD = Geo<T, V>::LD;
+  constexpr int NPART = kBlock / 64;
+  constexpr int EXT = TEMPORAL ? V : T;
+  const int lane = threadIdx.x & 63;
+  const int part = uniform(threadIdx.x >> 6);
+  const int beg = (EXT * part) / NPART, end = (EXT * (part + 1)) / NPART;
+  for (int rb = 0; rb < rows; rb += 64) {
+    const int row = rb + lane;
+    if (row < rows) {
+      float* r = lds + row * LD;
+      for (int i = beg; i < end; ++i) {
+        if constexpr (TEMPORAL) temporal_col<T, V, ADJ>(r, i, W);
+        else spatial_row<T, V, ADJ>(r, i, W);
+      }
+    }
+  }
+}
+
+// Full ConvTemporalGraphical on the LDS image, in place (forward: temporal then spatial;
+// adjoint: spatial^T then temporal^T).  Contains the barrier between the two halves;
+// caller provides the barriers before and after.
+template <int T, int V, bool ADJ>
+__device__ __forceinline__ void gcn_rows(float* lds, int rows, const float* __restrict__ Aw,
+                                         const float* __restrict__ Tw) {
+  if constexpr (!ADJ) {
+    mix_rows<T, V, true, false>(lds, rows, Tw);
+    __syncthreads();
+    mix_rows<T, V, false, false>(lds, rows, Aw);
+  } else {
+    mix_rows<T, V, false, true>(lds, rows, Aw);
+    __syncthreads();
+    mix_rows<T, V, true, true>(lds, rows, Tw);
+  }
+}
+
+}  // namespace coskad
+
+// ---- MFMA phase -----------------------------------------------------------------------
+// Batch reductions that are GEMMs with K = positions (BatchNorm second moments, conv weight
+// gradients): Out[a][b] += sum_p Arow[a][p] * Brow[b][p].  v_mfma_f32_16x16x4_f32 is an exact
+// fp32 FMA chain (same numerics as VALU) at the VALU FLOP rate, on the otherwise idle matrix
+// pipe, and does the cross-lane reduction over K for free.
+//   A operand: lane l holds A[i = l&15][k = l>>4];  B operand: B[k = l>>4][j = l&15]
+//   C/D      : lane l, reg r  <->  D[row = 4*(l>>4) + r][col = l&15]
+namespace coskad {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// One clip's worth of positions.  The 4 waves of the block split the K (position) steps;
+// each wave keeps its own accumulators for ALL (ta, tb) tile pairs.
+//   ldsA/ldsB : first row of the clip in the A / B row image (LD stride)
+//   va / vb   : number of valid rows (rows >= valid read as 0)
+//   SUMS      : also accumulate row sums of A (B operand == 1) into sacc
+template <int T, int V, int NTA, int NTB, bool SUMS>
+__device__ __forceinline__ void outer_accum(const float* ldsA, int va, const float* ldsB, int vb,
+                                            f32x4 (&acc)[NTA][NTB], f32x4 (&sacc)[NTA]) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  static_assert(TV % 4 == 0, "positions must be a multiple of the MFMA K step");
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int i = lane & 15, k = lane >> 4;
+  for (int p0 = 4 * wave; p0 < TV; p0 += 4 * (kBlock / 64)) {
+    float a[NTA], b[NTB];
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) {
+      const int row = 16 * ta + i;
+      a[ta] = row < va ? ldsA[row * LD + p0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+      const int row = 16 * tb + i;
+      b[tb] = row < vb ? ldsB[row * LD + p0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) {
+#pragma unroll
+      for (int tb = 0; tb < NTB; ++tb)
+        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+      if constexpr (SUMS)
+        sacc[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], 1.0f, sacc[ta], 0, 0, 0);
+    }
+  }
+}
+
+// Cross-wave reduction of MFMA accumulators and store of this block's partial.
+//   dst[(16*ta + row) * ldd + 16*tb + col]  (only row < va, col < vb are written)
+// scratch: LDS, >= 4 waves * 256 floats.  Contains barriers; all threads must call.
+template <int NTA, int NTB>
+__device__ __forceinline__ void store_outer(const f32x4 (&acc)[NTA][NTB], float* scratch, float* dst,
+                                            int ldd, int va, int vb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int ta = 0; ta < NTA; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scratch[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[ta][tb][r];
+      __syncthreads();
+      const int e = threadIdx.x;  // 256 threads <-> 16x16 tile elements
+      const int row = e >> 4, col = e & 15;
+      const float s = (scratch[e] + scratch[256 + e]) + (scratch[512 + e] + scratch[768 + e]);
+      if (16 * ta + row < va && 16 * tb + col < vb) dst[(16 * ta + row) * ldd + 16 * tb + col] = s;
+    }
+}
+
+// Same for the row-sum accumulators (all 16 columns of a sum tile are identical: take col 0).
+template <int NTA>
+__device__ __forceinline__ void store_sums(const f32x4 (&sacc)[NTA], float* scratch, float* dst, int va) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int ta = 0; ta < NTA; ++ta) {
+    __syncthreads();
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scratch[wave * 16 + 4 * (lane >> 4) + r] = sacc[ta][r];
+    }
+    __syncthreads();
+    const int e = threadIdx.x;
+    if (e < 16 && 16 * ta + e < va)
+      dst[16 * ta + e] = (scratch[e] + scratch[16 + e]) + (scratch[32 + e] + scratch[48 + e]);
+  }
+}
+
+template <int N, int M>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[N][M]) {
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+#pragma unroll
+    for (int b = 0; b < M; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+template <int N>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[N]) {
+#pragma unroll
+  for (int a = 0; a < N; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+}  // namespace coskad
