@@ -1,0 +1,262 @@
+// Train-mode BatchNorm statistics of one ST_GCNN_layer (reference stsgcn.py:56-80, 94-110)
+// WITHOUT materialising the conv outputs.
+//
+// Both BatchNorms see a 1x1 conv of a tensor we hold per tile (Z = gcn(X) for `tcn`, X for
+// `residual`), so their batch statistics follow from the first and second moments of the
+// conv INPUT:
+//     mean(W z + b) = W mu_z + b          var(W z + b) = diag(W C_z W^T)
+// with mu_z, C_z the mean / (biased) covariance of z over (N,T,V).  Moments are C_in x C_in
+// GEMMs with K = positions -> v_mfma_f32_16x16x4_f32 (exact fp32) per tile, fp64 across
+// tiles.  The layer kernel (stsgcn_fwd.hip) then runs once with the folded weights.
+//
+//   k_fwd_moments   : per-block partials of  sum x x^T, sum x, sum z z^T, sum z
+//   k_reduce_partials: fp64 sum over blocks (deterministic: fixed order, no atomics)
+//   k_train_fold    : stats -> folded weights, saved stats for backward, running-stat update
+#include "tile_ops.h"
+
+namespace coskad {
+
+constexpr int kMaxGrid = 512;  // persistent blocks of the reduction kernels (= partials to sum)
+
+template <int T, int V, int NTC>
+__global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict__ in,
+                                                       const float* __restrict__ Aw,
+                                                       const float* __restrict__ Tw,
+                                                       const float* __restrict__ in_slope,
+                                                       float* __restrict__ partials, int B, int Ci,
+                                                       int NB, int need_x) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* scratch = lds + NB * Ci * LD;  // 1024 floats
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  f32x4 mx[NTC][NTC], mz[NTC][NTC], sx[NTC], sz[NTC];
+  zero_acc(mx); zero_acc(mz); zero_acc(sx); zero_acc(sz);
+
+  const int ntiles = ceil_div(B, NB);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int clip0 = tile * NB;
+    const int nb = min(NB, B - clip0);
+    const int rows = nb * Ci;
+    __syncthreads();  // previous tile's MFMA reads are done
+    stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, lds, rows * TV, pre, a_in);
+    __syncthreads();
+    if (need_x) {
+      for (int n = 0; n < nb; ++n) {
+        const float* r = lds + n * Ci * LD;
+        outer_accum<T, V, NTC, NTC, true>(r, Ci, r, Ci, mx, sx);
+      }
+      __syncthreads();
+    }
+    gcn_rows<T, V, false>(lds, rows, Aw, Tw);
+    __syncthreads();
+    for (int n = 0; n < nb; ++n) {
+      const float* r = lds + n * Ci * LD;
+      outer_accum<T, V, NTC, NTC, true>(r, Ci, r, Ci, mz, sz);
+    }
+  }
+  // partial layout: [MX Ci*Ci][sumX Ci][MZ Ci*Ci][sumZ Ci]
+  float* dst = partials + (size_t)blockIdx.x * (2 * (Ci * Ci + Ci));
+  store_outer<NTC, NTC>(mx, scratch, dst, Ci, Ci, Ci);
+  store_sums<NTC>(sx, scratch, dst + Ci * Ci, Ci);
+  store_outer<NTC, NTC>(mz, scratch, dst + Ci * Ci + Ci, Ci, Ci, Ci);
+  store_sums<NTC>(sz, scratch, dst + 2 * Ci * Ci + Ci, Ci);
+}
+
+// out[e] = sum_p partials[p][e] in fp64.  block = 64 elements x 4 partial-slices.
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int P, int E,
+                                                          double* __restrict__ out) {
+  __shared__ double sh[256];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  double s = 0.0;
+  if (e < E)
+    for (int p = slice; p < P; p += 4) s += (double)partials[(size_t)p * E + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (slice == 0 && e < E)
+    out[e] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
+
+// stat block (floats), saved for the backward pass:
+//   [muX Ci][muZ Ci][WCs Co*Ci = Wt C_Z][WCr Co*Ci = Wr C_X][mean_s Co][istd_s Co][mean_r Co][istd_r Co]
+__host__ __device__ inline int stat_floats(int Ci, int Co) { return 2 * Ci + 2 * Co * Ci + 4 * Co; }
+
+__global__ __launch_bounds__(256) void k_train_fold(
+    const double* __restrict__ red, double npos, const float* __restrict__ Wt,
+    const float* __restrict__ bt, const float* __restrict__ gs, const float* __restrict__ bs,
+    float* __restrict__ rm_s, float* __restrict__ rv_s, long long* __restrict__ nbt_s,
+    const float* __restrict__ Wr, const float* __restrict__ br, const float* __restrict__ gr,
+    const float* __restrict__ brr, float* __restrict__ rm_r, float* __restrict__ rv_r,
+    long long* __restrict__ nbt_r, float momentum, float* __restrict__ wfold,
+    float* __restrict__ bias, float* __restrict__ stat, int Ci, int Co, int CoP) {
+  const bool ident = Wr == nullptr;
+  const double* MX = red;
+  const double* SX = red + Ci * Ci;
+  const double* MZ = red + Ci * Ci + Ci;
+  const double* SZ = red + 2 * Ci * Ci + Ci;
+  float* muX = stat;
+  float* muZ = stat + Ci;
+  float* WCs = stat + 2 * Ci;
+  float* WCr = WCs + Co * Ci;
+  float* mean_s = WCr + Co * Ci;
+  float* istd_s = mean_s + Co;
+  float* mean_r = istd_s + Co;
+  float* istd_r = mean_r + Co;
+  const double inv_n = 1.0 / npos;
+
+  for (int c = threadIdx.x; c < Ci; c += blockDim.x) {
+    muX[c] = (float)(SX[c] * inv_n);
+    muZ[c] = (float)(SZ[c] * inv_n);
+  }
+  // WC[o][c] = sum_c' W[o][c'] * C[c'][c],  C = M/n - mu mu^T   (fp64)
+  for (int i = threadIdx.x; i < 2 * Co * Ci; i += blockDim.x) {
+    const int br_ = i / (Co * Ci);
+    if (br_ == 1 && ident) { WCr[i - Co * Ci] = 0.f; continue; }
+    const int j = i - br_ * Co * Ci;
+    const int o = j / Ci, c = j - o * Ci;
+    const float* W = br_ ? Wr : Wt;
+    const double* M = br_ ? MX : MZ;
+    const double* S = br_ ? SX : SZ;
+    const double muc = S[c] * inv_n;
+    double acc = 0.0;
+    for (int k = 0; k < Ci; ++k) acc += (double)W[o * Ci + k] * (M[k * Ci + c] * inv_n - (S[k] * inv_n) * muc);
+    (br_ ? WCr : WCs)[j] = (float)acc;
+  }
+  __syncthreads();
+  const double unbias = npos > 1.0 ? npos / (npos - 1.0) : 1.0;
+  for (int i = threadIdx.x; i < 2 * Co; i += blockDim.x) {
+    const int br_ = i / Co, o = i - br_ * Co;
+    if (br_ == 1 && ident) { mean_r[o] = 0.f; istd_r[o] = 1.f; continue; }
+    const float* W = br_ ? Wr : Wt;
+    const float* b = br_ ? br : bt;
+    const double* S = br_ ? SX : SZ;
+    const float* WC = br_ ? WCr : WCs;
+    double m = b ? (double)b[o] : 0.0, var = 0.0;
+    for (int k = 0; k < Ci; ++k) {
+      m += (double)W[o * Ci + k] * (S[k] * inv_n);
+      var += (double)W[o * Ci + k] * (double)WC[o * Ci + k];
+    }
+    var = var > 0.0 ? var : 0.0;
+    (br_ ? mean_r : mean_s)[o] = (float)m;
+    (br_ ? istd_r : istd_s)[o] = (float)(1.0 / sqrt(var + (double)kBnEps));
+    float* rm = br_ ? rm_r : rm_s;
+    float* rv = br_ ? rv_r : rv_s;
+    if (rm) {  // nn.BatchNorm2d: running = (1-m) running + m batch ; unbiased variance
+      rm[o] = (1.f - momentum) * rm[o] + momentum * (float)m;
+      rv[o] = (1.f - momentum) * rv[o] + momentum * (float)(var * unbias);
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (nbt_s) nbt_s[0] += 1;
+    if (nbt_r && !ident) nbt_r[0] += 1;
+  }
+  __syncthreads();
+  // folded weights: U = Wz Z + Wx X + b
+  for (int i = threadIdx.x; i < 2 * Ci * CoP; i += blockDim.x) {
+    const int row = i / CoP, o = i - row * CoP;
+    float w = 0.f;
+    if (o < Co) {
+      if (row < Ci) w = gs[o] * istd_s[o] * Wt[o * Ci + row];
+      else {
+        const int c = row - Ci;
+        w = ident ? (c == o ? 1.f : 0.f) : gr[o] * istd_r[o] * Wr[o * Ci + c];
+      }
+    }
+    wfold[i] = w;
+  }
+  for (int o = threadIdx.x; o < CoP; o += blockDim.x) {
+    float b = 0.f;
+    if (o < Co) {
+      b = bs[o] + gs[o] * istd_s[o] * ((bt ? bt[o] : 0.f) - mean_s[o]);
+      if (!ident) b += brr[o] + gr[o] * istd_r[o] * ((br ? br[o] : 0.f) - mean_r[o]);
+    }
+    bias[o] = b;
+  }
+}
+
+// rows of the tile kernels that keep ONE Ci-row image (+1024 floats scratch) in LDS
+static int pick_nb_rows(int rows_per_clip, int B, int LD, int budget_bytes) {
+  int nb = rows_per_clip >= 64 ? 1 : 64 / rows_per_clip;
+  if (nb < 1) nb = 1;
+  while (nb > 1 && (size_t)nb * rows_per_clip * LD * 4 > (size_t)budget_bytes) --nb;
+  if (nb > B) nb = B;
+  return nb;
+}
+
+size_t train_stats_ws_bytes(int Ci) {
+  const size_t E = 2 * ((size_t)Ci * Ci + Ci);
+  return kMaxGrid * E * sizeof(float) + round_up((int)(E * sizeof(double)), 256) + 256;
+}
+
+template <int T, int V>
+static int launch_train_stats(const float* in, const float* Aw, const float* Tw, const float* in_slope,
+                              const float* Wt, const float* bt, const float* gs, const float* bs,
+                              float* rm_s, float* rv_s, long long* nbt_s, const float* Wr,
+                              const float* br, const float* gr, const float* brr, float* rm_r,
+                              float* rv_r, long long* nbt_r, float momentum, float* wfold, float* bias,
+                              float* stat, void* ws, size_t ws_bytes, int B, int Ci, int Co,
+                              hipStream_t st) {
+  constexpr int LD = Geo<T, V>::LD, TV = Geo<T, V>::TV;
+  if (Ci > 64) return fail(COSKAD_ERR_SHAPE, "train_stats: C_in=%d > 64 not supported", Ci);
+  if (ws_bytes < train_stats_ws_bytes(Ci))
+    return fail(COSKAD_ERR_WORKSPACE, "train_stats: workspace %zu < %zu bytes", ws_bytes, train_stats_ws_bytes(Ci));
+  const int E = 2 * (Ci * Ci + Ci);
+  const int NB = pick_nb_rows(Ci, B, LD, 60 * 1024);
+  const size_t lds = ((size_t)NB * Ci * LD + 1024) * sizeof(float);
+  const int ntiles = ceil_div(B, NB);
+  const int grid = ntiles < kMaxGrid ? ntiles : kMaxGrid;
+  float* partials = reinterpret_cast<float*>(ws);
+  double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + round_up((int)(kMaxGrid * (size_t)E * sizeof(float)), 256));
+  const int need_x = Wr != nullptr;
+  const int ntc = ceil_div(Ci, 16);
+#define LAUNCH_M(NTC)                                                                           \
+  hipLaunchKernelGGL((k_fwd_moments<T, V, NTC>), dim3(grid), dim3(kBlock), lds, st, in, Aw, Tw, \
+                     in_slope, partials, B, Ci, NB, need_x)
+  if (ntc == 1) LAUNCH_M(1);
+  else if (ntc == 2) LAUNCH_M(2);
+  else if (ntc == 3) LAUNCH_M(3);
+  else LAUNCH_M(4);
+#undef LAUNCH_M
+  int rc = check_launch("fwd_moments");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(256), 0, st, partials, grid, E, red);
+  rc = check_launch("reduce_partials");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_train_fold, dim3(1), dim3(256), 0, st, red, (double)B * TV, Wt, bt, gs, bs, rm_s,
+                     rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r, nbt_r, momentum, wfold, bias, stat, Ci,
+                     Co, round_up(Co, 16));
+  return check_launch("train_fold");
+}
+
+}  // namespace coskad
+
+using namespace coskad;
+
+extern "C" {
+
+size_t coskad_train_stats_ws_bytes(int Ci) { return train_stats_ws_bytes(Ci); }
+int coskad_stat_floats(int Ci, int Co) { return stat_floats(Ci, Co); }
+
+int coskad_layer_train_stats_f32(const float* in, const float* A, const float* Tm, const float* in_slope,
+                                 const float* Wt, const float* bt, const float* gamma_t,
+                                 const float* beta_t, float* rmean_t, float* rvar_t, long long* nbt_t,
+                                 const float* Wr, const float* br, const float* gamma_r,
+                                 const float* beta_r, float* rmean_r, float* rvar_r, long long* nbt_r,
+                                 float momentum, float* wfold, float* bias, float* stat, void* ws,
+                                 size_t ws_bytes, int B, int Ci, int Co, int T, int V,
+                                 hipStream_t stream) {
+  if (!in || !A || !Tm || !Wt || !gamma_t || !beta_t || !wfold || !bias || !stat || !ws)
+    return fail(COSKAD_ERR_ARG, "layer_train_stats: null pointer");
+  if (Wr && (!gamma_r || !beta_r)) return fail(COSKAD_ERR_ARG, "layer_train_stats: residual BN missing");
+  if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_train_stats: identity residual needs Ci == Co");
+  if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_train_stats: B=%d Ci=%d Co=%d", B, Ci, Co);
+#define CALL(T_, V_)                                                                                   \
+  return launch_train_stats<T_, V_>(in, A, Tm, in_slope, Wt, bt, gamma_t, beta_t, rmean_t, rvar_t, nbt_t, \
+                                    Wr, br, gamma_r, beta_r, rmean_r, rvar_r, nbt_r, momentum, wfold, \
+                                    bias, stat, ws, ws_bytes, B, Ci, Co, stream)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+}  // extern "C"

@@ -80,3 +80,42 @@ def layer_apply(x: Tensor, A: Tensor, Tm: Tensor, wfold: Tensor, bias: Tensor, C
     call("coskad_layer_apply_f32", ptr(x), ptr(out), ptr(A), ptr(Tm), ptr(wfold), ptr(bias),
          ptr(in_slope), ptr(out_slope), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
     return out
+
+
+def stat_floats(Ci: int, Co: int) -> int:
+    fn = _lib.lib().coskad_stat_floats
+    fn.restype = ctypes.c_int
+    return fn(i32(Ci), i32(Co))
+
+
+def train_stats_ws_bytes(Ci: int) -> int:
+    fn = _lib.lib().coskad_train_stats_ws_bytes
+    fn.restype = ctypes.c_size_t
+    return fn(i32(Ci))
+
+
+def layer_train_stats(x, A, Tm, in_slope, Wt, bt, gt, bet, rm_t, rv_t, nbt_t,
+                      Wr, br, gr, ber, rm_r, rv_r, nbt_r, ws, momentum: float = 0.1):
+    """Train-mode BN statistics of one layer -> (wfold, bias, stat); updates running stats in place."""
+    B, Ci, T, V = x.shape
+    Co = Wt.shape[0]
+    _chk(x, "x"); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
+    _chk(Wt, "Wt", (Co, Ci)); _chk(gt, "gamma_t", (Co,)); _chk(bet, "beta_t", (Co,))
+    for n, t in (("bt", bt), ("rm_t", rm_t), ("rv_t", rv_t), ("br", br), ("gamma_r", gr), ("beta_r", ber),
+                 ("rm_r", rm_r), ("rv_r", rv_r)):
+        _chk(t, n, (Co,), optional=True)
+    _chk(Wr, "Wr", (Co, Ci), optional=True)
+    _chk(in_slope, "in_slope", (1,), optional=True)
+    _chk(nbt_t, "nbt_t", (), dtype=torch.int64, optional=True)
+    _chk(nbt_r, "nbt_r", (), dtype=torch.int64, optional=True)
+    need = train_stats_ws_bytes(Ci)
+    if ws is None or ws.numel() * ws.element_size() < need:
+        raise ValueError(f"workspace too small: need {need} bytes")
+    wfold = torch.empty(2 * Ci, cop(Co), device=x.device, dtype=torch.float32)
+    bias = torch.empty(cop(Co), device=x.device, dtype=torch.float32)
+    stat = torch.empty(stat_floats(Ci, Co), device=x.device, dtype=torch.float32)
+    call("coskad_layer_train_stats_f32", ptr(x), ptr(A), ptr(Tm), ptr(in_slope), ptr(Wt), ptr(bt), ptr(gt),
+         ptr(bet), ptr(rm_t), ptr(rv_t), ptr(nbt_t), ptr(Wr), ptr(br), ptr(gr), ptr(ber), ptr(rm_r),
+         ptr(rv_r), ptr(nbt_r), ctypes.c_float(momentum), ptr(wfold), ptr(bias), ptr(stat), ptr(ws),
+         ctypes.c_size_t(ws.numel() * ws.element_size()), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    return wfold, bias, stat

@@ -46,6 +46,27 @@ int coskad_layer_apply_f32(const float* in, float* out, const float* A, const fl
                            const float* out_slope, int B, int Ci, int Co, int T, int V,
                            hipStream_t stream);
 
+/* ---- train-mode BatchNorm statistics -------------------------------------------------- */
+
+/* Bytes of scratch `ws` that coskad_layer_train_stats_f32 needs for C_in = Ci. */
+size_t coskad_train_stats_ws_bytes(int Ci);
+/* Floats in the per-layer stat block saved for the backward pass. */
+int coskad_stat_floats(int Ci, int Co);
+
+/* Batch statistics of both BatchNorm2d of one ST_GCNN_layer in training mode
+ * (stsgcn.py:65,76 via 106-108), from the moments of the conv inputs; writes the folded
+ * weights for coskad_layer_apply_f32, the stat block for the backward pass, and updates
+ * running_mean / running_var (unbiased) / num_batches_tracked in place (NULL to skip).
+ * Wr == NULL: identity residual (stsgcn.py:79-80). */
+int coskad_layer_train_stats_f32(const float* in, const float* A, const float* Tm, const float* in_slope,
+                                 const float* Wt, const float* bt, const float* gamma_t,
+                                 const float* beta_t, float* rmean_t, float* rvar_t, long long* nbt_t,
+                                 const float* Wr, const float* br, const float* gamma_r,
+                                 const float* beta_r, float* rmean_r, float* rvar_r, long long* nbt_r,
+                                 float momentum, float* wfold, float* bias, float* stat, void* ws,
+                                 size_t ws_bytes, int B, int Ci, int Co, int T, int V,
+                                 hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,3 +74,62 @@ def test_eval_layers_ragged_batch():
     acts = _eval_chain(st, x)
     for i, (a, r) in enumerate(zip(acts, ref)):
         np.testing.assert_allclose(a.numpy(), r.numpy(), rtol=1e-4, atol=1e-4, err_msg=f"layer {i}")
+
+
+def _train_chain(st, x):
+    """train-mode encoder: batch stats (moments kernels) + apply; returns per-layer activations
+    and the updated BN buffers."""
+    from coskad_amd import ops
+    n = R.n_layers(st, "encoder.model")
+    h, slope, acts, bufs = dev(x), None, [], {}
+    ws = torch.empty(ops.train_stats_ws_bytes(64), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        p = f"encoder.model.{i}"
+        d = {k[len(p) + 1:]: dev(v) for k, v in st.items() if k.startswith(p + ".")}
+        Co, Ci = d["tcn.0.weight"].shape[:2]
+        has_res = "residual.0.weight" in d
+        wfold, bias, stat = ops.layer_train_stats(
+            h, d["gcn.A"], d["gcn.T"], slope,
+            d["tcn.0.weight"].reshape(Co, Ci), d["tcn.0.bias"], d["tcn.1.weight"], d["tcn.1.bias"],
+            d["tcn.1.running_mean"], d["tcn.1.running_var"], d["tcn.1.num_batches_tracked"],
+            d["residual.0.weight"].reshape(Co, Ci) if has_res else None, d.get("residual.0.bias"),
+            d.get("residual.1.weight"), d.get("residual.1.bias"), d.get("residual.1.running_mean"),
+            d.get("residual.1.running_var"), d.get("residual.1.num_batches_tracked"), ws)
+        u = ops.layer_apply(h, d["gcn.A"], d["gcn.T"], wfold, bias, Co, in_slope=slope)
+        acts.append(torch.where(u > 0, u, d["prelu.weight"] * u).cpu())
+        for k in d:
+            if "running" in k or "num_batches" in k:
+                bufs[f"{p}.{k}"] = d[k].cpu()
+        h, slope = u, d["prelu.weight"]
+    return acts, bufs
+
+
+@pytest.mark.parametrize("name", ["stse_default.npz", "stse_v25.npz", "stse_b1.npz"])
+def test_train_forward_matches_oracle_and_golden(golden, name):
+    g = golden(name)
+    st = state_from(g)
+    x = torch.from_numpy(g["x"])
+    st_ref = {k: v.clone() for k, v in st.items()}
+    ref = []
+    with torch.no_grad():
+        zref = R.stse_encode(x, st_ref, training=True, collect=ref)
+    np.testing.assert_allclose(zref.numpy(), g["train.z"], rtol=1e-5, atol=2e-6)  # oracle == reference
+    acts, bufs = _train_chain(st, x)
+    for i, (a, r) in enumerate(zip(acts, ref)):
+        np.testing.assert_allclose(a.numpy(), r.numpy(), rtol=1e-4, atol=1e-4, err_msg=f"layer {i}")
+    for k, v in bufs.items():
+        np.testing.assert_allclose(v.numpy(), g["sd1." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_train_forward_large_ragged_batch():
+    st = R.init_stse_state(seed=5)
+    x = R.synthetic_clips(1031, seed=6)  # > kMaxGrid tiles on the Ci=32 layers, ragged
+    st_ref = {k: v.clone() for k, v in st.items()}
+    ref = []
+    with torch.no_grad():
+        R.stse_encode(x, st_ref, training=True, collect=ref)
+    acts, bufs = _train_chain(st, x)
+    for i, (a, r) in enumerate(zip(acts, ref)):
+        np.testing.assert_allclose(a.numpy(), r.numpy(), rtol=1e-4, atol=1e-4, err_msg=f"layer {i}")
+    for k, v in bufs.items():
+        np.testing.assert_allclose(v.numpy(), st_ref[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
