@@ -1,0 +1,238 @@
+// Bottleneck projection of STSE (reference models/sts/ae.py:97-101,157):
+//     z[n][j] = b[j] + sum_k W[j][k] * PReLU(U[n][k]),   k = (c,t,v) flattened, K = hid*T*V
+// and its backward.  The encoder's last layer hands over its PRE-activation U; PReLU is
+// applied on load (forward) and its derivative on store (backward).
+//
+// Skinny GEMM (latent <= 16 columns) that must stream U at HBM rate:
+//   forward : one block = 16 clips; the 4 waves split K; v_mfma_f32_16x16x4_f32 with
+//             A = PReLU(U) [clip][k], B = W^T [k][latent]; every lane loads float4 along k
+//             (the 4 components feed 4 successive MFMAs, so any k-permutation is consistent).
+//   backward: one wave = a 64-column slab of K; per 16-clip block it loads U once (float4 per
+//             lane) and uses it three ways: PReLU(U) as the B operand of dW += dz^T X, U's sign
+//             as the mask of dU = (dz W) * PReLU'(U), and U itself for the slope gradient.
+#include "tile_ops.h"
+
+namespace coskad {
+
+constexpr int kBtlWaves = kBlock / 64;
+
+__global__ __launch_bounds__(kBlock) void k_btlnk_fwd(const float* __restrict__ U,
+                                                     const float* __restrict__ W,
+                                                     const float* __restrict__ bias,
+                                                     const float* __restrict__ slope,
+                                                     float* __restrict__ z, int B, int K, int L) {
+  __shared__ float red[kBtlWaves][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int n = blockIdx.x * 16 + i;
+  const bool pre = slope != nullptr;
+  const float a = pre ? slope[0] : 0.f;
+  const bool rowok = n < B, colok = i < L;
+  const float* up = U + (size_t)(rowok ? n : 0) * K;
+  const float* wp = W + (size_t)(colok ? i : 0) * K;
+  const int nsteps = ceil_div(K, 16);
+  const int per = ceil_div(nsteps, kBtlWaves);
+  const int s0 = wave * per, s1 = min(nsteps, s0 + per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int s = s0; s < s1; ++s) {
+    const int k = s * 16 + 4 * kk;
+    float4 x = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) {
+      if (rowok) x = *reinterpret_cast<const float4*>(up + k);
+      if (colok) w = *reinterpret_cast<const float4*>(wp + k);
+    }
+    if (pre) { x.x = prelu_f(x.x, a); x.y = prelu_f(x.y, a); x.z = prelu_f(x.z, a); x.w = prelu_f(x.w, a); }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, w.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, w.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, w.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, w.w, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+  __syncthreads();
+  const int e = threadIdx.x, row = e >> 4, col = e & 15;
+  const int nn = blockIdx.x * 16 + row;
+  if (nn < B && col < L) {
+    float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    z[(size_t)nn * L + col] = s + (bias ? bias[col] : 0.f);
+  }
+}
+
+// grid = (ceil(K/256), S clip-chunks).  dWp: [S][L][K] partials, dap: [gridDim.x*gridDim.y].
+__global__ __launch_bounds__(kBlock) void k_btlnk_bwd(const float* __restrict__ U,
+                                                     const float* __restrict__ W,
+                                                     const float* __restrict__ dz,
+                                                     const float* __restrict__ slope,
+                                                     float* __restrict__ dU, float* __restrict__ dWp,
+                                                     float* __restrict__ dap, int B, int K, int L,
+                                                     int chunk) {
+  __shared__ float sred[kBtlWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int kc = (blockIdx.x * kBtlWaves + wave) * 64 + 4 * c;  // this lane's 4 columns
+  const bool kok = kc < K;
+  const bool pre = slope != nullptr;
+  const float a = pre ? slope[0] : 0.f;
+  // W fragments of the slab: B[kk = j][col] for j0 = 0,4,8,12 -> lane (c, q) holds W[j0+q][kc..kc+3]
+  float4 wf[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int j = 4 * g + q;
+    wf[g] = (kok && j < L) ? *reinterpret_cast<const float4*>(W + (size_t)j * K + kc)
+                           : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 dw[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) dw[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float da = 0.f;
+  const int nbeg = blockIdx.y * chunk, nend = min(B, nbeg + chunk);
+  for (int n0 = nbeg; n0 < nend; n0 += 16) {
+    // dX tile: A[i = clip][kk = j] = dz[n0+i][4g+kk]
+    f32x4 dx[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nn = n0 + c, j = 4 * g + q;
+      const float av = (nn < nend && j < L) ? dz[(size_t)nn * L + j] : 0.f;
+      dx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[g].x, dx[0], 0, 0, 0);
+      dx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[g].y, dx[1], 0, 0, 0);
+      dx[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[g].z, dx[2], 0, 0, 0);
+      dx[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wf[g].w, dx[3], 0, 0, 0);
+    }
+    // step s: lane group q owns clip n0 + 4q + s  (K-order of the dW MFMA is ours to choose;
+    // this choice makes the U load serve operand, mask and store address at once)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int nn = n0 + 4 * q + s;
+      const bool ok = kok && nn < nend;
+      float4 u = ok ? *reinterpret_cast<const float4*>(U + (size_t)nn * K + kc) : float4{0.f, 0.f, 0.f, 0.f};
+      float4 x = u;
+      if (pre) { x.x = prelu_f(u.x, a); x.y = prelu_f(u.y, a); x.z = prelu_f(u.z, a); x.w = prelu_f(u.w, a); }
+      // dW[j][k] += dz[n][j] * x[n][k]:  A[i = j][kk = q] = dz[n0+4q+s][j = c]
+      const float dzv = (nn < nend && c < L) ? dz[(size_t)nn * L + c] : 0.f;
+      dw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x.x, dw[0], 0, 0, 0);
+      dw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x.y, dw[1], 0, 0, 0);
+      dw[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x.z, dw[2], 0, 0, 0);
+      dw[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, x.w, dw[3], 0, 0, 0);
+      // dX row (4q + s) of the tile = register s of dx[m], column c, k = kc + m
+      float4 g = {dx[0][s], dx[1][s], dx[2][s], dx[3][s]};
+      if (pre) {
+        da += (u.x < 0.f ? g.x * u.x : 0.f) + (u.y < 0.f ? g.y * u.y : 0.f) +
+              (u.z < 0.f ? g.z * u.z : 0.f) + (u.w < 0.f ? g.w * u.w : 0.f);
+        g.x = u.x > 0.f ? g.x : a * g.x; g.y = u.y > 0.f ? g.y : a * g.y;
+        g.z = u.z > 0.f ? g.z : a * g.z; g.w = u.w > 0.f ? g.w : a * g.w;
+      }
+      if (ok) *reinterpret_cast<float4*>(dU + (size_t)nn * K + kc) = g;
+    }
+  }
+  // dW partial: tile m, reg r <-> j = 4q + r, k = kc + m
+  if (kok) {
+    float* dst = dWp + (size_t)blockIdx.y * L * K;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 4 * q + r;
+      if (j < L) *reinterpret_cast<float4*>(dst + (size_t)j * K + kc) = float4{dw[0][r], dw[1][r], dw[2][r], dw[3][r]};
+    }
+  }
+  da = wave_sum(da);
+  if (lane == 0) sred[wave] = da;
+  __syncthreads();
+  if (threadIdx.x == 0) dap[blockIdx.y * gridDim.x + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+// out[e] (+)= sum_p partials[p][e]; fp64 accumulate, fp32 store.
+__global__ __launch_bounds__(256) void k_reduce_partials_f32(const float* __restrict__ partials, int P,
+                                                              size_t E, float* __restrict__ out,
+                                                              int accumulate) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  double s = 0.0;
+  for (int p = 0; p < P; ++p) s += (double)partials[(size_t)p * E + e];
+  out[e] = accumulate ? out[e] + (float)s : (float)s;
+}
+
+// single-block: out[0] (+)= sum of n floats
+__global__ __launch_bounds__(256) void k_sum_scalar(const float* __restrict__ v, int n,
+                                                     float* __restrict__ out, int accumulate) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)v[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)sh[0] : (float)sh[0];
+}
+
+// db[j] = sum_n dz[n][j]   (single block; B*L is tiny next to the activations)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dz, int B, int L,
+                                                 float* __restrict__ db, int accumulate) {
+  __shared__ double sh[256];
+  const int j = threadIdx.x % L, sl = threadIdx.x / L, nsl = 256 / L;
+  double s = 0.0;
+  if (sl < nsl)
+    for (int n = sl; n < B; n += nsl) s += (double)dz[(size_t)n * L + j];
+  sh[threadIdx.x] = sl < nsl ? s : 0.0;
+  __syncthreads();
+  if (threadIdx.x < L) {
+    double t = 0.0;
+    for (int k = 0; k < nsl; ++k) t += sh[k * L + threadIdx.x];
+    db[threadIdx.x] = accumulate ? db[threadIdx.x] + (float)t : (float)t;
+  }
+}
+
+static int btl_chunks(int B) {
+  int s = ceil_div(B, 256);
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+}  // namespace coskad
+
+using namespace coskad;
+
+extern "C" {
+
+int coskad_btlnk_fwd_f32(const float* U, const float* W, const float* bias, const float* slope, float* z,
+                         int B, int K, int L, hipStream_t stream) {
+  if (!U || !W || !z) return fail(COSKAD_ERR_ARG, "btlnk_fwd: null pointer");
+  if (B <= 0 || K <= 0 || L <= 0) return fail(COSKAD_ERR_ARG, "btlnk_fwd: B=%d K=%d L=%d", B, K, L);
+  if (L > 16) return fail(COSKAD_ERR_SHAPE, "btlnk_fwd: latent_dim=%d > 16 not supported", L);
+  if (K % 4) return fail(COSKAD_ERR_SHAPE, "btlnk_fwd: K=%d must be a multiple of 4", K);
+  hipLaunchKernelGGL(k_btlnk_fwd, dim3(ceil_div(B, 16)), dim3(kBlock), 0, stream, U, W, bias, slope, z, B, K, L);
+  return check_launch("btlnk_fwd");
+}
+
+size_t coskad_btlnk_bwd_ws_bytes(int B, int K, int L) {
+  const int S = btl_chunks(B);
+  return ((size_t)S * L * K + (size_t)S * ceil_div(K, 256) + 64) * sizeof(float);
+}
+
+/* dU = (dz W) * PReLU'(U);  dW (+)= dz^T PReLU(U);  db (+)= sum dz;  dslope (+)= sum (dz W) U [U<0] */
+int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const float* slope, float* dU,
+                         float* dW, float* db, float* dslope, void* ws, size_t ws_bytes, int accumulate,
+                         int B, int K, int L, hipStream_t stream) {
+  if (!U || !W || !dz || !dU || !dW || !ws) return fail(COSKAD_ERR_ARG, "btlnk_bwd: null pointer");
+  if (B <= 0 || K <= 0 || L <= 0) return fail(COSKAD_ERR_ARG, "btlnk_bwd: B=%d K=%d L=%d", B, K, L);
+  if (L > 16) return fail(COSKAD_ERR_SHAPE, "btlnk_bwd: latent_dim=%d > 16 not supported", L);
+  if (K % 4) return fail(COSKAD_ERR_SHAPE, "btlnk_bwd: K=%d must be a multiple of 4", K);
+  if (ws_bytes < coskad_btlnk_bwd_ws_bytes(B, K, L)) return fail(COSKAD_ERR_WORKSPACE, "btlnk_bwd: workspace too small");
+  const int S = btl_chunks(B);
+  const int chunk = round_up(ceil_div(B, S), 16);
+  const int gx = ceil_div(K, 256);
+  float* dWp = reinterpret_cast<float*>(ws);
+  float* dap = dWp + (size_t)S * L * K;
+  hipLaunchKernelGGL(k_btlnk_bwd, dim3(gx, S), dim3(kBlock), 0, stream, U, W, dz, slope, dU, dWp, dap, B, K, L, chunk);
+  int rc = check_launch("btlnk_bwd");
+  if (rc) return rc;
+  const size_t E = (size_t)L * K;
+  hipLaunchKernelGGL(k_reduce_partials_f32, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, dWp, S, E, dW, accumulate);
+  if (db) hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, stream, dz, B, L, db, accumulate);
+  if (dslope && slope) hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, stream, dap, gx * S, dslope, accumulate);
+  return check_launch("btlnk_bwd_reduce");
+}
+
+}  // extern "C"

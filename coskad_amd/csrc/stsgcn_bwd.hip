@@ -1,0 +1,677 @@
+// Backward of one ST_GCNN_layer in training mode (reference stsgcn.py:94-116 under autograd),
+// recomputing the cheap intermediates instead of saving them.
+//
+// Forward (per position):  Z = gcn(X),  S = Wt Z + bt,  R = Wr X + br,
+//                          U = BN_s(S) + BN_r(R),       next layer's input = PReLU(U).
+// Given dU (gradient w.r.t. the pre-activation U):
+//
+//  1. k_bwd_reduce : batch reductions  sdU = sum dU,  P = sum dU Z^T,  Q = sum dU X^T
+//                    (GEMMs with K = positions -> MFMA f32).  Everything BatchNorm's backward
+//                    needs is linear in these: e.g. sum dU*S = rowdot(Wt, P) + bt*sdU.
+//  2. k_bwd_fold   : one block.  Parameter gradients (dWt, dgamma, dbeta, ...; conv biases in
+//                    front of a train-mode BN get exactly 0) and the coefficient matrices of
+//                    the data path:
+//                        dZ      = Bt dU + Kt Z + kt          (BN_s and conv_t transposed)
+//                        dX_res  = Br dU + Kr X + kr          (BN_r and conv_r transposed)
+//  3. k_bwd_data   : dZ per position, adjoint gcn, + dX_res, then the PReLU derivative of the
+//                    producer layer -> dU_prev; also the slope gradient of that PReLU.
+//                    Optionally stores dZ for step 4.
+//  4. k_bwd_gcn_params : dA[t,v,w] = sum_rows Y[t,v] dZ[t,w],  dT[v,t,q] = sum_rows X[t,v] dY[q,v]
+//                    (GEMMs with K = rows (clip,channel) -> MFMA f32).
+#include "tile_ops.h"
+
+namespace coskad {
+
+constexpr int kMaxGridBwd = 512;
+
+// ---------------------------------------------------------------------------------------
+// 1. reductions.  LDS: X image (nb*Ci rows) then dU image (nb*Co rows) then 1024 scratch.
+//    partial row: [P Co*Ci][Q Co*Ci][sdU Co]
+// ---------------------------------------------------------------------------------------
+template <int T, int V, int NTO, int NTC>
+__global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__ in,
+                                                      const float* __restrict__ dU,
+                                                      const float* __restrict__ Aw,
+                                                      const float* __restrict__ Tw,
+                                                      const float* __restrict__ in_slope,
+                                                      float* __restrict__ partials, int B, int Ci,
+                                                      int Co, int NB, int need_q) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldx = lds;
+  float* ldu = lds + NB * Ci * LD;
+  float* scratch = ldu + NB * Co * LD;
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  f32x4 pacc[NTO][NTC], qacc[NTO][NTC], sacc[NTO], sdummy[NTO];
+  zero_acc(pacc); zero_acc(qacc); zero_acc(sacc); zero_acc(sdummy);
+
+  const int ntiles = ceil_div(B, NB);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int clip0 = tile * NB;
+    const int nb = min(NB, B - clip0);
+    __syncthreads();
+    stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, pre, a_in);
+    stage_rows<T, V>(dU + (size_t)clip0 * Co * TV, ldu, nb * Co * TV, false, 0.f);
+    __syncthreads();
+    if (need_q) {
+      for (int n = 0; n < nb; ++n)
+        outer_accum<T, V, NTO, NTC, false>(ldu + n * Co * LD, Co, ldx + n * Ci * LD, Ci, qacc, sdummy);
+      __syncthreads();
+    }
+    gcn_rows<T, V, false>(ldx, nb * Ci, Aw, Tw);
+    __syncthreads();
+    for (int n = 0; n < nb; ++n)
+      outer_accum<T, V, NTO, NTC, true>(ldu + n * Co * LD, Co, ldx + n * Ci * LD, Ci, pacc, sacc);
+  }
+  float* dst = partials + (size_t)blockIdx.x * (2 * Co * Ci + Co);
+  store_outer<NTO, NTC>(pacc, scratch, dst, Ci, Co, Ci);
+  store_outer<NTO, NTC>(qacc, scratch, dst + Co * Ci, Ci, Co, Ci);
+  store_sums<NTO>(sacc, scratch, dst + 2 * Co * Ci, Co);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials_d(const float* __restrict__ partials, int P, int E,
+                                                            double* __restrict__ out) {
+  __shared__ double sh[256];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  double s = 0.0;
+  if (e < E)
+    for (int p = slice; p < P; p += 4) s += (double)partials[(size_t)p * E + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (slice == 0 && e < E)
+    out[e] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
+
+// ---------------------------------------------------------------------------------------
+// 2. fold.  stat block layout: see stsgcn_train.hip (muX, muZ, WCs, WCr, mean_s, istd_s, mean_r, istd_r)
+//    coef block (floats): [wDZ (Co+Ci)*CiP][kt CiP][wDX (Co+Ci)*CiP][kr CiP]
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline int coef_floats(int Ci, int Co) {
+  const int CiP = round_up(Ci, 16);
+  return 2 * ((Co + Ci) * CiP + CiP);
+}
+
+__device__ __forceinline__ void put(float* dst, float v, int accumulate) { *dst = accumulate ? *dst + v : v; }
+
+__global__ __launch_bounds__(256) void k_bwd_fold(
+    const double* __restrict__ red, double npos, const float* __restrict__ stat,
+    const float* __restrict__ Wt, const float* __restrict__ gs, const float* __restrict__ Wr,
+    const float* __restrict__ gr, float* __restrict__ dWt, float* __restrict__ dbt,
+    float* __restrict__ dgs, float* __restrict__ dbs, float* __restrict__ dWr, float* __restrict__ dbr,
+    float* __restrict__ dgr, float* __restrict__ dbr2, float* __restrict__ coef, int Ci, int Co,
+    int accumulate) {
+  extern __shared__ double shd[];  // k2s[Co], k2r[Co], g1s[Co], g1r[Co], sd[Co]
+  const bool ident = Wr == nullptr;
+  const int CiP = round_up(Ci, 16);
+  const double* P = red;
+  const double* Q = red + Co * Ci;
+  const double* sdU = red + 2 * Co * Ci;
+  const float* muX = stat;
+  const float* muZ = stat + Ci;
+  const float* WCs = stat + 2 * Ci;
+  const float* WCr = WCs + Co * Ci;
+  const float* istd_s = WCr + Co * Ci + Co;
+  const float* istd_r = istd_s + 2 * Co;
+  double* k2s = shd;
+  double* k2r = shd + Co;
+  double* g1s = shd + 2 * Co;
+  double* g1r = shd + 3 * Co;
+  float* wDZ = coef;
+  float* kt = wDZ + (Co + Ci) * CiP;
+  float* wDX = kt + CiP;
+  float* kr = wDX + (Co + Ci) * CiP;
+
+  // per-channel BN gradients
+  for (int i = threadIdx.x; i < 2 * Co; i += blockDim.x) {
+    const int b = i / Co, o = i - b * Co;
+    if (b == 1 && ident) { k2r[o] = 0.0; g1r[o] = 1.0; continue; }
+    const float* W = b ? Wr : Wt;
+    const double* M = b ? Q : P;
+    const float* mu = b ? muX : muZ;
+    const double istd = (double)(b ? istd_r : istd_s)[o];
+    const double gamma = (double)(b ? gr : gs)[o];
+    double wp = 0.0, wmu = 0.0;
+    for (int c = 0; c < Ci; ++c) {
+      wp += (double)W[o * Ci + c] * M[o * Ci + c];
+      wmu += (double)W[o * Ci + c] * (double)mu[c];
+    }
+    const double sdus = wp - wmu * sdU[o];       // sum dU * (conv_out - mean)
+    const double dgamma = istd * sdus;
+    put((b ? dgr : dgs) + o, (float)dgamma, accumulate);
+    put((b ? dbr2 : dbs) + o, (float)sdU[o], accumulate);
+    float* dbias = b ? dbr : dbt;
+    if (dbias) put(dbias + o, 0.f, accumulate);  // conv bias in front of a train-mode BN: exactly 0
+    (b ? g1r : g1s)[o] = gamma * istd;
+    (b ? k2r : k2s)[o] = gamma * istd * dgamma * istd / npos;
+  }
+  __syncthreads();
+  // conv weight gradients: dW[o,c] = g1 (M[o,c] - sdU[o] mu[c]) - g1 dgamma istd WC[o,c]
+  //                                = g1 (M[o,c] - sdU[o] mu[c]) - k2 * n * WC[o,c]
+  for (int i = threadIdx.x; i < 2 * Co * Ci; i += blockDim.x) {
+    const int b = i / (Co * Ci);
+    if (b == 1 && ident) break;
+    const int j = i - b * Co * Ci, o = j / Ci, c = j - o * Ci;
+    const double* M = b ? Q : P;
+    const float* mu = b ? muX : muZ;
+    const float* WC = b ? WCr : WCs;
+    const double g1 = (b ? g1r : g1s)[o], k2 = (b ? k2r : k2s)[o];
+    const double v = g1 * (M[j] - sdU[o] * (double)mu[c]) - k2 * npos * (double)WC[j];
+    put((b ? dWr : dWt) + j, (float)v, accumulate);
+  }
+  // data-path coefficients.  rows 0..Co-1: B[c][o] = g1[o] W[o,c];  rows Co..Co+Ci-1: K[c][c'] = -sum_o W[o,c] k2[o] W[o,c']
+  for (int i = threadIdx.x; i < 2 * (Co + Ci) * CiP; i += blockDim.x) {
+    const int b = i / ((Co + Ci) * CiP);
+    const int j = i - b * (Co + Ci) * CiP;
+    const int row = j / CiP, c = j - row * CiP;
+    const float* W = b ? Wr : Wt;
+    float v = 0.f;
+    if (c < Ci) {
+      if (b == 1 && ident) {
+        v = (row < Co && row == c) ? 1.f : 0.f;
+      } else if (row < Co) {
+        v = (float)((b ? g1r : g1s)[row] * (double)W[row * Ci + c]);
+      } else {
+        const int c2 = row - Co;
+        const double* k2 = b ? k2r : k2s;
+        double acc = 0.0;
+        for (int o = 0; o < Co; ++o) acc += (double)W[o * Ci + c] * k2[o] * (double)W[o * Ci + c2];
+        v = (float)(-acc);
+      }
+    }
+    (b ? wDX : wDZ)[j] = v;
+  }
+  // constants: k[c] = -sum_o W[o,c] g1[o] sdU[o]/n - sum_c' K[c][c'] mu[c']
+  //                 = -sum_o W[o,c] (g1[o] sdU[o]/n - k2[o] (W[o] . mu))
+  for (int i = threadIdx.x; i < 2 * CiP; i += blockDim.x) {
+    const int b = i / CiP, c = i - b * CiP;
+    float v = 0.f;
+    if (c < Ci && !(b == 1 && ident)) {
+      const float* W = b ? Wr : Wt;
+      const float* mu = b ? muX : muZ;
+      const double* g1 = b ? g1r : g1s;
+      const double* k2 = b ? k2r : k2s;
+      double acc = 0.0;
+      for (int o = 0; o < Co; ++o) {
+        double wmu = 0.0;
+        for (int c2 = 0; c2 < Ci; ++c2) wmu += (double)W[o * Ci + c2] * (double)mu[c2];
+        acc += (double)W[o * Ci + c] * (g1[o] * sdU[o] / npos - k2[o] * wmu);
+      }
+      v = (float)(-acc);
+    }
+    (b ? kr : kt)[c] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// 3. data path.  LDS: one Ci-row image per clip (+ 64 floats).  CIP = Ci rounded up to a
+//    power of two (register arrays need static bounds).
+// ---------------------------------------------------------------------------------------
+template <int T, int V, int CIP>
+__global__ __launch_bounds__(kBlock) void k_bwd_data(
+    const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
+    const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
+    float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
+    int Co, int NB) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int CH = CIP < 16 ? CIP : 16;  // output-channel chunk of the position phases
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float sred[kBlock / 64];
+  const int CiP = round_up(Ci, 16);
+  const float* wDZ = coef;
+  const float* kt = wDZ + (Co + Ci) * CiP;
+  const float* wDX = kt + CiP;
+  const float* kr = wDX + (Co + Ci) * CiP;
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const int clip0 = blockIdx.x * NB;
+  const int nb = min(NB, B - clip0);
+  const int rows = nb * Ci;
+  const float* gin = in + (size_t)clip0 * Ci * TV;
+  const float* gdu = dU + (size_t)clip0 * Co * TV;
+
+  stage_rows<T, V>(gin, lds, rows * TV, pre, a_in);
+  __syncthreads();
+  gcn_rows<T, V, false>(lds, rows, Aw, Tw);
+  __syncthreads();
+
+  const int P = nb * TV;
+  const int rounds = ceil_div(P, kBlock);
+  // position phase A: dZ[:,p] = kt + Bt dU[:,p] + Kt Z[:,p], in place over Z
+  for (int r = 0; r < rounds; ++r) {
+    const int pos = r * kBlock + threadIdx.x;
+    const bool act = pos < P;
+    const int pc = act ? pos : 0;
+    const int n = pc / TV, p = pc - n * TV;
+    float* zcol = lds + (n * Ci) * LD + p;
+    const float* ducol = gdu + (size_t)n * Co * TV + p;
+    float zr[CIP], out[CIP];
+#pragma unroll
+    for (int c = 0; c < CIP; ++c) {
+      zr[c] = c < Ci ? zcol[c * LD] : 0.f;
+      out[c] = kt[c < CiP ? c : 0];
+    }
+    for (int o0 = 0; o0 < Co; o0 += 8) {
+      float dr[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dr[k] = (o0 + k < Co) ? ducol[(size_t)(o0 + k) * TV] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float* w = wDZ + (o0 + k < Co ? o0 + k : 0) * CiP;
+#pragma unroll
+        for (int c = 0; c < CIP; ++c) out[c] = fmaf(w[c < CiP ? c : 0], dr[k], out[c]);
+      }
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < CIP; ++c2) {
+      const float* w = wDZ + (Co + (c2 < Ci ? c2 : 0)) * CiP;
+#pragma unroll
+      for (int c = 0; c < CIP; ++c) out[c] = fmaf(w[c < CiP ? c : 0], zr[c2], out[c]);
+    }
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < CIP; ++c)
+        if (c < Ci) zcol[c * LD] = out[c];
+    }
+  }
+  __syncthreads();
+  if (dZout) unstage_rows<T, V>(dZout + (size_t)clip0 * Ci * TV, lds, rows * TV);
+  float da = 0.f;
+  if (dIn) {
+    gcn_rows<T, V, true>(lds, rows, Aw, Tw);  // (barrier inside; unstage above only read)
+    __syncthreads();
+    // position phase B: dX = gcn^T(dZ) + kr + Br dU + Kr X ; dU_prev = dX * PReLU'(U_prev)
+    for (int r = 0; r < rounds; ++r) {
+      const int pos = r * kBlock + threadIdx.x;
+      const bool act = pos < P;
+      const int pc = act ? pos : 0;
+      const int n = pc / TV, p = pc - n * TV;
+      const float* gcol = lds + (n * Ci) * LD + p;
+      const float* ducol = gdu + (size_t)n * Co * TV + p;
+      const float* ucol = gin + (size_t)n * Ci * TV + p;
+      float* dcol = dIn + ((size_t)(clip0 + n) * Ci) * TV + p;
+      float ur[CIP];
+#pragma unroll
+      for (int c = 0; c < CIP; ++c) ur[c] = c < Ci ? ucol[(size_t)c * TV] : 0.f;
+      for (int c0 = 0; c0 < Ci; c0 += CH) {
+        float acc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = kr[c0 + j] + ((c0 + j < Ci) ? gcol[(c0 + j) * LD] : 0.f);
+        for (int o0 = 0; o0 < Co; o0 += 8) {
+          float dr[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dr[k] = (o0 + k < Co) ? ducol[(size_t)(o0 + k) * TV] : 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float* w = wDX + (o0 + k < Co ? o0 + k : 0) * CiP + c0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[j] = fmaf(w[j], dr[k], acc[j]);
+          }
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < CIP; ++c2) {
+          const float x = pre ? prelu_f(ur[c2], a_in) : ur[c2];
+          const float* w = wDX + (Co + (c2 < Ci ? c2 : 0)) * CiP + c0;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[j] = fmaf(w[j], c2 < Ci ? x : 0.f, acc[j]);
+        }
+        // select ur[c0 + j] with static indices
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          float u = 0.f;
+#pragma unroll
+          for (int c = 0; c < CIP; ++c) u = (c == c0 + j) ? ur[c] : u;
+          float g = acc[j];
+          if (pre) {
+            if (act && c0 + j < Ci && u < 0.f) da = fmaf(g, u, da);
+            g = u > 0.f ? g : a_in * g;
+          }
+          if (act && c0 + j < Ci) dcol[(size_t)(c0 + j) * TV] = g;
+        }
+      }
+    }
+  }
+  if (da_partials) {
+    da = wave_sum(da);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = da;
+    __syncthreads();
+    if (threadIdx.x == 0) da_partials[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// 4. gcn parameter gradients.  LDS: image Y/X (nb*Ci rows) + image dZ/dY (nb*Ci rows).
+//    MFMA with K = rows: A[i][k] = img1[row k][col a0+i], B[k][j] = img2[row k][col b0+j].
+//    waves own disjoint frames (dA) / joints (dT): no cross-wave reduction.
+//    partial row: [dA T*V*V][dT V*T*T]
+// ---------------------------------------------------------------------------------------
+template <int T, int V, int NTA, int NTB>
+__device__ __forceinline__ void rowk_accum(const float* img1, int a0, int na, const float* img2, int b0,
+                                           int nbcols, int rows, f32x4 (&acc)[NTA][NTB]) {
+  constexpr int LD = Geo<T, V>::LD;
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, k = lane >> 4;
+  for (int r0 = 0; r0 < rows; r0 += 4) {
+    const bool rok = r0 + k < rows;
+    const int row = rok ? r0 + k : 0;
+    float a[NTA], b[NTB];
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) {
+      const int col = 16 * ta + i;
+      a[ta] = (rok && col < na) ? img1[row * LD + a0 + col] : 0.f;
+    }
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+      const int col = 16 * tb + i;
+      b[tb] = (rok && col < nbcols) ? img2[row * LD + b0 + col] : 0.f;
+    }
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < NTB; ++tb)
+        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+  }
+}
+
+template <int T, int V>
+__global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restrict__ in,
+                                                          const float* __restrict__ dZ,
+                                                          const float* __restrict__ Aw,
+                                                          const float* __restrict__ Tw,
+                                                          const float* __restrict__ in_slope,
+                                                          float* __restrict__ partials, int B, int Ci,
+                                                          int NB) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int NW = kBlock / 64;
+  constexpr int NTV = (V + 15) / 16, NTT = (T + 15) / 16;
+  constexpr int TPW = (T + NW - 1) / NW, VPW = (V + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* img1 = lds;
+  float* img2 = lds + NB * Ci * LD;
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int tbeg = (T * wave) / NW, tend = (T * (wave + 1)) / NW;
+  const int vbeg = (V * wave) / NW, vend = (V * (wave + 1)) / NW;
+  f32x4 accA[TPW][NTV][NTV], accT[VPW][NTT][NTT];
+#pragma unroll
+  for (int a = 0; a < TPW; ++a) zero_acc(accA[a]);
+#pragma unroll
+  for (int a = 0; a < VPW; ++a) zero_acc(accT[a]);
+
+  const int ntiles = ceil_div(B, NB);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int clip0 = tile * NB;
+    const int nb = min(NB, B - clip0);
+    const int rows = nb * Ci;
+    const float* gin = in + (size_t)clip0 * Ci * TV;
+    __syncthreads();
+    stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
+    stage_rows<T, V>(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
+    __syncthreads();
+    mix_rows<T, V, true, false>(img1, rows, Tw);  // Y = temporal(X)
+    __syncthreads();
+    // dA[t] += Y[:, t, :]^T dZ[:, t, :]
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      const int t = tbeg + tt;
+      if (t < tend) rowk_accum<T, V, NTV, NTV>(img1, t * V, V, img2, t * V, V, rows, accA[tt]);
+    }
+    __syncthreads();
+    mix_rows<T, V, false, true>(img2, rows, Aw);  // dY = spatial^T(dZ)
+    stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);  // X again (img1 is free: dA is done)
+    __syncthreads();
+    // dT[v][t][q] += sum_rows X[t*V+v] dY[q*V+v]: columns strided by V -> gather through a0 = v, stride V
+#pragma unroll
+    for (int vv = 0; vv < VPW; ++vv) {
+      const int v = vbeg + vv;
+      if (v < vend) {
+        const int i = lane & 15, k = lane >> 4;
+        for (int r0 = 0; r0 < rows; r0 += 4) {
+          const bool rok = r0 + k < rows;
+          const int row = rok ? r0 + k : 0;
+          float a[NTT], b[NTT];
+#pragma unroll
+          for (int ta = 0; ta < NTT; ++ta) {
+            const int t = 16 * ta + i;
+            a[ta] = (rok && t < T) ? img1[row * LD + t * V + v] : 0.f;
+            b[ta] = (rok && t < T) ? img2[row * LD + t * V + v] : 0.f;
+          }
+#pragma unroll
+          for (int ta = 0; ta < NTT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NTT; ++tb)
+              accT[vv][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], accT[vv][ta][tb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // store: D[row = 4*(lane>>4)+r][col = lane&15]
+  float* dstA = partials + (size_t)blockIdx.x * (T * V * V + V * T * T);
+  float* dstT = dstA + T * V * V;
+  const int col = lane & 15, rg = lane >> 4;
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int t = tbeg + tt;
+    if (t < tend) {
+#pragma unroll
+      for (int ta = 0; ta < NTV; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NTV; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int v = 16 * ta + 4 * rg + r, w = 16 * tb + col;
+            if (v < V && w < V) dstA[(t * V + v) * V + w] = accA[tt][ta][tb][r];
+          }
+    }
+  }
+#pragma unroll
+  for (int vv = 0; vv < VPW; ++vv) {
+    const int v = vbeg + vv;
+    if (v < vend) {
+#pragma unroll
+      for (int ta = 0; ta < NTT; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NTT; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int t = 16 * ta + 4 * rg + r, q = 16 * tb + col;
+            if (t < T && q < T) dstT[(v * T + t) * T + q] = accT[vv][ta][tb][r];
+          }
+    }
+  }
+}
+
+// out[e] (+)= sum_p partials[p*Erow + offset + e],  e < count
+__global__ __launch_bounds__(256) void k_reduce_to_f32(const float* __restrict__ partials, int P, int Erow,
+                                                        int offset, int count, float* __restrict__ out,
+                                                        int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  double s = 0.0;
+  for (int p = 0; p < P; ++p) s += (double)partials[(size_t)p * Erow + offset + e];
+  out[e] = accumulate ? out[e] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(256) void k_sum_to(const float* __restrict__ v, int n, float* __restrict__ out,
+                                                 int accumulate) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)v[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)sh[0] : (float)sh[0];
+}
+
+static int nb_for(int rows_per_clip, int B, int LD, int budget) {
+  int nb = rows_per_clip >= 64 ? 1 : 64 / rows_per_clip;
+  if (nb < 1) nb = 1;
+  while (nb > 1 && (size_t)nb * rows_per_clip * LD * 4 > (size_t)budget) --nb;
+  if (nb > B) nb = B;
+  return nb;
+}
+
+// workspace layout (bytes): [partials: kMaxGridBwd * Emax floats][red: Emax doubles][coef floats][da partials]
+struct BwdWs {
+  float* partials;
+  double* red;
+  float* coef;
+  float* dap;
+  float* dz;
+};
+
+static size_t bwd_emax(int Ci, int Co, int T, int V) {
+  const size_t e1 = 2 * (size_t)Co * Ci + Co;
+  const size_t e2 = (size_t)T * V * V + (size_t)V * T * T;
+  return e1 > e2 ? e1 : e2;
+}
+
+size_t layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V) {
+  const size_t E = bwd_emax(Ci, Co, T, V);
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  return al(kMaxGridBwd * E * sizeof(float)) + al(E * sizeof(double)) +
+         al(coef_floats(Ci, Co) * sizeof(float)) + al((size_t)(B + 1) * sizeof(float)) +
+         al((size_t)B * Ci * T * V * sizeof(float));
+}
+
+static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
+  const size_t E = bwd_emax(Ci, Co, T, V);
+  char* p = reinterpret_cast<char*>(ws);
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  BwdWs w;
+  w.partials = reinterpret_cast<float*>(p); p += al(kMaxGridBwd * E * sizeof(float));
+  w.red = reinterpret_cast<double*>(p);     p += al(E * sizeof(double));
+  w.coef = reinterpret_cast<float*>(p);     p += al(coef_floats(Ci, Co) * sizeof(float));
+  w.dap = reinterpret_cast<float*>(p);      p += al((size_t)(B + 1) * sizeof(float));
+  w.dz = reinterpret_cast<float*>(p);
+  return w;
+}
+
+template <int T, int V>
+static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, const float* Tw,
+                            const float* in_slope, const float* stat, const float* Wt, const float* gs,
+                            const float* Wr, const float* gr, float* dIn, float* dA, float* dT, float* dWt,
+                            float* dbt, float* dgs, float* dbs, float* dWr, float* dbr, float* dgr,
+                            float* dbr2, float* dslope_in, void* ws, size_t ws_bytes, int accumulate,
+                            int B, int Ci, int Co, hipStream_t st) {
+  constexpr int LD = Geo<T, V>::LD, TV = Geo<T, V>::TV;
+  if (Ci > 64 || Co > 64) return fail(COSKAD_ERR_SHAPE, "layer_bwd: channels (%d,%d) > 64 not supported", Ci, Co);
+  if (ws_bytes < layer_bwd_ws_bytes(B, Ci, Co, T, V))
+    return fail(COSKAD_ERR_WORKSPACE, "layer_bwd: workspace %zu < %zu bytes", ws_bytes, layer_bwd_ws_bytes(B, Ci, Co, T, V));
+  BwdWs w = carve(ws, B, Ci, Co, T, V);
+  int rc;
+  // 1. reductions
+  {
+    const int E = 2 * Co * Ci + Co;
+    const int NB = nb_for(Ci + Co, B, LD, 150 * 1024);
+    const size_t lds = ((size_t)NB * (Ci + Co) * LD + 1024) * sizeof(float);
+    if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
+    const int ntiles = ceil_div(B, NB);
+    const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
+    const int nto = ceil_div(Co, 16), ntc = ceil_div(Ci, 16);
+    const int need_q = Wr != nullptr;
+#define LAUNCH_R(NTO, NTC)                                                                              \
+  do {                                                                                                  \
+    auto k = k_bwd_reduce<T, V, NTO, NTC>;                                                              \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dU, Aw, Tw, in_slope, w.partials, B,    \
+                       Ci, Co, NB, need_q);                                                             \
+  } while (0)
+#define LAUNCH_R_O(NTO)                                          \
+  do {                                                           \
+    if (ntc == 1) LAUNCH_R(NTO, 1);                              \
+    else if (ntc == 2) LAUNCH_R(NTO, 2);                         \
+    else if (ntc == 3) LAUNCH_R(NTO, 3);                         \
+    else LAUNCH_R(NTO, 4);                                       \
+  } while (0)
+    if (nto == 1) LAUNCH_R_O(1);
+    else if (nto == 2) LAUNCH_R_O(2);
+    else if (nto == 3) LAUNCH_R_O(3);
+    else LAUNCH_R_O(4);
+#undef LAUNCH_R_O
+#undef LAUNCH_R
+    if ((rc = check_launch("bwd_reduce"))) return rc;
+    hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(256), 0, st, w.partials, grid, E, w.red);
+    if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+  }
+  // 2. fold
+  hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(256), 4 * Co * sizeof(double), st, w.red, (double)B * TV, stat,
+                     Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate);
+  if ((rc = check_launch("bwd_fold"))) return rc;
+  // 3. data path
+  int grid_d;
+  {
+    const int NB = nb_for(Ci, B, LD, 60 * 1024);
+    const size_t lds = (size_t)NB * Ci * LD * sizeof(float);
+    grid_d = ceil_div(B, NB);
+    float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
+#define LAUNCH_D(CIP)                                                                                   \
+  hipLaunchKernelGGL((k_bwd_data<T, V, CIP>), dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw,       \
+                     w.coef, in_slope, dIn, w.dz, dap, B, Ci, Co, NB)
+    if (Ci <= 2) LAUNCH_D(2);
+    else if (Ci <= 4) LAUNCH_D(4);
+    else if (Ci <= 8) LAUNCH_D(8);
+    else if (Ci <= 16) LAUNCH_D(16);
+    else if (Ci <= 32) LAUNCH_D(32);
+    else LAUNCH_D(64);
+#undef LAUNCH_D
+    if ((rc = check_launch("bwd_data"))) return rc;
+    if (dap) {
+      hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, st, dap, grid_d, dslope_in, accumulate);
+      if ((rc = check_launch("bwd_dslope"))) return rc;
+    }
+  }
+  // 4. gcn parameter gradients
+  {
+    const int E = T * V * V + V * T * T;
+    const int NB = nb_for(Ci, B, LD, 60 * 1024);
+    const size_t lds = (size_t)2 * NB * Ci * LD * sizeof(float);
+    const int ntiles = ceil_div(B, NB);
+    const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
+    auto k = k_bwd_gcn_params<T, V>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB);
+    if ((rc = check_launch("bwd_gcn_params"))) return rc;
+    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 256)), dim3(256), 0, st, w.partials, grid, E, 0,
+                       T * V * V, dA, accumulate);
+    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 256)), dim3(256), 0, st, w.partials, grid, E,
+                       T * V * V, V * T * T, dT, accumulate);
+    if ((rc = check_launch("bwd_gcn_reduce"))) return rc;
+  }
+  return COSKAD_OK;
+}
+
+}  // namespace coskad
+
+using namespace coskad;
+
+extern "C" {
+
+size_t coskad_layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V) { return layer_bwd_ws_bytes(B, Ci, Co, T, V); }
+
+int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const float* Tm,
+                         const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
+                         const float* Wr, const float* gamma_r, float* dIn, float* dA, float* dT, float* dWt,
+                         float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
+                         float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
+                         int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream) {
+  if (!in || !dU || !A || !Tm || !stat || !Wt || !gamma_t || !dA || !dT || !dWt || !dgamma_t || !dbeta_t || !ws)
+    return fail(COSKAD_ERR_ARG, "layer_bwd: null pointer");
+  if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd: residual grads missing");
+  if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_bwd: identity residual needs Ci == Co");
+  if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd: B=%d Ci=%d Co=%d", B, Ci, Co);
+#define CALL(T_, V_)                                                                                       \
+  return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
+                                  dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
+                                  ws_bytes, accumulate, B, Ci, Co, stream)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+}  // extern "C"

@@ -119,3 +119,148 @@ def layer_train_stats(x, A, Tm, in_slope, Wt, bt, gt, bet, rm_t, rv_t, nbt_t,
          ptr(rv_r), ptr(nbt_r), ctypes.c_float(momentum), ptr(wfold), ptr(bias), ptr(stat), ptr(ws),
          ctypes.c_size_t(ws.numel() * ws.element_size()), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
     return wfold, bias, stat
+
+
+def _bytes(t: Tensor) -> int:
+    return t.numel() * t.element_size()
+
+
+def layer_bwd_ws_bytes(B, Ci, Co, T, V) -> int:
+    fn = _lib.lib().coskad_layer_bwd_ws_bytes
+    fn.restype = ctypes.c_size_t
+    return fn(i32(B), i32(Ci), i32(Co), i32(T), i32(V))
+
+
+def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, need_dx=True,
+              dIn=None, accumulate=False):
+    """Backward of one layer.  `grads` maps names -> preallocated gradient tensors:
+    A, T, Wt, bt (opt), gt, bet, Wr, br (opt), gr, ber, slope_in (opt).  Returns dIn (or None)."""
+    B, Ci, T, V = x_in.shape
+    Co = Wt.shape[0]
+    _chk(x_in, "x_in"); _chk(dU, "dU", (B, Co, T, V)); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
+    _chk(Wt, "Wt", (Co, Ci)); _chk(gt, "gamma_t", (Co,)); _chk(stat, "stat", (stat_floats(Ci, Co),))
+    _chk(Wr, "Wr", (Co, Ci), optional=True); _chk(gr, "gamma_r", (Co,), optional=True)
+    _chk(in_slope, "in_slope", (1,), optional=True)
+    for k, shp in (("A", (T, V, V)), ("T", (V, T, T)), ("Wt", (Co, Ci)), ("gt", (Co,)), ("bet", (Co,))):
+        _chk(grads[k], "grad " + k, shp)
+    for k, shp in (("bt", (Co,)), ("Wr", (Co, Ci)), ("br", (Co,)), ("gr", (Co,)), ("ber", (Co,)), ("slope_in", (1,))):
+        _chk(grads.get(k), "grad " + k, shp, optional=True)
+    need = layer_bwd_ws_bytes(B, Ci, Co, T, V)
+    if ws is None or _bytes(ws) < need:
+        raise ValueError(f"workspace too small: need {need} bytes")
+    if need_dx and dIn is None:
+        dIn = torch.empty_like(x_in)
+    call("coskad_layer_bwd_f32", ptr(x_in), ptr(dU), ptr(A), ptr(Tm), ptr(in_slope), ptr(stat), ptr(Wt), ptr(gt),
+         ptr(Wr), ptr(gr), ptr(dIn if need_dx else None), ptr(grads["A"]), ptr(grads["T"]), ptr(grads["Wt"]),
+         ptr(grads.get("bt")), ptr(grads["gt"]), ptr(grads["bet"]), ptr(grads.get("Wr")), ptr(grads.get("br")),
+         ptr(grads.get("gr")), ptr(grads.get("ber")), ptr(grads.get("slope_in")), ptr(ws),
+         ctypes.c_size_t(_bytes(ws)), i32(1 if accumulate else 0), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    return dIn if need_dx else None
+
+
+def btlnk_fwd(U: Tensor, W: Tensor, bias: Optional[Tensor], slope: Optional[Tensor]) -> Tensor:
+    """z = Linear(flatten(PReLU(U)))  (reference ae.py:97-101)."""
+    B = U.shape[0]
+    K = U.numel() // B
+    L = W.shape[0]
+    _chk(U, "U"); _chk(W, "W", (L, K)); _chk(bias, "bias", (L,), optional=True); _chk(slope, "slope", (1,), optional=True)
+    z = torch.empty(B, L, device=U.device, dtype=torch.float32)
+    call("coskad_btlnk_fwd_f32", ptr(U), ptr(W), ptr(bias), ptr(slope), ptr(z), i32(B), i32(K), i32(L), _stream())
+    return z
+
+
+def btlnk_bwd_ws_bytes(B, K, L) -> int:
+    fn = _lib.lib().coskad_btlnk_bwd_ws_bytes
+    fn.restype = ctypes.c_size_t
+    return fn(i32(B), i32(K), i32(L))
+
+
+def btlnk_bwd(U, W, dz, slope, dW, db, dslope, ws, dU=None, accumulate=False):
+    B = U.shape[0]
+    K = U.numel() // B
+    L = W.shape[0]
+    _chk(U, "U"); _chk(W, "W", (L, K)); _chk(dz, "dz", (B, L)); _chk(dW, "dW", (L, K))
+    _chk(db, "db", (L,), optional=True); _chk(dslope, "dslope", (1,), optional=True); _chk(slope, "slope", (1,), optional=True)
+    need = btlnk_bwd_ws_bytes(B, K, L)
+    if ws is None or _bytes(ws) < need:
+        raise ValueError(f"workspace too small: need {need} bytes")
+    if dU is None:
+        dU = torch.empty_like(U)
+    call("coskad_btlnk_bwd_f32", ptr(U), ptr(W), ptr(dz), ptr(slope), ptr(dU), ptr(dW), ptr(db), ptr(dslope), ptr(ws),
+         ctypes.c_size_t(_bytes(ws)), i32(1 if accumulate else 0), i32(B), i32(K), i32(L), _stream())
+    return dU
+
+
+HEAD_SLOTS = 19
+
+
+def head_ws(B: int, device) -> Tensor:
+    fn = _lib.lib().coskad_head_ws_floats
+    fn.restype = ctypes.c_size_t
+    return torch.empty(fn(i32(B)), device=device, dtype=torch.float32)
+
+
+def mse_head(z, c, need_grad=True, need_score=False, acc=None, upstream=1.0, ws=None):
+    """-> (stats[19], dz or None, score or None).  stats[0] = F.mse_loss(z, c)."""
+    B, L = z.shape
+    _chk(z, "z"); _chk(c, "c", (L,)); _chk(acc, "acc", (HEAD_SLOTS,), optional=True)
+    ws = head_ws(B, z.device) if ws is None else ws
+    dz = torch.empty_like(z) if need_grad else None
+    score = torch.empty(B, device=z.device, dtype=torch.float32) if need_score else None
+    stats = torch.empty(HEAD_SLOTS, device=z.device, dtype=torch.float32)
+    call("coskad_mse_head_f32", ptr(z), ptr(c), ptr(dz), ptr(score), ptr(stats), ptr(acc), ctypes.c_float(upstream),
+         ptr(ws), i32(B), i32(L), _stream())
+    return stats, dz, score
+
+
+def poincare_head(z, c, need_grad=True, need_zh=False, need_score=False, acc=None, upstream=1.0, ws=None):
+    """-> (stats[19], dz, zh, score).  stats[0] = dist(c, project(expmap0(z))).mean()."""
+    B, L = z.shape
+    _chk(z, "z"); _chk(c, "c", (L,), optional=True); _chk(acc, "acc", (HEAD_SLOTS,), optional=True)
+    ws = head_ws(B, z.device) if ws is None else ws
+    dz = torch.empty_like(z) if (need_grad and c is not None) else None
+    zh = torch.empty_like(z) if need_zh else None
+    score = torch.empty(B, device=z.device, dtype=torch.float32) if (need_score and c is not None) else None
+    stats = torch.empty(HEAD_SLOTS, device=z.device, dtype=torch.float32)
+    call("coskad_poincare_head_f32", ptr(z), ptr(c), ptr(dz), ptr(zh), ptr(score), ptr(stats), ptr(acc),
+         ctypes.c_float(upstream), ptr(ws), i32(B), i32(L), _stream())
+    return stats, dz, zh, score
+
+
+def poincare_dist(zh, c):
+    B, L = zh.shape
+    _chk(zh, "zh"); _chk(c, "c", (L,))
+    score = torch.empty(B, device=zh.device, dtype=torch.float32)
+    call("coskad_poincare_dist_f32", ptr(zh), ptr(c), ptr(score), i32(B), i32(L), _stream())
+    return score
+
+
+def center_finalize(acc, eps: float, L: int):
+    _chk(acc, "acc", (HEAD_SLOTS,))
+    c = torch.empty(L, device=acc.device, dtype=torch.float32)
+    call("coskad_center_finalize_f32", ptr(acc), ptr(c), ctypes.c_float(eps), i32(L), _stream())
+    return c
+
+
+def midpoint_finalize(acc, L: int):
+    _chk(acc, "acc", (HEAD_SLOTS,))
+    c = torch.empty(L, device=acc.device, dtype=torch.float32)
+    call("coskad_midpoint_finalize_f32", ptr(acc), ptr(c), i32(L), _stream())
+    return c
+
+
+def sqnorm(p, mask, scale: float, ws=None):
+    _chk(p, "p"); _chk(mask, "mask", p.shape, optional=True)
+    ws = torch.empty(256, device=p.device, dtype=torch.float32) if ws is None else ws
+    out = torch.empty(1, device=p.device, dtype=torch.float32)
+    call("coskad_sqnorm_f32", ptr(p), ptr(mask), ctypes.c_size_t(p.numel()), ctypes.c_float(scale), ptr(out), ptr(ws), _stream())
+    return out
+
+
+def adam(p, g, m, v, mask, lr, beta1, beta2, eps, step, gscale=1.0, reg_coef=0.0):
+    for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, n, p.shape)
+    _chk(mask, "mask", p.shape, optional=True)
+    call("coskad_adam_f32", ptr(p), ptr(g), ptr(m), ptr(v), ptr(mask), ctypes.c_size_t(p.numel()), ctypes.c_float(lr),
+         ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), i32(step), ctypes.c_float(gscale),
+         ctypes.c_float(reg_coef), _stream())

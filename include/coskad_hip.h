@@ -67,6 +67,68 @@ int coskad_layer_train_stats_f32(const float* in, const float* A, const float* T
                                  size_t ws_bytes, int B, int Ci, int Co, int T, int V,
                                  hipStream_t stream);
 
+/* ---- backward of one ST_GCNN_layer (autograd of stsgcn.py:94-116 in training mode) ------ */
+
+size_t coskad_layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V);
+
+/* in   : the layer's input as stored by the producer (pre-activation; in_slope = its PReLU weight,
+ *        NULL when `in` is the raw network input)
+ * dU   : gradient w.r.t. this layer's pre-activation output [B,Co,T,V]
+ * stat : stat block written by coskad_layer_train_stats_f32 in the forward pass
+ * dIn  : gradient w.r.t. `in` (already multiplied by the producer's PReLU derivative); NULL to skip
+ * dslope_in : gradient of the producer's PReLU weight (1 float); NULL to skip
+ * parameter gradients are written (accumulate == 0) or added (accumulate != 0).
+ * Wr == NULL: identity residual. */
+int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const float* Tm,
+                         const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
+                         const float* Wr, const float* gamma_r, float* dIn, float* dA, float* dT, float* dWt,
+                         float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
+                         float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
+                         int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream);
+
+/* ---- bottleneck Linear (models/sts/ae.py:97-101,157) ---------------------------------- */
+
+/* z[n][j] = bias[j] + sum_k W[j][k] * PReLU_slope(U[n][k]);  slope NULL: no activation. L <= 16. */
+int coskad_btlnk_fwd_f32(const float* U, const float* W, const float* bias, const float* slope, float* z,
+                         int B, int K, int L, hipStream_t stream);
+size_t coskad_btlnk_bwd_ws_bytes(int B, int K, int L);
+/* dU = (dz W) * PReLU'(U);  dW (+)= dz^T PReLU(U);  db (+)= sum_n dz;  dslope (+)= sum (dz W) U [U<0] */
+int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const float* slope, float* dU,
+                         float* dW, float* db, float* dslope, void* ws, size_t ws_bytes, int accumulate,
+                         int B, int K, int L, hipStream_t stream);
+
+/* ---- one-class heads, centre statistics, regulariser, optimiser ------------------------ */
+
+int coskad_head_slots(void);            /* floats in a stats / acc block (19) */
+size_t coskad_head_ws_floats(int B);    /* scratch floats the head kernels need */
+
+/* F.mse_loss(z, c) (euclidean_encoder_staticCenter.py:187, _dynamicCenter.py:116), its gradient,
+ * the per-window score of utils/eval_utils.py:63-64, and the running-centre sums (:172-178).
+ * stats: [0] loss, [1..L] sum_n z, [17] B, [18] sum_n |z_n|;  acc += raw sums. */
+int coskad_mse_head_f32(const float* z, const float* c, float* dz, float* score, float* stats, float* acc,
+                        float upstream, float* ws, int B, int L, hipStream_t stream);
+
+/* zh = project(expmap0(z)); loss = mean dist(c, zh) (hyperbolic_encoder.py:147,157 with the formulas
+ * of utils/hyper_math.py:13-29,100-105,173-179,207-210,302-306), gradient w.r.t. z, score = dist,
+ * stats: [0] loss, [1..L] sum gamma*zh, [17] sum (gamma-1), [18] sum |zh|;  c NULL: embed + sums only. */
+int coskad_poincare_head_f32(const float* z, const float* c, float* dz, float* zh, float* score,
+                             float* stats, float* acc, float upstream, float* ws, int B, int L,
+                             hipStream_t stream);
+int coskad_poincare_dist_f32(const float* zh, const float* c, float* score, int B, int L, hipStream_t stream);
+
+/* c = acc[1..L] / acc[17], then |c| < eps -> +-eps (staticCenter.py:118-121). */
+int coskad_center_finalize_f32(const float* acc, float* c, float eps, int L, hipStream_t stream);
+/* gyromidpoint from acc of coskad_poincare_head_f32 (hyperbolic_encoder.py:122,179). */
+int coskad_midpoint_finalize_f32(const float* acc, float* c, int L, hipStream_t stream);
+
+/* out[0] = scale * sum_i mask[i] p[i]^2  (utils/model_utils.py:90-105). ws: 256 floats. */
+int coskad_sqnorm_f32(const float* p, const float* mask, size_t n, float scale, float* out, float* ws,
+                      hipStream_t stream);
+/* torch.optim.Adam step on flat buffers with g = grad*gscale + reg_coef*mask*p. */
+int coskad_adam_f32(float* p, const float* g, float* m, float* v, const float* mask, size_t n, float lr,
+                    float beta1, float beta2, float eps, int step, float gscale, float reg_coef,
+                    hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

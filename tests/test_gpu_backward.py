@@ -1,0 +1,210 @@
+"""GPU parity of the backward kernels, heads and optimiser against the CPU oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import state_from
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(t):
+    return None if t is None else t.detach().cuda().contiguous()
+
+
+def close(a, b, rtol=2e-4, atol_rel=2e-5, msg=""):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    scale = max(float(np.abs(b).max()), 1e-8)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_rel * scale, err_msg=msg)
+
+
+def make_layer_state(Ci, Co, V, seed, identity=False):
+    g = torch.Generator().manual_seed(seed)
+    T = 12
+    st = {}
+    p = "L"
+    st[p + ".gcn.A"] = (torch.rand(T, V, V, generator=g) * 2 - 1) / V ** 0.5
+    st[p + ".gcn.T"] = (torch.rand(V, T, T, generator=g) * 2 - 1) / T ** 0.5
+    for br, bn in (("tcn.0", "tcn.1"), ("residual.0", "residual.1")):
+        if br.startswith("residual") and identity:
+            continue
+        st[f"{p}.{br}.weight"] = (torch.rand(Co, Ci, 1, 1, generator=g) * 2 - 1) / Ci ** 0.5
+        st[f"{p}.{br}.bias"] = (torch.rand(Co, generator=g) * 2 - 1) / Ci ** 0.5
+        st[f"{p}.{bn}.weight"] = 1 + 0.2 * torch.randn(Co, generator=g)
+        st[f"{p}.{bn}.bias"] = 0.2 * torch.randn(Co, generator=g)
+        st[f"{p}.{bn}.running_mean"] = torch.zeros(Co)
+        st[f"{p}.{bn}.running_var"] = torch.ones(Co)
+        st[f"{p}.{bn}.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    st[p + ".prelu.weight"] = torch.full((1,), 0.25)
+    return st
+
+
+LAYER_CASES = [
+    # Ci, Co, V, B, first(no input act / no dx), identity
+    (2, 32, 17, 37, True, False),
+    (32, 16, 17, 9, False, False),
+    (16, 32, 17, 11, False, False),
+    (32, 64, 17, 5, False, False),
+    (64, 32, 17, 3, False, False),
+    (8, 8, 25, 6, False, True),
+    (4, 8, 14, 7, False, False),
+    (8, 2, 18, 5, False, False),
+]
+
+
+@pytest.mark.parametrize("Ci,Co,V,B,first,identity", LAYER_CASES)
+def test_layer_backward(Ci, Co, V, B, first, identity):
+    from coskad_amd import ops
+    T = 12
+    st = make_layer_state(Ci, Co, V, seed=Ci * 100 + Co, identity=identity)
+    g = torch.Generator().manual_seed(7)
+    x_pre = torch.randn(B, Ci, T, V, generator=g)
+    probe = torch.randn(B, Co, T, V, generator=g)
+    slope = torch.tensor([0.2])
+    # oracle
+    pk = [k for k in st if R.is_param_key(k) and st[k].is_floating_point()]
+    stc = {k: v.clone() for k, v in st.items()}
+    for k in pk:
+        stc[k].requires_grad_(True)
+    xo = x_pre.clone().requires_grad_(not first)
+    so = slope.clone().requires_grad_(not first)
+    X = xo if first else R.prelu(xo, so)
+    U = R.st_gcnn_layer(X, stc, "L", training=True, return_preact=True)
+    (U * probe).sum().backward()
+    # HIP
+    d = {k[2:]: dev(v) for k, v in st.items()}
+    ws = torch.empty(max(ops.train_stats_ws_bytes(Ci), ops.layer_bwd_ws_bytes(B, Ci, Co, T, V)), dtype=torch.uint8, device="cuda")
+    sl = None if first else dev(slope)
+    Wt = d["tcn.0.weight"].reshape(Co, Ci)
+    Wr = None if identity else d["residual.0.weight"].reshape(Co, Ci)
+    wfold, bias, stat = ops.layer_train_stats(
+        dev(x_pre), d["gcn.A"], d["gcn.T"], sl, Wt, d["tcn.0.bias"], d["tcn.1.weight"], d["tcn.1.bias"],
+        d["tcn.1.running_mean"], d["tcn.1.running_var"], d["tcn.1.num_batches_tracked"],
+        Wr, d.get("residual.0.bias"), d.get("residual.1.weight"), d.get("residual.1.bias"),
+        d.get("residual.1.running_mean"), d.get("residual.1.running_var"), d.get("residual.1.num_batches_tracked"), ws)
+    u_hip = ops.layer_apply(dev(x_pre), d["gcn.A"], d["gcn.T"], wfold, bias, Co, in_slope=sl)
+    close(u_hip, U, rtol=1e-4, atol_rel=1e-5, msg="forward preact")
+    z = lambda *s: torch.full(s, float("nan"), device="cuda")  # poison: kernels must overwrite
+    grads = {"A": z(T, V, V), "T": z(V, T, T), "Wt": z(Co, Ci), "bt": z(Co), "gt": z(Co), "bet": z(Co)}
+    if not identity:
+        grads.update({"Wr": z(Co, Ci), "br": z(Co), "gr": z(Co), "ber": z(Co)})
+    if not first:
+        grads["slope_in"] = z(1)
+    dIn = ops.layer_bwd(dev(x_pre), dev(probe), d["gcn.A"], d["gcn.T"], sl, stat, Wt, d["tcn.1.weight"], Wr,
+                        d.get("residual.1.weight"), grads, ws, need_dx=not first)
+    gmax = max(float(stc[k].grad.abs().max()) for k in pk if stc[k].grad is not None)
+    ref = {"A": stc["L.gcn.A"].grad, "T": stc["L.gcn.T"].grad, "Wt": stc["L.tcn.0.weight"].grad.reshape(Co, Ci),
+           "bt": stc["L.tcn.0.bias"].grad, "gt": stc["L.tcn.1.weight"].grad, "bet": stc["L.tcn.1.bias"].grad}
+    if not identity:
+        ref.update({"Wr": stc["L.residual.0.weight"].grad.reshape(Co, Ci), "br": stc["L.residual.0.bias"].grad,
+                    "gr": stc["L.residual.1.weight"].grad, "ber": stc["L.residual.1.bias"].grad})
+    for k, r in ref.items():
+        a, b = grads[k].cpu().numpy(), r.numpy()
+        assert np.isfinite(a).all(), k
+        np.testing.assert_allclose(a, b, rtol=5e-4, atol=5e-5 * max(np.abs(b).max(), 1e-9) + 2e-5 * gmax, err_msg=k)
+    if not first:
+        close(dIn, xo.grad, rtol=5e-4, atol_rel=5e-5, msg="dIn")
+        close(grads["slope_in"], so.grad, rtol=5e-4, atol_rel=1e-4, msg="dslope_in")
+
+
+@pytest.mark.parametrize("B,hid,V,L,with_slope", [(37, 64, 17, 16, True), (5, 8, 25, 8, True), (16, 4, 17, 4, False), (300, 16, 17, 16, True)])
+def test_bottleneck(B, hid, V, L, with_slope):
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(B + hid)
+    T = 12
+    K = hid * T * V
+    U = torch.randn(B, hid, T, V, generator=g, requires_grad=True)
+    W = (torch.randn(L, K, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(L, generator=g).requires_grad_(True)
+    a = torch.tensor([0.3], requires_grad=True)
+    X = R.prelu(U, a) if with_slope else U
+    z = R.linear(X.reshape(B, -1), W, b)
+    dz = torch.randn(B, L, generator=g)
+    (z * dz).sum().backward()
+    sl = dev(a) if with_slope else None
+    zh = ops.btlnk_fwd(dev(U), dev(W), dev(b), sl)
+    close(zh, z, rtol=1e-4, atol_rel=1e-5, msg="z")
+    ws = torch.empty(ops.btlnk_bwd_ws_bytes(B, K, L), dtype=torch.uint8, device="cuda")
+    dW = torch.full((L, K), float("nan"), device="cuda")
+    db = torch.full((L,), float("nan"), device="cuda")
+    da = torch.full((1,), float("nan"), device="cuda")
+    dU = ops.btlnk_bwd(dev(U), dev(W), dev(dz), sl, dW, db, da if with_slope else None, ws)
+    close(dU, U.grad, msg="dU")
+    close(dW, W.grad, msg="dW")
+    close(db, b.grad, msg="db")
+    if with_slope:
+        close(da, a.grad, rtol=5e-4, atol_rel=1e-4, msg="dslope")
+
+
+def test_mse_head():
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(1000, 16, generator=g, requires_grad=True)
+    c = torch.randn(16, generator=g)
+    loss = R.mse_to_center(z, c)
+    loss.backward()
+    acc = torch.zeros(ops.HEAD_SLOTS, device="cuda")
+    stats, dz, score = ops.mse_head(dev(z), dev(c), need_score=True, acc=acc)
+    stats, dz2, _ = ops.mse_head(dev(z), dev(c), acc=acc)  # second call accumulates again
+    close(stats[0], loss, rtol=1e-5)
+    close(dz, z.grad)
+    close(score, R.euclid_window_score(z.detach(), c), rtol=1e-5)
+    close(stats[1:17], z.detach().sum(0), rtol=1e-4, atol_rel=1e-5)
+    close(acc[1:17], 2 * z.detach().sum(0), rtol=1e-4, atol_rel=1e-5)
+    assert float(acc[17]) == 2000.0
+    cc = ops.center_finalize(acc, 0.5, 16).cpu()
+    np.testing.assert_allclose(cc.numpy(), R.clamp_center(z.detach().mean(0), 0.5).numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_poincare_head_matches_oracle_and_golden(golden):
+    from coskad_amd import ops
+    g = golden("hyper_math.npz")
+    u = torch.from_numpy(g["u"]).clone().requires_grad_(True)
+    c = torch.from_numpy(g["a"][3])
+    loss, zh = R.poincare_loss(u, c)
+    loss.backward()
+    stats, dz, zh_hip, score = ops.poincare_head(dev(u), dev(c), need_zh=True, need_score=True)
+    np.testing.assert_allclose(zh_hip.cpu().numpy(), g["project_expmap0"], rtol=1e-5, atol=2e-6)  # the reference itself
+    np.testing.assert_allclose(score.cpu().numpy(), g["dist_bcast"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(stats[0]), float(g["loss"]), rtol=1e-4)
+    np.testing.assert_allclose(dz.cpu().numpy(), g["dloss_du"], rtol=2e-3, atol=2e-6)
+    close(dz, u.grad, rtol=2e-3, atol_rel=2e-5)
+    # on-ball distance
+    sc2 = ops.poincare_dist(dev(torch.from_numpy(g["project_expmap0"])), dev(c)).cpu()
+    np.testing.assert_allclose(sc2.numpy(), g["dist_bcast"], rtol=2e-4, atol=2e-5)
+
+
+def test_poincare_center(golden):
+    from coskad_amd import ops
+    g = golden("stse_default.npz")
+    z = torch.from_numpy(g["train.z"])
+    c = torch.from_numpy(g["hyp.c"])
+    acc = torch.zeros(ops.HEAD_SLOTS, device="cuda")
+    stats, dz, zh, _ = ops.poincare_head(dev(z), dev(c), need_zh=True, acc=acc)
+    np.testing.assert_allclose(zh.cpu().numpy(), g["hyp.zh"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(float(stats[0]), float(g["hyp.loss"]), rtol=1e-5)
+    np.testing.assert_allclose(dz.cpu().numpy(), g["hyp.dz"], rtol=5e-4, atol=1e-7)
+    mid = ops.midpoint_finalize(acc, 16).cpu()
+    np.testing.assert_allclose(mid.numpy(), g["hyp.center"], rtol=1e-3, atol=2e-5)  # Klein-model mean == gyromidpoint
+
+
+def test_adam_and_reg():
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    mask = (torch.rand(n, generator=g) > 0.3).float()
+    reg_scale = 0.5 / 7
+    np.testing.assert_allclose(float(ops.sqnorm(dev(p0), dev(mask), reg_scale)), float(reg_scale * (mask * p0 * p0).sum()), rtol=1e-5)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-2)
+    ph, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    alpha = 0.1
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        opt.zero_grad()
+        pt.grad = gr + alpha * 2 * reg_scale * mask * pt.detach()
+        opt.step()
+        ops.adam(ph, dev(gr), m, v, dev(mask), 1e-2, 0.9, 0.999, 1e-8, step, reg_coef=alpha * 2 * reg_scale)
+    np.testing.assert_allclose(ph.cpu().numpy(), pt.detach().numpy(), rtol=1e-5, atol=1e-6)
