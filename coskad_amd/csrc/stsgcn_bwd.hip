@@ -649,11 +649,49 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
 
 }  // namespace coskad
 
+namespace coskad {
+template <int T, int V>
+static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* Aw, const float* Tw, float* dA,
+                                 float* dT, void* ws, int accumulate, int rows, hipStream_t st) {
+  constexpr int LD = Geo<T, V>::LD;
+  const int E = T * V * V + V * T * T;
+  const int NB = rows < 64 ? rows : 64;
+  const size_t lds = (size_t)2 * NB * LD * sizeof(float);
+  const int ntiles = ceil_div(rows, NB);
+  const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
+  float* partials = reinterpret_cast<float*>(ws);
+  auto k = k_bwd_gcn_params<T, V>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB);
+  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 256)), dim3(256), 0, st, partials, grid, E, 0, T * V * V, dA, accumulate);
+  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 256)), dim3(256), 0, st, partials, grid, E, T * V * V, V * T * T, dT, accumulate);
+  return check_launch("gcn_bwd_params");
+}
+}  // namespace coskad
+
 using namespace coskad;
 
 extern "C" {
 
 size_t coskad_layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V) { return layer_bwd_ws_bytes(B, Ci, Co, T, V); }
+
+size_t coskad_gcn_bwd_params_ws_bytes(int T, int V) {
+  return (size_t)kMaxGridBwd * ((size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
+}
+
+
+/* Parameter gradients of ConvTemporalGraphical (stsgcn.py:154-155): dA[t,v,w] = sum Y[.,t,v] dZ[.,t,w],
+ * dT[v,t,q] = sum X[.,t,v] dY[.,q,v] over rows = N*C, given X and dZ. */
+int coskad_gcn_bwd_params_f32(const float* x, const float* dZ, const float* A, const float* Tm, float* dA,
+                              float* dT, void* ws, size_t ws_bytes, int accumulate, int rows, int T, int V,
+                              hipStream_t stream) {
+  if (!x || !dZ || !A || !Tm || !dA || !dT || !ws) return fail(COSKAD_ERR_ARG, "gcn_bwd_params: null pointer");
+  if (rows <= 0) return fail(COSKAD_ERR_ARG, "gcn_bwd_params: rows=%d", rows);
+  if (ws_bytes < coskad_gcn_bwd_params_ws_bytes(T, V)) return fail(COSKAD_ERR_WORKSPACE, "gcn_bwd_params: workspace too small");
+#define CALL(T_, V_) return launch_gcn_bwd_params<T_, V_>(x, dZ, A, Tm, dA, dT, ws, accumulate, rows, stream)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
 
 int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const float* Tm,
                          const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,

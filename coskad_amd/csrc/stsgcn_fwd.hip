@@ -146,6 +146,55 @@ __global__ void k_bn_fold(const float* __restrict__ Wt, const float* __restrict_
   }
 }
 
+// elementwise PReLU with one shared slope (nn.PReLU(), stsgcn.py:82,110) for the API paths that must
+// materialise a post-activation tensor (the fused chain exchanges pre-activations instead).
+__global__ __launch_bounds__(256) void k_prelu_fwd(const float* __restrict__ u, const float* __restrict__ slope,
+                                                    float* __restrict__ out, size_t n4, size_t n) {
+  const float a = slope[0];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    float4 v = reinterpret_cast<const float4*>(u)[i];
+    v.x = prelu_f(v.x, a); v.y = prelu_f(v.y, a); v.z = prelu_f(v.z, a); v.w = prelu_f(v.w, a);
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
+    const size_t j = 4 * n4 + threadIdx.x;
+    out[j] = prelu_f(u[j], a);
+  }
+}
+
+// dU = dOut * PReLU'(U);  partials[block] = sum dOut * U [U < 0]
+__global__ __launch_bounds__(256) void k_prelu_bwd(const float* __restrict__ u, const float* __restrict__ dout,
+                                                    const float* __restrict__ slope, float* __restrict__ du,
+                                                    float* __restrict__ partials, size_t n) {
+  __shared__ float sh[4];
+  const float a = slope[0];
+  float da = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float x = u[i], g = dout[i];
+    if (x < 0.f) da = fmaf(g, x, da);
+    du[i] = x > 0.f ? g : a * g;
+  }
+  da = wave_sum(da);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = da;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void k_sum_small(const float* __restrict__ v, int n, float* __restrict__ out,
+                                                    int accumulate) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)v[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)sh[0] : (float)sh[0];
+}
+
 static int pick_nb(int Ci, int B, int LD) {
   // 64 rows per row-phase batch is the sweet spot (one lane per row); cap by LDS.
   int nb = Ci >= 64 ? 1 : 64 / Ci;
@@ -218,6 +267,24 @@ int coskad_gcn_f32(const float* in, float* out, const float* A, const float* Tm,
 #define CALL(T_, V_) return launch_gcn<T_, V_>(in, out, A, Tm, rows, adjoint, stream)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
+}
+
+int coskad_prelu_fwd_f32(const float* u, const float* slope, float* out, size_t n, hipStream_t stream) {
+  if (!u || !slope || !out || n == 0) return fail(COSKAD_ERR_ARG, "prelu_fwd: bad argument");
+  const size_t n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1);
+  hipLaunchKernelGGL(k_prelu_fwd, dim3(grid), dim3(256), 0, stream, u, slope, out, n4, n);
+  return check_launch("prelu_fwd");
+}
+
+/* ws: >= 1024 floats */
+int coskad_prelu_bwd_f32(const float* u, const float* dout, const float* slope, float* du, float* dslope,
+                         float* ws, int accumulate, size_t n, hipStream_t stream) {
+  if (!u || !dout || !slope || !du || !ws || n == 0) return fail(COSKAD_ERR_ARG, "prelu_bwd: bad argument");
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_prelu_bwd, dim3(grid), dim3(256), 0, stream, u, dout, slope, du, ws, n);
+  if (dslope) hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(256), 0, stream, ws, grid, dslope, accumulate);
+  return check_launch("prelu_bwd");
 }
 
 int coskad_bn_fold_f32(const float* Wt, const float* bt, const float* gamma_t, const float* beta_t,

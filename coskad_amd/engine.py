@@ -1,0 +1,160 @@
+"""Host-side orchestration of the HIP kernels for a stack of ST_GCNN layers.
+
+A *chain* is the ``nn.Sequential`` of ST_GCNN layers of the reference's Encoder / Decoder
+(models/common/components.py:70-105,143-179).  Layers exchange PRE-activations: layer i
+writes U_i, layer i+1 applies PReLU_i while staging U_i (see csrc/stsgcn_fwd.hip).
+
+  chain_forward  : eval  -> bn_fold (running stats) + layer_apply per layer
+                   train -> layer_train_stats (batch stats, running-stat update) + layer_apply
+  chain_backward : layer_bwd per layer, last to first
+
+Everything here is plumbing around C-ABI calls (coskad_amd.ops); there is no CPU path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class LayerTensors:
+    """Views of one ST_GCNN_layer's parameters / buffers (reference stsgcn.py:47-91)."""
+    A: Tensor
+    T: Tensor
+    Wt: Tensor              # tcn.0.weight  [Co,Ci,1,1]
+    bt: Optional[Tensor]    # tcn.0.bias
+    gt: Tensor              # tcn.1.weight
+    bet: Tensor             # tcn.1.bias
+    rm_t: Tensor
+    rv_t: Tensor
+    nbt_t: Tensor
+    Wr: Optional[Tensor]    # residual.0.weight (None: identity residual)
+    br: Optional[Tensor]
+    gr: Optional[Tensor]
+    ber: Optional[Tensor]
+    rm_r: Optional[Tensor]
+    rv_r: Optional[Tensor]
+    nbt_r: Optional[Tensor]
+    slope: Tensor           # prelu.weight [1]
+    momentum: float = 0.1
+
+    @property
+    def Co(self) -> int:
+        return self.Wt.shape[0]
+
+    @property
+    def Ci(self) -> int:
+        return self.Wt.shape[1]
+
+    def w2(self, w: Optional[Tensor]) -> Optional[Tensor]:
+        return None if w is None else w.view(w.shape[0], w.shape[1])
+
+    def param_list(self) -> List[Tensor]:
+        ps = [self.A, self.T, self.Wt]
+        if self.bt is not None:
+            ps.append(self.bt)
+        ps += [self.gt, self.bet]
+        if self.Wr is not None:
+            ps.append(self.Wr)
+            if self.br is not None:
+                ps.append(self.br)
+            ps += [self.gr, self.ber]
+        ps.append(self.slope)
+        return ps
+
+    def grad_names(self) -> List[str]:
+        ns = ["A", "T", "Wt"]
+        if self.bt is not None:
+            ns.append("bt")
+        ns += ["gt", "bet"]
+        if self.Wr is not None:
+            ns.append("Wr")
+            if self.br is not None:
+                ns.append("br")
+            ns += ["gr", "ber"]
+        ns.append("slope")
+        return ns
+
+
+class Workspace:
+    """Grow-only scratch shared by all kernels of one module (byte tensor on the device)."""
+
+    def __init__(self) -> None:
+        self.buf: Optional[Tensor] = None
+
+    def get(self, nbytes: int, device) -> Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+@dataclass
+class ChainCtx:
+    """What chain_backward needs from chain_forward (train mode)."""
+    inputs: List[Tensor] = field(default_factory=list)   # input of layer i (x, U_0, U_1, ...)
+    stats: List[Tensor] = field(default_factory=list)    # stat block of layer i
+    in_slope: Optional[Tensor] = None                    # activation applied to inputs[0] (None: raw)
+
+
+def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Workspace,
+                  in_slope: Optional[Tensor] = None, want_ctx: bool = False):
+    """-> (U_last, ctx).  U_last is the last layer's PRE-activation; apply layers[-1].slope to it."""
+    B, C, T, V = x.shape
+    ctx = ChainCtx(in_slope=in_slope) if want_ctx else None
+    h, slope = x, in_slope
+    for L in layers:
+        if h.shape[1] != L.Ci:
+            raise ValueError(f"layer expects {L.Ci} input channels, got {h.shape[1]}")
+        if training:
+            buf = ws.get(ops.train_stats_ws_bytes(L.Ci), x.device)
+            wfold, bias, stat = ops.layer_train_stats(
+                h, L.A, L.T, slope, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
+                L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum)
+        else:
+            wfold, bias = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t,
+                                      L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
+            stat = None
+        u = ops.layer_apply(h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)
+        if ctx is not None:
+            ctx.inputs.append(h)
+            ctx.stats.append(stat)
+        h, slope = u, L.slope
+    return h, ctx
+
+
+def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Workspace,
+                   grads: List[Dict[str, Tensor]], need_dx: bool, accumulate: bool = False) -> Optional[Tensor]:
+    """Backward through the chain.  `grads[i]` maps A,T,Wt,bt,gt,bet,Wr,br,gr,ber,slope -> tensors to
+    fill for layer i.  The slope gradient of layer i is produced while back-propagating through
+    layer i+1 (its consumer); the caller owns the last layer's slope gradient.
+    Returns d(inputs[0]) if need_dx."""
+    n = len(layers)
+    for i in range(n - 1, -1, -1):
+        L = layers[i]
+        x_in = ctx.inputs[i]
+        B, Ci, T, V = x_in.shape
+        in_slope = layers[i - 1].slope if i > 0 else ctx.in_slope
+        g = dict(grads[i])
+        g.pop("slope", None)
+        if i > 0:
+            g["slope_in"] = grads[i - 1]["slope"]
+        want_dx = need_dx or i > 0
+        buf = ws.get(ops.layer_bwd_ws_bytes(B, Ci, L.Co, T, V), x_in.device)
+        dIn = ops.layer_bwd(x_in, dU, L.A, L.T, in_slope, ctx.stats[i], L.w2(L.Wt), L.gt, L.w2(L.Wr), L.gr,
+                            _as2d(g), buf, need_dx=want_dx, accumulate=accumulate)
+        dU = dIn
+    return dU if need_dx else None
+
+
+def _as2d(g: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    out = dict(g)
+    for k in ("Wt", "Wr"):
+        if out.get(k) is not None and out[k].dim() == 4:
+            out[k] = out[k].view(out[k].shape[0], out[k].shape[1])
+    return out

@@ -1,0 +1,91 @@
+"""Mirror of the reference's models/common/components.py (Encoder / Decoder / MLP) on the HIP path."""
+from __future__ import annotations
+
+from typing import List, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from ... import engine
+from ..graph_layers.stsgcn import ST_GCNN_layer, _PReLUFn, run_chain
+
+Tensor = torch.Tensor
+
+
+class _Stack(nn.Module):
+    """nn.Sequential of ST_GCNN layers run as one fused chain."""
+
+    def _build(self, chans: List[int], n_frames: int, n_joints: int, dropout: float, bias: bool) -> None:
+        layers = nn.ModuleList()
+        for ci, co in zip(chans[:-1], chans[1:]):
+            layers.append(ST_GCNN_layer(in_channels=ci, out_channels=co, kernel_size=(1, 1), stride=1,
+                                        time_dim=n_frames, joints_dim=n_joints, dropout=dropout, bias=bias))
+        self.model = nn.Sequential(*layers)
+        self._ws = engine.Workspace()
+
+    def forward_preact(self, X: Tensor) -> Tuple[Tensor, Tensor]:
+        """-> (U_last, slope_last): the fused path's hand-over to a consumer that applies PReLU on load."""
+        return run_chain(X, list(self.model), self._ws)
+
+    def forward(self, X: Tensor) -> Tensor:
+        u, slope = self.forward_preact(X)
+        return _PReLUFn.apply(u, slope)
+
+
+class Encoder(_Stack):
+    """STS-GCN encoder: channels input_dim -> layer_channels... -> hidden_dimension
+    (reference components.py:47-105)."""
+
+    def __init__(self, input_dim: int, layer_channels: List[int], hidden_dimension: int, n_frames: int,
+                 n_joints: int, dropout: float, bias: bool = True,
+                 device: Union[str, torch.device] = 'cpu') -> None:
+        super().__init__()
+        self.input_dim, self.layer_channels, self.hidden_dimension = input_dim, layer_channels, hidden_dimension
+        self.n_frames, self.n_joints, self.dropout, self.bias, self.device = n_frames, n_joints, dropout, bias, device
+        self.build_model()
+
+    def build_model(self) -> None:
+        self._build([self.input_dim] + list(self.layer_channels) + [self.hidden_dimension],
+                    self.n_frames, self.n_joints, self.dropout, self.bias)
+
+
+class Decoder(_Stack):
+    """STS-GCN decoder: hidden_dimension -> reversed(layer_channels)... -> output_dim
+    (reference components.py:109-179)."""
+
+    def __init__(self, output_dim: int, layer_channels: List[int], hidden_dimension: int, n_frames: int,
+                 n_joints: int, dropout: float, bias: bool = True,
+                 device: Union[str, torch.device] = 'cpu') -> None:
+        super().__init__()
+        self.output_dim, self.layer_channels, self.hidden_dimension = output_dim, list(layer_channels)[::-1], hidden_dimension
+        self.n_frames, self.n_joints, self.dropout, self.bias, self.device = n_frames, n_joints, dropout, bias, device
+        self.build_model()
+
+    def build_model(self) -> None:
+        self._build([self.hidden_dimension] + list(self.layer_channels) + [self.output_dim],
+                    self.n_frames, self.n_joints, self.dropout, self.bias)
+
+
+class MLP(nn.Module):
+    """[Linear -> BatchNorm1d -> ReLU] per hidden size + final Linear (reference components.py:183-240,
+    whose constructor is broken -- SURVEY 8a row a8; this implements the evident intent and accepts both
+    `hidden_layers=` and the `hidden_size=` spelling STSE passes at ae.py:161).  Secondary path: runs on
+    torch's own ROCm ops (parity unpinned)."""
+
+    def __init__(self, input_size: int, output_size: int, hidden_layers: List[int] = None, bias=True,
+                 device: Union[str, torch.device] = 'cpu', *, hidden_size: List[int] = None) -> None:
+        super().__init__()
+        hidden_layers = hidden_layers if hidden_layers is not None else hidden_size
+        self.input_size, self.output_size, self.hidden_layers, self.bias = input_size, output_size, list(hidden_layers or []), bias
+        self.build_model()
+
+    def build_model(self) -> None:
+        layer_list, input_size = [], self.input_size
+        for next_dim in self.hidden_layers:
+            layer_list += [nn.Linear(input_size, next_dim, bias=self.bias), nn.BatchNorm1d(next_dim), nn.ReLU(inplace=True)]
+            input_size = next_dim
+        layer_list.append(nn.Linear(input_size, self.output_size, bias=self.bias))
+        self.net = nn.Sequential(*layer_list)
+
+    def forward(self, X: Tensor) -> Tensor:
+        return self.net(X)

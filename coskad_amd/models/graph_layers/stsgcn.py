@@ -1,0 +1,177 @@
+"""Mirror of the reference's models/graph_layers/stsgcn.py on the HIP path.
+
+Same class names, constructor arguments, attribute / state_dict names
+(``gcn.A``, ``gcn.T``, ``tcn.0.weight``, ``tcn.1.running_mean``, ``residual.0.weight``,
+``prelu.weight`` ...), so a reference checkpoint loads unchanged.  The torch sub-modules
+(`nn.Conv2d`, `nn.BatchNorm2d`, `nn.PReLU`) are PARAMETER CONTAINERS only: forward never calls
+them; it calls the gfx950 kernels through coskad_amd.engine / coskad_amd.ops.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from ... import engine, ops
+
+Tensor = torch.Tensor
+
+
+class _GcnFn(torch.autograd.Function):
+    """ConvTemporalGraphical.forward (reference stsgcn.py:143-156) and its gradients."""
+
+    @staticmethod
+    def forward(ctx, X, A, T):
+        X = X.contiguous()
+        ctx.save_for_backward(X, A, T)
+        return ops.gcn(X, A.contiguous(), T.contiguous(), adjoint=False)
+
+    @staticmethod
+    def backward(ctx, dZ):
+        X, A, T = ctx.saved_tensors
+        dZ = dZ.contiguous()
+        dX = ops.gcn(dZ, A, T, adjoint=True) if ctx.needs_input_grad[0] else None
+        dA = dT = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dA, dT = ops.gcn_bwd_params(X, dZ, A, T)
+        return dX, dA, dT
+
+
+class ConvTemporalGraphical(nn.Module):
+    """Learned space-time-separable mixing: T[V,T,T] per joint, A[T,V,V] per frame
+    (reference stsgcn.py:120-156; init stsgcn.py:134-140)."""
+
+    def __init__(self, time_dim: int, joints_dim: int) -> None:
+        super().__init__()
+        self.A = nn.Parameter(torch.empty(time_dim, joints_dim, joints_dim))
+        stdv = 1.0 / math.sqrt(self.A.size(1))
+        self.A.data.uniform_(-stdv, stdv)
+        self.T = nn.Parameter(torch.empty(joints_dim, time_dim, time_dim))
+        stdv = 1.0 / math.sqrt(self.T.size(1))
+        self.T.data.uniform_(-stdv, stdv)
+
+    def forward(self, X: Tensor) -> Tensor:
+        return _GcnFn.apply(X, self.A, self.T)
+
+
+def layer_tensors(layer: "ST_GCNN_layer") -> engine.LayerTensors:
+    tc, tb = layer.tcn[0], layer.tcn[1]
+    has_res = not isinstance(layer.residual, nn.Identity)
+    rc, rb = (layer.residual[0], layer.residual[1]) if has_res else (None, None)
+    return engine.LayerTensors(
+        A=layer.gcn.A, T=layer.gcn.T, Wt=tc.weight, bt=tc.bias, gt=tb.weight, bet=tb.bias,
+        rm_t=tb.running_mean, rv_t=tb.running_var, nbt_t=tb.num_batches_tracked,
+        Wr=rc.weight if has_res else None, br=rc.bias if has_res else None,
+        gr=rb.weight if has_res else None, ber=rb.bias if has_res else None,
+        rm_r=rb.running_mean if has_res else None, rv_r=rb.running_var if has_res else None,
+        nbt_r=rb.num_batches_tracked if has_res else None, slope=layer.prelu.weight,
+        momentum=tb.momentum if tb.momentum is not None else 0.1)
+
+
+class _ChainFn(torch.autograd.Function):
+    """A stack of ST_GCNN layers as ONE autograd node.
+
+    forward(x, in_slope, meta, *params) -> U_last (pre-activation of the last layer).
+    meta = (layers, training, workspace).  Parameter order per layer = LayerTensors.param_list().
+    """
+
+    @staticmethod
+    def forward(ctx, x, in_slope, meta, *params):
+        layers, training, ws = meta
+        x = x.contiguous()
+        with torch.no_grad():
+            u, cctx = engine.chain_forward(x, layers, training, ws, in_slope=in_slope, want_ctx=True)
+        ctx.layers, ctx.cctx, ctx.ws, ctx.training = layers, cctx, ws, training
+        return u
+
+    @staticmethod
+    def backward(ctx, dU):
+        if not ctx.training:
+            raise RuntimeError("coskad_amd: backward through an eval-mode (running-stats) ST-GCN chain is not "
+                               "implemented; call .train() for training (reference trains in train mode)")
+        layers = ctx.layers
+        grads = []
+        for L in layers:
+            g = {n: torch.empty_like(p) for n, p in zip(L.grad_names(), L.param_list())}
+            grads.append(g)
+        # the last layer's slope gradient belongs to the consumer of U_last: zero here
+        grads[-1]["slope"].zero_()
+        need_dx = ctx.needs_input_grad[0]
+        dx = engine.chain_backward(ctx.cctx, layers, dU.contiguous(), ctx.ws, grads, need_dx=need_dx)
+        flat = []
+        for L, g in zip(layers, grads):
+            flat += [g[n] for n in L.grad_names()]
+        d_in_slope = None  # an external in_slope is not a parameter of this chain
+        return (dx, d_in_slope, None, *flat)
+
+
+def run_chain(x: Tensor, layer_modules: List["ST_GCNN_layer"], ws: engine.Workspace,
+              in_slope: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """-> (U_last, slope_last): pre-activation of the last layer and the PReLU weight to apply to it."""
+    layers = [layer_tensors(m) for m in layer_modules]
+    training = layer_modules[0].training
+    params: List[Tensor] = []
+    for L in layers:
+        params += L.param_list()
+    u = _ChainFn.apply(x, in_slope, (layers, training, ws), *params)
+    return u, layers[-1].slope
+
+
+class _PReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, slope):
+        u = u.contiguous()
+        ctx.save_for_backward(u, slope)
+        return ops.prelu_fwd(u, slope)
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, slope = ctx.saved_tensors
+        dslope = torch.empty_like(slope)
+        du = ops.prelu_bwd(u, dout.contiguous(), slope, dslope)
+        return du, dslope
+
+
+class ST_GCNN_layer(nn.Module):
+    """Space-Time-Separable graph-conv block (reference stsgcn.py:9-116):
+    out = PReLU( BN(Conv1x1(gcn(X))) + residual(X) ),  residual = BN(Conv1x1(X)) or identity."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: Union[Tuple[int], List[int]],
+                 stride: int, time_dim: int, joints_dim: int, dropout: float, bias: bool = True,
+                 emb_dim: int = None) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.stride, self.time_dim, self.joints_dim = stride, time_dim, joints_dim
+        self.dropout, self.bias, self.emb_dim, self.kernel_size = dropout, bias, emb_dim, kernel_size
+        assert self.kernel_size[0] % 2 == 1
+        assert self.kernel_size[1] % 2 == 1
+        if tuple(kernel_size) != (1, 1) or stride != 1:
+            raise NotImplementedError("coskad_amd ST_GCNN_layer: only kernel_size (1,1), stride 1 (what every "
+                                      "reference Encoder/Decoder builds, components.py:77-78,150-151)")
+        if dropout:
+            raise NotImplementedError("coskad_amd ST_GCNN_layer: dropout > 0 is not on the HIP path "
+                                      "(all reference configs use dropout: 0)")
+        if emb_dim is not None:
+            raise NotImplementedError("coskad_amd ST_GCNN_layer: emb_dim is unused by the reference's models")
+        self.build_model()
+        self._ws = engine.Workspace()
+
+    def build_model(self) -> None:
+        self.gcn = ConvTemporalGraphical(self.time_dim, self.joints_dim)
+        self.tcn = nn.Sequential(
+            nn.Conv2d(self.in_channels, self.out_channels, (1, 1), (1, 1), (0, 0), bias=self.bias),
+            nn.BatchNorm2d(self.out_channels),
+            nn.Dropout(self.dropout, inplace=True))
+        if self.stride != 1 or self.in_channels != self.out_channels:
+            self.residual = nn.Sequential(
+                nn.Conv2d(self.in_channels, self.out_channels, kernel_size=1, stride=(1, 1), bias=self.bias),
+                nn.BatchNorm2d(self.out_channels))
+        else:
+            self.residual = nn.Identity()
+        self.prelu = nn.PReLU()
+
+    def forward(self, X: Tensor, t: Tensor = None) -> Tensor:
+        u, slope = run_chain(X, [self], self._ws)
+        return _PReLUFn.apply(u, slope)

@@ -1,0 +1,145 @@
+"""Mirror of the reference's models/sts/ae.py (STSE, STSAE) on the HIP path.
+
+Accepts the shipped keyword set (`input_dim, layer_channels, hidden_dimension, ...`, ae.py:16-18) AND
+the legacy one the Lightning wrappers still use (`c_in, h_dim, channels`,
+euclidean_encoder_staticCenter.py:77-80) -- SURVEY 8b.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from ... import engine, ops
+from ..common.components import MLP, Decoder, Encoder
+from ..graph_layers.stsgcn import _PReLUFn
+
+Tensor = torch.Tensor
+
+
+class _BottleneckFn(torch.autograd.Function):
+    """z = Linear(flatten(PReLU_slope(U)))  (reference ae.py:97-101): PReLU fused into the load."""
+
+    @staticmethod
+    def forward(ctx, U, slope, W, b, ws):
+        U = U.contiguous()
+        ctx.save_for_backward(U, slope, W)
+        ctx.ws, ctx.has_bias = ws, b is not None
+        return ops.btlnk_fwd(U, W.contiguous(), b, slope)
+
+    @staticmethod
+    def backward(ctx, dz):
+        U, slope, W = ctx.saved_tensors
+        B, L = dz.shape
+        K = W.shape[1]
+        dW = torch.empty_like(W)
+        db = torch.empty(L, device=W.device, dtype=W.dtype) if ctx.has_bias else None
+        dslope = torch.empty_like(slope)
+        buf = ctx.ws.get(ops.btlnk_bwd_ws_bytes(B, K, L), U.device)
+        dU = ops.btlnk_bwd(U, W, dz.contiguous(), slope, dW, db, dslope, buf)
+        return dU, dslope, dW, db, None
+
+
+def _legacy(kw: dict, new: str, old: str, default=None):
+    if new in kw and kw[new] is not None:
+        return kw[new]
+    if old in kw and kw[old] is not None:
+        return kw[old]
+    return default
+
+
+class STSE(nn.Module):
+    """STS-GCN encoder + bottleneck to a latent pulled towards a centre `c` (reference ae.py:12-165)."""
+
+    encoder_classes = {'sts_gcn': Encoder}
+
+    def __init__(self, input_dim: int = None, layer_channels: List[int] = None, hidden_dimension: int = None,
+                 latent_dim: int = None, n_frames: int = None, n_joints: int = None, encoder_type: str = 'sts_gcn',
+                 projector: str = 'linear', distance: str = 'euclidean', dropout: float = 0.0, bias: bool = True,
+                 device: Union[str, torch.device] = 'cpu', *, projector_hidden_layers: List[int] = None,
+                 c_in: int = None, h_dim: int = None, channels: List[int] = None, **unused) -> None:
+        super().__init__()
+        self.input_dim = _legacy(dict(a=input_dim, b=c_in), 'a', 'b')
+        self.layer_channels = list(_legacy(dict(a=layer_channels, b=channels), 'a', 'b'))
+        self.hidden_dimension = _legacy(dict(a=hidden_dimension, b=h_dim), 'a', 'b')
+        self.latent_dim, self.n_frames, self.n_joints = latent_dim, n_frames, n_joints
+        self.encoder_type = encoder_type.lower()
+        self.projector = projector.lower()
+        # the reference's yamls select 'mlp' without giving sizes: default [latent_dim]
+        self.projector_hidden_layers = projector_hidden_layers if projector_hidden_layers is not None else [latent_dim]
+        self.distance = distance.lower()
+        self.dropout, self.bias, self.device = dropout, bias, device
+        self._ws = engine.Workspace()
+        self.build_model()
+
+    def build_model(self) -> None:
+        self._set_encoder_type()
+        self._set_projector_type()
+        self.register_buffer('c', torch.zeros(self.latent_dim))
+        if self.distance == 'mahalanobis':
+            self.register_buffer('inv_cov_matrix', torch.zeros((self.latent_dim, self.latent_dim)))
+
+    def _set_encoder_type(self) -> None:
+        if self.encoder_type in self.encoder_classes:
+            self.encoder = self.encoder_classes[self.encoder_type](
+                input_dim=self.input_dim, layer_channels=self.layer_channels, hidden_dimension=self.hidden_dimension,
+                n_frames=self.n_frames, n_joints=self.n_joints, dropout=self.dropout, bias=self.bias, device=self.device)
+        elif self.encoder_type in ('st_gcn', 'learnable_gcn', 'static_gcn'):
+            raise NotImplementedError(f"coskad_amd: encoder type {self.encoder_type} is outside the STS-GCN hot path "
+                                      "(SURVEY 8f rank 4)")
+        else:
+            raise ValueError(f'Encoder type {self.encoder_type} not supported.')
+
+    def _set_projector_type(self) -> None:
+        input_size = self.hidden_dimension * self.n_frames * self.n_joints
+        if self.projector == 'linear':
+            self.btlnk = nn.Linear(in_features=input_size, out_features=self.latent_dim, bias=self.bias)
+        elif self.projector == 'mlp':
+            self.btlnk = MLP(input_size=input_size, output_size=self.latent_dim,
+                             hidden_size=self.projector_hidden_layers, bias=self.bias, device=self.device)
+        else:
+            raise ValueError(f'Projector type {self.projector} not supported.')
+
+    def encode(self, X: Tensor, return_shape: bool = False):
+        assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
+        B = X.shape[0]
+        U, slope = self.encoder.forward_preact(X)   # [B, hid, T, V] pre-activation of the last layer
+        X_shape = (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)
+        if isinstance(self.btlnk, nn.Linear) and self.latent_dim <= 16:
+            Z = _BottleneckFn.apply(U, slope, self.btlnk.weight, self.btlnk.bias, self._ws)
+        else:
+            Z = self.btlnk(_PReLUFn.apply(U, slope).reshape(B, -1))
+        if return_shape:
+            return Z, X_shape
+        return Z
+
+    def forward(self, X: Tensor) -> Tensor:
+        return self.encode(X)
+
+
+class STSAE(STSE):
+    """STSE + rev_btlnk Linear + mirrored STS-GCN decoder (reference ae.py:168-265).  forward -> (Z, X_rec)."""
+
+    def build_model(self) -> None:
+        super().build_model()
+        self.rev_btlnk = nn.Linear(in_features=self.latent_dim,
+                                   out_features=self.hidden_dimension * self.n_frames * self.n_joints)
+        self._set_decoder_type()
+
+    def _set_decoder_type(self) -> None:
+        if self.encoder_type == 'sts_gcn':
+            self.decoder = Decoder(self.input_dim, self.layer_channels, self.hidden_dimension, self.n_frames,
+                                   self.n_joints, self.dropout, self.bias)
+        else:
+            raise ValueError(f'No decoder available for encoder type {self.encoder_type}.')
+
+    def decode(self, Z: Tensor, input_shape: Tuple[int]) -> Tensor:
+        B, C, T, V, M = input_shape
+        H = self.rev_btlnk(Z)            # latent -> hid*T*V (tiny GEMM, torch/rocBLAS)
+        H = H.view(B * M, C, T, V)
+        return self.decoder(H)
+
+    def forward(self, X: Tensor) -> Tuple[Tensor]:
+        Z, X_shape = self.encode(X, return_shape=True)
+        return Z, self.decode(Z, X_shape)

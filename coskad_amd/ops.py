@@ -264,3 +264,33 @@ def adam(p, g, m, v, mask, lr, beta1, beta2, eps, step, gscale=1.0, reg_coef=0.0
     call("coskad_adam_f32", ptr(p), ptr(g), ptr(m), ptr(v), ptr(mask), ctypes.c_size_t(p.numel()), ctypes.c_float(lr),
          ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), i32(step), ctypes.c_float(gscale),
          ctypes.c_float(reg_coef), _stream())
+
+
+def prelu_fwd(u: Tensor, slope: Tensor) -> Tensor:
+    _chk(u, "u"); _chk(slope, "slope", (1,))
+    out = torch.empty_like(u)
+    call("coskad_prelu_fwd_f32", ptr(u), ptr(slope), ptr(out), ctypes.c_size_t(u.numel()), _stream())
+    return out
+
+
+def prelu_bwd(u: Tensor, dout: Tensor, slope: Tensor, dslope: Optional[Tensor] = None, accumulate=False) -> Tensor:
+    _chk(u, "u"); _chk(dout, "dout", u.shape); _chk(slope, "slope", (1,)); _chk(dslope, "dslope", (1,), optional=True)
+    du = torch.empty_like(u)
+    ws = torch.empty(1024, device=u.device, dtype=torch.float32)
+    call("coskad_prelu_bwd_f32", ptr(u), ptr(dout), ptr(slope), ptr(du), ptr(dslope), ptr(ws),
+         i32(1 if accumulate else 0), ctypes.c_size_t(u.numel()), _stream())
+    return du
+
+
+def gcn_bwd_params(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor):
+    """(dA, dT) of ConvTemporalGraphical given its input and output gradient."""
+    N, C, T, V = x.shape
+    _chk(x, "x"); _chk(dZ, "dZ", x.shape); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
+    fn = _lib.lib().coskad_gcn_bwd_params_ws_bytes
+    fn.restype = ctypes.c_size_t
+    nbytes = fn(i32(T), i32(V))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dA, dT = torch.empty_like(A), torch.empty_like(Tm)
+    call("coskad_gcn_bwd_params_f32", ptr(x), ptr(dZ), ptr(A), ptr(Tm), ptr(dA), ptr(dT), ptr(ws),
+         ctypes.c_size_t(nbytes), i32(0), i32(N * C), i32(T), i32(V), _stream())
+    return dA, dT

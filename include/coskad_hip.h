@@ -46,6 +46,13 @@ int coskad_layer_apply_f32(const float* in, float* out, const float* A, const fl
                            const float* out_slope, int B, int Ci, int Co, int T, int V,
                            hipStream_t stream);
 
+/* nn.PReLU() with one shared weight (stsgcn.py:82,110), elementwise, for API paths that must
+ * materialise the post-activation tensor.  bwd: du = dout * PReLU'(u); dslope (+)= sum dout*u [u<0];
+ * ws >= 1024 floats. */
+int coskad_prelu_fwd_f32(const float* u, const float* slope, float* out, size_t n, hipStream_t stream);
+int coskad_prelu_bwd_f32(const float* u, const float* dout, const float* slope, float* du, float* dslope,
+                         float* ws, int accumulate, size_t n, hipStream_t stream);
+
 /* ---- train-mode BatchNorm statistics -------------------------------------------------- */
 
 /* Bytes of scratch `ws` that coskad_layer_train_stats_f32 needs for C_in = Ci. */
@@ -85,6 +92,13 @@ int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const
                          float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
                          float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                          int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream);
+
+/* Parameter gradients of ConvTemporalGraphical alone (stsgcn.py:154-155), given its input x and
+ * the gradient dZ of its output; rows = N*C. */
+size_t coskad_gcn_bwd_params_ws_bytes(int T, int V);
+int coskad_gcn_bwd_params_f32(const float* x, const float* dZ, const float* A, const float* Tm, float* dA,
+                              float* dT, void* ws, size_t ws_bytes, int accumulate, int rows, int T, int V,
+                              hipStream_t stream);
 
 /* ---- bottleneck Linear (models/sts/ae.py:97-101,157) ---------------------------------- */
 

@@ -1,0 +1,91 @@
+"""GPU parity of the module mirror (STSE / STSAE with the reference's names) against the golden vectors:
+reference checkpoints load by key, forward and torch-autograd backward match."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import state_from
+
+pytestmark = pytest.mark.gpu
+
+
+def build_stse(g, cls=None, **kw):
+    from coskad_amd.models.sts.ae import STSE
+    st = state_from(g)
+    chans = []
+    i = 0
+    while f"encoder.model.{i}.tcn.0.weight" in st:
+        chans.append(st[f"encoder.model.{i}.tcn.0.weight"].shape[0])
+        i += 1
+    V = st["encoder.model.0.gcn.A"].shape[1]
+    m = (cls or STSE)(input_dim=2, layer_channels=chans[:-1], hidden_dimension=chans[-1], latent_dim=st["c"].shape[0],
+                      n_frames=12, n_joints=V, encoder_type='STS_GCN', projector='linear', distance='euclidean', dropout=0.0, **kw)
+    missing, unexpected = m.load_state_dict(st, strict=True)
+    return m.cuda(), st
+
+
+@pytest.mark.parametrize("name", ["stse_default.npz", "stse_v25.npz", "stse_b1.npz"])
+def test_stse_eval_and_train_step(golden, name):
+    g = golden(name)
+    m, st = build_stse(g)
+    assert set(m.state_dict().keys()) == set(st.keys())
+    x = torch.from_numpy(g["x"]).cuda()
+    m.eval()
+    with torch.no_grad():
+        z = m(x)
+    np.testing.assert_allclose(z.cpu().numpy(), g["eval.z"], rtol=1e-4, atol=1e-4)
+    # one train step with torch autograd driving the HIP nodes
+    m.train()
+    c = torch.from_numpy(g["c"]).cuda()
+    z = m(x)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["train.z"], rtol=1e-4, atol=1e-4)
+    loss = ((z - c) ** 2).mean()
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["train.loss_hypersphere"], rtol=1e-4)
+    gmax = max(np.abs(g["grad." + n]).max() for n, _ in m.named_parameters())
+    for n, p in m.named_parameters():
+        ref = g["grad." + n]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max() + 2e-5 * gmax, err_msg=n)
+    for k, v in g.items():
+        if k.startswith("sd1.") and k != "sd1.c":
+            np.testing.assert_allclose(m.state_dict()[k[4:]].cpu().numpy(), v, rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_legacy_keywords(golden):
+    from coskad_amd.models.sts.ae import STSE
+    m = STSE(c_in=2, h_dim=64, latent_dim=16, n_frames=12, dropout=0.0, n_joints=17, channels=[32, 16, 32],
+             projector='linear', encoder_type='STS_GCN')
+    assert sum(p.numel() for p in m.parameters()) == 239716
+    with pytest.raises(ValueError):
+        STSE(c_in=2, h_dim=64, latent_dim=16, n_frames=12, dropout=0.0, n_joints=17, channels=[32, 16, 32], encoder_type='nope')
+
+
+def test_stsae(golden):
+    from coskad_amd.models.sts.ae import STSAE
+    g = golden("stsae_small.npz")
+    m, st = build_stse(g, cls=STSAE)
+    x = torch.from_numpy(g["x"]).cuda()
+    m.eval()
+    with torch.no_grad():
+        z, xr = m(x)
+    np.testing.assert_allclose(z.cpu().numpy(), g["eval.z"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(xr.cpu().numpy(), g["eval.xrec"], rtol=1e-4, atol=1e-4)
+    m.train()
+    z, xr = m(x)
+    np.testing.assert_allclose(xr.detach().cpu().numpy(), g["train.xrec"], rtol=2e-4, atol=2e-4)
+    c = torch.from_numpy(g["c"]).cuda()
+    loss = ((xr - x) ** 2).mean() + ((z - c) ** 2).mean()
+    np.testing.assert_allclose(loss.item(), g["train.loss"], rtol=1e-4)
+    loss.backward()
+    gmax = max(np.abs(g["grad." + n]).max() for n, _ in m.named_parameters())
+    for n, p in m.named_parameters():
+        ref = g["grad." + n]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max() + 5e-5 * gmax, err_msg=n)
+
+
+def test_cpu_tensor_fails_loudly():
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd._lib import CoskadHipError
+    m = STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    with pytest.raises(CoskadHipError):
+        m(torch.zeros(2, 2, 12, 17))
