@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""bench.py -- pose-clips/sec of the STS-GCN encoder train step (fwd + loss + reg + bwd + Adam).
+
+Workload (BASELINE.json configs[1]): euclidean_encoder_dynamicCenter, synthetic clips
+B=4096 per GPU, T=12, V=17, C=2, channels 2->32->16->32->64, latent 16, fp32.
+  python bench.py --gpus N --steps K --warmup W       (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.
+
+roofline  : the dominant kernel's ALGORITHMIC bytes per launch / its average duration, measured with HIP
+            events on the launch stream inside the timed region, against 8 TB/s (MI355X_MICROARCH.md).
+cpu_baseline: the CPU oracle (oracle/ref_cpu.py: plain PyTorch CPU ops, pinned to the reference by golden
+            vectors) doing the same train step on a bounded sample on this box's host cores (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T, V, C_IN = 12, 17, 2
+CHANNELS, HID, LATENT = [32, 16, 32], 64, 16
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def algorithmic_bytes_per_clip():
+    """every layer reads its input once and writes its output once (fp32)."""
+    chans = [C_IN] + CHANNELS + [HID]
+    tv = T * V
+    fwd = sum(4 * tv * (ci + co) for ci, co in zip(chans[:-1], chans[1:])) + 4 * HID * tv + 4 * LATENT
+    # backward per layer: read dOut, read saved input, write dIn (no dIn for layer 1); bottleneck: read U, dz; write dU
+    bwd = (2 * 4 * HID * tv + 2 * 4 * LATENT)
+    for i, (ci, co) in enumerate(zip(chans[:-1], chans[1:])):
+        bwd += 4 * tv * (co + ci + (ci if i > 0 else 0))
+    return fwd, bwd
+
+
+def cpu_baseline(sample_b: int, iters: int):
+    import torch
+    from oracle import ref_cpu as R
+    # the GPU box gives a one-GPU job a 16-core share; os.cpu_count() reports the whole host and
+    # oversubscribing OpenMP threads makes the CPU path crawl
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))
+    st = R.init_stse_state(seed=0)
+    st["c"] = torch.full((LATENT,), 0.1)
+    params = {k: v.requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4)
+    x = R.synthetic_clips(sample_b, seed=1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        z = R.stse_encode(x, st, training=True)
+        loss = R.mse_to_center(z, st["c"]) + 1e-6 * R.calc_reg_loss(list(params.items()))
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(sample_b / dt, 1), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} train steps (fwd+loss+reg+bwd+Adam) of the CPU oracle on B={sample_b} synthetic clips"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="clips per GPU (weak scaling)")
+    ap.add_argument("--head", default="euclidean", choices=["euclidean", "poincare"])
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("COSKAD_GRAPH", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=512)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from coskad_amd import _lib
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import STSETrainStep
+    from oracle import ref_cpu as R  # synthetic inputs / initialisers only (and cpu_baseline)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl")  # RCCL on ROCm
+
+    B = args.batch
+    st = R.init_stse_state(C_IN, CHANNELS, HID, LATENT, T, V, seed=0)   # same weights on every rank
+    st["c"] = torch.full((LATENT,), 0.1)
+    model = STSE(C_IN, CHANNELS, HID, LATENT, T, V, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    model.load_state_dict(st, strict=True)
+    model.cuda().train()
+    eng = STSETrainStep(model, lr=1e-4, alpha=1e-6, head=args.head, use_graph=bool(args.graph))
+    x = R.synthetic_clips(B, C_IN, T, V, seed=100 + rank).cuda()   # each rank: its own shard of clips
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(x)
+    sync()
+    # dominant kernel probe: the layer-4 forward kernel (32 -> 64 channels), one kernel per C-ABI call
+    probe = {"name": "coskad_layer_apply_f32", "tag": (CHANNELS[-1], HID), "events": []}
+    if not args.graph:
+        _lib.PROBE = probe
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = eng.step(x)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.PROBE = None
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = float(stats[0])
+
+    if rank == 0:
+        fwd_b, bwd_b = algorithmic_bytes_per_clip()
+        roof = None
+        if probe["events"]:
+            ms = sum(a.elapsed_time(b) for a, b in probe["events"]) / len(probe["events"])
+            byts = B * 4 * T * V * (CHANNELS[-1] + HID)      # layer 4: read 32 ch, write 64 ch, per launch
+            ach = byts / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_layer_apply<12,17,8> (layer 4, 32->64)", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": round(ms * 1e3, 2), "launches": len(probe["events"])}
+        out = {
+            "metric": "pose_clips_per_sec_fwd_bwd", "value": round(world * B * args.steps / dt, 1), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "euclidean_encoder_dynamicCenter train step (fwd+mse-to-centre+L2 reg+bwd+Adam), "
+                                   f"synthetic clips B={B}/GPU T={T} V={V} C={C_IN}, channels 2-32-16-32-64, latent 16",
+                       "clips_per_gpu": B, "global_batch": B * world, "head": args.head,
+                       "parallelism": f"dp{world}", "hip_graph": bool(args.graph)},
+            "algorithmic_bytes_per_clip": {"fwd": fwd_b, "bwd": bwd_b},
+            "step_hbm_frac": round(world * B * args.steps / dt * (fwd_b + bwd_b) / world / (HBM_PEAK_GBS * 1e9), 4),
+            "final_loss": round(loss, 6),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 8)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

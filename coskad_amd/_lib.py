@@ -34,17 +34,34 @@ def lib() -> ctypes.CDLL:
             raise CoskadHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C coskad_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch ships its own libamdhip64; load it FIRST so this library binds to the same HIP runtime
+        # (two runtimes in one process do not share devices/streams).
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.coskad_last_error.restype = ctypes.c_char_p
         _lib.coskad_abi_version.restype = ctypes.c_int
     return _lib
 
 
-def call(name: str, *args) -> None:
+# Optional per-call timing probe (bench.py): PROBE = {"name": <entry point>, "filter": callable or None,
+# "events": []}.  When set, matching calls are bracketed by HIP events on torch's current stream (the
+# stream every kernel of this library is enqueued on).
+PROBE = None
+
+
+def call(name: str, *args, tag=None) -> None:
     """Call an `int coskad_*(...)` entry point; raise on a non-zero return."""
     fn = getattr(lib(), name)
     fn.restype = ctypes.c_int
-    rc = fn(*args)
+    if PROBE is not None and PROBE["name"] == name and (PROBE.get("tag") is None or PROBE["tag"] == tag):
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        PROBE["events"].append((e0, e1))
+    else:
+        rc = fn(*args)
     if rc != 0:
         msg = lib().coskad_last_error().decode(errors="replace")
         raise CoskadHipError(f"{name} failed ({rc}): {msg}")

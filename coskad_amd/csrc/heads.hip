@@ -304,6 +304,33 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
   p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// hyper[0] = lr, hyper[1] = beta1^t, hyper[2] = beta2^t  (device-resident so a captured hipGraph can be
+// replayed: the step count advances in memory, not in kernel arguments)
+__global__ void k_adam_tick(float* __restrict__ hyper, float beta1, float beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    hyper[1] *= beta1;
+    hyper[2] *= beta2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ mask, size_t n,
+                                                   const float* __restrict__ hyper, float beta1, float beta2,
+                                                   float eps, float gscale, float reg_coef) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float lr = hyper[0], bc1 = 1.f - hyper[1], bc2s = sqrtf(1.f - hyper[2]);
+  const float pi = p[i];
+  float gi = g[i] * gscale;
+  if (reg_coef != 0.f) gi = fmaf(reg_coef * (mask ? mask[i] : 1.f), pi, gi);
+  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = pi - (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+}
+
 __global__ __launch_bounds__(256) void k_scale_sum(const float* __restrict__ v, int n, float scale,
                                                     float* __restrict__ out) {
   __shared__ double sh[256];
@@ -407,6 +434,17 @@ int coskad_adam_f32(float* p, const float* g, float* m, float* v, const float* m
   hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, mask, n, lr,
                      beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), gscale, reg_coef);
   return check_launch("adam");
+}
+
+/* Same update with lr / beta^t read from device memory: hyper = {lr, beta1^t, beta2^t} (initialise to
+ * {lr, 1, 1}); every call first advances beta^t, so the call is replayable inside a hipGraph. */
+int coskad_adam_dev_f32(float* p, const float* g, float* m, float* v, const float* mask, size_t n, float* hyper,
+                        float beta1, float beta2, float eps, float gscale, float reg_coef, hipStream_t stream) {
+  if (!p || !g || !m || !v || !hyper || n == 0) return fail(COSKAD_ERR_ARG, "adam_dev: bad argument");
+  hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, stream, hyper, beta1, beta2);
+  hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, mask, n, hyper,
+                     beta1, beta2, eps, gscale, reg_coef);
+  return check_launch("adam_dev");
 }
 
 }  // extern "C"

@@ -78,7 +78,7 @@ def layer_apply(x: Tensor, A: Tensor, Tm: Tensor, wfold: Tensor, bias: Tensor, C
     else:
         _chk(out, "out", (B, Co, T, V))
     call("coskad_layer_apply_f32", ptr(x), ptr(out), ptr(A), ptr(Tm), ptr(wfold), ptr(bias),
-         ptr(in_slope), ptr(out_slope), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+         ptr(in_slope), ptr(out_slope), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream(), tag=(Ci, Co))
     return out
 
 
@@ -294,3 +294,13 @@ def gcn_bwd_params(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor):
     call("coskad_gcn_bwd_params_f32", ptr(x), ptr(dZ), ptr(A), ptr(Tm), ptr(dA), ptr(dT), ptr(ws),
          ctypes.c_size_t(nbytes), i32(0), i32(N * C), i32(T), i32(V), _stream())
     return dA, dT
+
+
+def adam_dev(p, g, m, v, mask, hyper, beta1, beta2, eps, gscale=1.0, reg_coef=0.0):
+    """Adam with {lr, beta1^t, beta2^t} in the device tensor `hyper` (replayable in a hipGraph)."""
+    for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, n, p.shape)
+    _chk(mask, "mask", p.shape, optional=True); _chk(hyper, "hyper", (4,))
+    call("coskad_adam_dev_f32", ptr(p), ptr(g), ptr(m), ptr(v), ptr(mask), ctypes.c_size_t(p.numel()), ptr(hyper),
+         ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(gscale),
+         ctypes.c_float(reg_coef), _stream())

@@ -1,0 +1,154 @@
+"""Explicit (autograd-free) train step of STSE on the HIP path: forward, one-class head, backward,
+regulariser, Adam -- the reference's `training_step` + optimizer step
+(models/euclidean_encoder_dynamicCenter.py:105-122, models/hyperbolic_encoder.py:137-172, Adam at :196)
+as a fixed sequence of C-ABI calls on flat parameter / gradient buffers.
+
+Data parallelism (reference: Lightning DDPStrategy, train_COSKAD.py:78): one process per GPU, clips
+sharded over ranks, ONE all-reduce of the flat fp32 gradient buffer per step over RCCL, centre statistics
+all-reduced when the centre is refreshed.  BatchNorm statistics stay per rank (reference semantics: no
+sync_batchnorm).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import engine, ops
+from .models.graph_layers.stsgcn import layer_tensors
+
+Tensor = torch.Tensor
+
+
+class FlatParams:
+    """Re-home a module's parameters as views of one flat fp32 buffer (+ a flat gradient buffer),
+    in named_parameters() order.  state_dict keys and shapes are untouched."""
+
+    def __init__(self, module: torch.nn.Module) -> None:
+        named = [(n, p) for n, p in module.named_parameters()]
+        self.names = [n for n, _ in named]
+        total = sum(p.numel() for _, p in named)
+        dev = named[0][1].device
+        self.flat = torch.empty(total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        # regulariser mask: calc_reg_loss skips tensors whose NAME contains 'bias' (model_utils.py:92)
+        self.reg_mask = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.views: Dict[str, Tensor] = {}
+        self.gviews: Dict[str, Tensor] = {}
+        self.n_reg_tensors = 0
+        off = 0
+        for n, p in named:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            self.views[n], self.gviews[n] = p.data, p.grad
+            if 'bias' not in n:
+                self.reg_mask[off:off + k] = 1.0
+                self.n_reg_tensors += 1
+            off += k
+
+
+class STSETrainStep:
+    """One-class training of an STSE (linear projector) without autograd.
+
+    head: 'euclidean' -> F.mse_loss(z, c);  'poincare' -> dist(c, project(expmap0(z))).mean().
+    """
+
+    def __init__(self, model, lr: float = 1e-4, alpha: float = 1e-6, head: str = 'euclidean',
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, use_graph: bool = False) -> None:
+        from .models.sts.ae import STSE
+        if not isinstance(model, STSE) or not isinstance(model.btlnk, torch.nn.Linear):
+            raise TypeError("STSETrainStep drives an STSE with projector='linear'")
+        self.model, self.head, self.alpha = model, head, float(alpha)
+        self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.fp = FlatParams(model)
+        dev = self.fp.flat.device
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], device=dev, dtype=torch.float32)
+        self.layers = [layer_tensors(l) for l in model.encoder.model]
+        self.ws = engine.Workspace()
+        self.center_acc = torch.zeros(ops.HEAD_SLOTS, device=dev, dtype=torch.float32)
+        self.reg_scale = 0.5 / self.fp.n_reg_tensors          # calc_reg_loss value = reg_scale * sum p^2
+        self.reg_coef = self.alpha * 2.0 * self.reg_scale      # its gradient coefficient, times alpha
+        # gradient views per layer, in the kernels' vocabulary
+        self.grads: List[Dict[str, Tensor]] = []
+        for i, L in enumerate(self.layers):
+            pre = f"encoder.model.{i}."
+            g = {"A": pre + "gcn.A", "T": pre + "gcn.T", "Wt": pre + "tcn.0.weight", "bt": pre + "tcn.0.bias",
+                 "gt": pre + "tcn.1.weight", "bet": pre + "tcn.1.bias", "Wr": pre + "residual.0.weight",
+                 "br": pre + "residual.0.bias", "gr": pre + "residual.1.weight", "ber": pre + "residual.1.bias",
+                 "slope": pre + "prelu.weight"}
+            self.grads.append({k: self.fp.gviews[n] for k, n in g.items() if n in self.fp.gviews})
+        self.use_graph = use_graph
+        self._graph = None
+        self._x_static: Optional[Tensor] = None
+        self._stats_static: Optional[Tensor] = None
+        self.steps = 0
+
+    def set_lr(self, lr: float) -> None:
+        self.hyper[0] = lr
+
+    # -- the step ---------------------------------------------------------------------------
+    def _body(self, x: Tensor) -> Tensor:
+        m = self.model
+        B = x.shape[0]
+        U, ctx = engine.chain_forward(x, self.layers, True, self.ws, want_ctx=True)
+        slope = self.layers[-1].slope
+        W, b = m.btlnk.weight, m.btlnk.bias
+        z = ops.btlnk_fwd(U, W, b, slope)
+        if self.head == 'euclidean':
+            stats, dz, _ = ops.mse_head(z, m.c, acc=self.center_acc)
+        elif self.head == 'poincare':
+            stats, dz, _, _ = ops.poincare_head(z, m.c, acc=self.center_acc)
+        else:
+            raise ValueError(f"unknown head {self.head}")
+        K = W.shape[1]
+        buf = self.ws.get(ops.btlnk_bwd_ws_bytes(B, K, W.shape[0]), x.device)
+        dU = ops.btlnk_bwd(U, W, dz, slope, self.fp.gviews["btlnk.weight"],
+                           self.fp.gviews.get("btlnk.bias"), self.grads[-1]["slope"], buf)
+        engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False)
+        if self.world > 1:
+            dist.all_reduce(self.fp.grad, group=self.pg)   # RCCL, one flat 0.96 MB buffer
+        ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,
+                     self.beta2, self.eps, gscale=1.0 / self.world, reg_coef=self.reg_coef)
+        return stats
+
+    def step(self, x: Tensor) -> Tensor:
+        """One optimisation step on clips x [B,C,T,V]; returns the head's stats block (stats[0] = loss)."""
+        self.steps += 1
+        if not self.use_graph:
+            return self._body(x)
+        if self._graph is None or self._x_static.shape != x.shape:
+            self._x_static = x.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):          # warm-up outside capture (allocator, lazy module load)
+                self._body(self._x_static)
+            torch.cuda.current_stream().wait_stream(s)
+            self.steps += 1
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._stats_static = self._body(self._x_static)
+        self._x_static.copy_(x)
+        self._graph.replay()
+        return self._stats_static
+
+    def reg_loss(self) -> Tensor:
+        """utils/model_utils.py::calc_reg_loss value of the current parameters (1-element tensor)."""
+        return ops.sqnorm(self.fp.flat, self.fp.reg_mask, self.reg_scale)
+
+    # -- centre bookkeeping (staticCenter.py:145-155; hyperbolic_encoder.py:175-183) ----------
+    def refresh_center(self, eps: float = 1e-3) -> Tensor:
+        """c <- statistics accumulated since the last refresh (all-reduced over ranks), then reset them."""
+        if self.world > 1:
+            dist.all_reduce(self.center_acc, group=self.pg)
+        L = self.model.latent_dim
+        c = ops.center_finalize(self.center_acc, eps, L) if self.head == 'euclidean' else ops.midpoint_finalize(self.center_acc, L)
+        self.model.c.copy_(c)
+        self.center_acc.zero_()
+        return self.model.c

@@ -143,6 +143,10 @@ int coskad_adam_f32(float* p, const float* g, float* m, float* v, const float* m
                     float beta1, float beta2, float eps, int step, float gscale, float reg_coef,
                     hipStream_t stream);
 
+/* Adam with {lr, beta1^t, beta2^t} in device memory (hipGraph-replayable; init hyper = {lr, 1, 1}). */
+int coskad_adam_dev_f32(float* p, const float* g, float* m, float* v, const float* mask, size_t n, float* hyper,
+                        float beta1, float beta2, float eps, float gscale, float reg_coef, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
