@@ -1,0 +1,67 @@
+"""Data parallelism for the hot path: one process per GPU, clips sharded over ranks, RCCL over xGMI.
+
+The reference relies on Lightning's DDPStrategy (train_COSKAD.py:75-78): DistributedSampler sharding,
+bucketed gradient all-reduce, rank-0 buffer broadcast.  Here the model is 0.96 MB, so the whole gradient
+is ONE flat fp32 buffer and ONE all-reduce per step (latency-bound, 2*(W-1)/W*0.96 MB on the wire), and
+the running centre statistics (19 floats) are all-reduced when the centre is refreshed -- which makes the
+W-GPU centre equal the single-process one (the reference lets rank 0's centre win).
+
+These helpers are device-agnostic (`nccl` = RCCL on the GPUs, `gloo` in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+Tensor = torch.Tensor
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def shard_indices(n: int, rank_: int, world: int) -> torch.Tensor:
+    """DistributedSampler(shuffle=False) semantics: rank r takes clips r, r+W, r+2W, ...; the tail is padded
+    by wrapping so every rank gets ceil(n/W) clips."""
+    per = (n + world - 1) // world
+    idx = torch.arange(rank_, rank_ + per * world, world)
+    return idx % n
+
+
+def allreduce_mean_(flat_grad: Tensor, group=None) -> Tensor:
+    """In-place mean over ranks of the flat gradient buffer (DDP semantics: SUM then / W)."""
+    w = world_size(group)
+    if w > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+        flat_grad.div_(w)
+    return flat_grad
+
+
+def allreduce_sum_(stats: Tensor, group=None) -> Tensor:
+    """In-place sum over ranks of additive statistics (centre sums / counts, gyromidpoint sums)."""
+    if world_size(group) > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    return stats
+
+
+def broadcast_(t: Tensor, src: int = 0, group=None) -> Tensor:
+    if world_size(group) > 1:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def gather_rows(t: Tensor, group=None) -> Tensor:
+    """all_gather of per-rank row blocks [N_r, ...] (equal N_r) -> [W*N_r, ...] in rank order
+    (validation: latents + metadata to score on every rank)."""
+    w = world_size(group)
+    if w == 1:
+        return t
+    out = [torch.empty_like(t) for _ in range(w)]
+    dist.all_gather(out, t.contiguous(), group=group)
+    return torch.cat(out, dim=0)

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from . import engine, ops
+from . import engine, ops, parallel
 from .models.graph_layers.stsgcn import layer_tensors
 
 Tensor = torch.Tensor
@@ -113,7 +113,7 @@ class STSETrainStep:
                            self.fp.gviews.get("btlnk.bias"), self.grads[-1]["slope"], buf)
         engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False)
         if self.world > 1:
-            dist.all_reduce(self.fp.grad, group=self.pg)   # RCCL, one flat 0.96 MB buffer
+            dist.all_reduce(self.fp.grad, group=self.pg)   # RCCL, one flat 0.96 MB buffer (SUM; /W in Adam)
         ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,
                      self.beta2, self.eps, gscale=1.0 / self.world, reg_coef=self.reg_coef)
         return stats
@@ -145,8 +145,7 @@ class STSETrainStep:
     # -- centre bookkeeping (staticCenter.py:145-155; hyperbolic_encoder.py:175-183) ----------
     def refresh_center(self, eps: float = 1e-3) -> Tensor:
         """c <- statistics accumulated since the last refresh (all-reduced over ranks), then reset them."""
-        if self.world > 1:
-            dist.all_reduce(self.center_acc, group=self.pg)
+        parallel.allreduce_sum_(self.center_acc, self.pg)
         L = self.model.latent_dim
         c = ops.center_finalize(self.center_acc, eps, L) if self.head == 'euclidean' else ops.midpoint_finalize(self.center_acc, L)
         self.model.c.copy_(c)

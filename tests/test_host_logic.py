@@ -1,0 +1,90 @@
+"""Host-side logic that needs no GPU: module surface, state_dict contract, flat-parameter views,
+regulariser mask, loud failure on CPU tensors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import state_from
+from oracle import ref_cpu as R
+
+
+def test_state_dict_contract(golden):
+    from coskad_amd.models.sts.ae import STSE, STSAE
+    g = golden("stse_default.npz")
+    st = state_from(g)
+    m = STSE(2, [32, 16, 32], 64, 16, 12, 17, 'STS_GCN', 'linear', 'euclidean', 0.0)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(st.keys())          # same names, same order as the reference
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(st[k].shape), k
+    m.load_state_dict(st, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 239716
+    ga = golden("stsae_small.npz")
+    ma = STSAE(2, [16, 8, 16], 16, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    ma.load_state_dict(state_from(ga), strict=True)
+    mm = STSE(2, [8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'mahalanobis', 0.0)
+    assert tuple(mm.inv_cov_matrix.shape) == (8, 8)
+
+
+def test_reference_initialisers():
+    from coskad_amd.models.graph_layers.stsgcn import ConvTemporalGraphical, ST_GCNN_layer
+    torch.manual_seed(0)
+    g = ConvTemporalGraphical(12, 17)
+    assert g.A.shape == (12, 17, 17) and g.T.shape == (17, 12, 12)
+    assert g.A.abs().max() <= 1 / 17 ** 0.5 and g.T.abs().max() <= 1 / 12 ** 0.5   # stsgcn.py:134-140
+    layer = ST_GCNN_layer(4, 4, (1, 1), 1, 12, 17, 0.0)
+    assert isinstance(layer.residual, torch.nn.Identity)                            # stsgcn.py:79-80
+    assert float(layer.prelu.weight) == 0.25
+    with pytest.raises(AssertionError):
+        ST_GCNN_layer(4, 8, (2, 1), 1, 12, 17, 0.0)                                 # stsgcn.py:40-41
+    with pytest.raises(NotImplementedError):
+        ST_GCNN_layer(4, 8, (3, 3), 1, 12, 17, 0.0)
+
+
+def test_unknown_types_raise_like_reference():
+    from coskad_amd.models.sts.ae import STSE
+    with pytest.raises(ValueError):
+        STSE(2, [8], 8, 8, 12, 17, 'nope', 'linear', 'euclidean', 0.0)      # ae.py:142
+    with pytest.raises(ValueError):
+        STSE(2, [8], 8, 8, 12, 17, 'sts_gcn', 'nope', 'euclidean', 0.0)     # ae.py:164
+    m = STSE(2, [8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    with pytest.raises(AssertionError):
+        m(torch.zeros(2, 2, 12))                                            # ae.py:88
+
+
+def test_product_path_has_no_cpu_fallback():
+    from coskad_amd._lib import CoskadHipError
+    from coskad_amd.models.sts.ae import STSE
+    m = STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    with pytest.raises(CoskadHipError, match="no CPU fallback"):
+        m(torch.zeros(2, 2, 12, 17))
+
+
+def test_flat_params_and_reg_mask():
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import FlatParams
+    m = STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    fp = FlatParams(m)
+    assert fp.flat.numel() == sum(p.numel() for p in m.parameters())
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    # parameters are views of the flat buffer: writing the buffer changes the module
+    fp.flat.zero_()
+    assert all(float(p.abs().sum()) == 0 for p in m.parameters())
+    fp.flat.copy_(torch.arange(fp.flat.numel(), dtype=torch.float32))
+    named = list(m.named_parameters())
+    assert float(named[0][1].reshape(-1)[0]) == 0.0
+    # reg mask == calc_reg_loss's name filter (utils/model_utils.py:92)
+    n_nonbias = sum(1 for n, _ in named if 'bias' not in n)
+    assert fp.n_reg_tensors == n_nonbias
+    ref = R.calc_reg_loss([(n, p.detach()) for n, p in named])
+    mine = 0.5 / fp.n_reg_tensors * float((fp.reg_mask * fp.flat * fp.flat).sum())
+    np.testing.assert_allclose(mine, float(ref), rtol=1e-6)
+
+
+def test_bench_byte_model():
+    import bench
+    fwd, bwd = bench.algorithmic_bytes_per_clip()
+    assert fwd == 236704
+    assert abs(bwd - 354208) <= 64  # SURVEY 8d (+ the dz read)
