@@ -168,21 +168,20 @@ __global__ __launch_bounds__(256) void k_sum_scalar(const float* __restrict__ v,
   if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)sh[0] : (float)sh[0];
 }
 
-// db[j] = sum_n dz[n][j]   (single block; B*L is tiny next to the activations)
+// db[j] = sum_n dz[n][j]: one block per latent column, 256 threads stride over the clips
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dz, int B, int L,
                                                  float* __restrict__ db, int accumulate) {
   __shared__ double sh[256];
-  const int j = threadIdx.x % L, sl = threadIdx.x / L, nsl = 256 / L;
+  const int j = blockIdx.x;
   double s = 0.0;
-  if (sl < nsl)
-    for (int n = sl; n < B; n += nsl) s += (double)dz[(size_t)n * L + j];
-  sh[threadIdx.x] = sl < nsl ? s : 0.0;
+  for (int n = threadIdx.x; n < B; n += 256) s += (double)dz[(size_t)n * L + j];
+  sh[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x < L) {
-    double t = 0.0;
-    for (int k = 0; k < nsl; ++k) t += sh[k * L + threadIdx.x];
-    db[threadIdx.x] = accumulate ? db[threadIdx.x] + (float)t : (float)t;
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) db[j] = accumulate ? db[j] + (float)sh[0] : (float)sh[0];
 }
 
 static int btl_chunks(int B) {
@@ -230,7 +229,7 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
   if (rc) return rc;
   const size_t E = (size_t)L * K;
   hipLaunchKernelGGL(k_reduce_partials_f32, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, dWp, S, E, dW, accumulate);
-  if (db) hipLaunchKernelGGL(k_colsum, dim3(1), dim3(256), 0, stream, dz, B, L, db, accumulate);
+  if (db) hipLaunchKernelGGL(k_colsum, dim3(L), dim3(256), 0, stream, dz, B, L, db, accumulate);
   if (dslope && slope) hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, stream, dap, gx * S, dslope, accumulate);
   return check_launch("btlnk_bwd_reduce");
 }

@@ -102,40 +102,49 @@ __global__ __launch_bounds__(256) void k_bwd_fold(
     float* __restrict__ dgs, float* __restrict__ dbs, float* __restrict__ dWr, float* __restrict__ dbr,
     float* __restrict__ dgr, float* __restrict__ dbr2, float* __restrict__ coef, int Ci, int Co,
     int accumulate) {
-  extern __shared__ double shd[];  // k2s[Co], k2r[Co], g1s[Co], g1r[Co], sd[Co]
+  // LDS: doubles k2[2][Co], g1[2][Co], h[2][Co] (h = g1 sdU/n - k2 (W.mu)); floats W[2][Co*Ci], mu[2][Ci]
+  extern __shared__ double shd[];
   const bool ident = Wr == nullptr;
   const int CiP = round_up(Ci, 16);
   const double* P = red;
   const double* Q = red + Co * Ci;
   const double* sdU = red + 2 * Co * Ci;
-  const float* muX = stat;
-  const float* muZ = stat + Ci;
   const float* WCs = stat + 2 * Ci;
   const float* WCr = WCs + Co * Ci;
   const float* istd_s = WCr + Co * Ci + Co;
   const float* istd_r = istd_s + 2 * Co;
-  double* k2s = shd;
-  double* k2r = shd + Co;
-  double* g1s = shd + 2 * Co;
-  double* g1r = shd + 3 * Co;
+  double* k2 = shd;            // [2][Co]
+  double* g1 = shd + 2 * Co;   // [2][Co]
+  double* hh = shd + 4 * Co;   // [2][Co]
+  float* Wl = reinterpret_cast<float*>(shd + 6 * Co);  // [2][Co*Ci]
+  float* mul = Wl + 2 * Co * Ci;                       // [2][Ci]: muZ then muX
   float* wDZ = coef;
   float* kt = wDZ + (Co + Ci) * CiP;
   float* wDX = kt + CiP;
   float* kr = wDX + (Co + Ci) * CiP;
 
+  for (int i = threadIdx.x; i < Co * Ci; i += blockDim.x) {
+    Wl[i] = Wt[i];
+    Wl[Co * Ci + i] = ident ? 0.f : Wr[i];
+  }
+  for (int i = threadIdx.x; i < Ci; i += blockDim.x) {
+    mul[i] = stat[Ci + i];   // muZ (branch 0)
+    mul[Ci + i] = stat[i];   // muX (branch 1)
+  }
+  __syncthreads();
   // per-channel BN gradients
   for (int i = threadIdx.x; i < 2 * Co; i += blockDim.x) {
     const int b = i / Co, o = i - b * Co;
-    if (b == 1 && ident) { k2r[o] = 0.0; g1r[o] = 1.0; continue; }
-    const float* W = b ? Wr : Wt;
-    const double* M = b ? Q : P;
-    const float* mu = b ? muX : muZ;
+    if (b == 1 && ident) { k2[i] = 0.0; g1[i] = 1.0; hh[i] = 0.0; continue; }
+    const float* W = Wl + b * Co * Ci + o * Ci;
+    const double* M = (b ? Q : P) + o * Ci;
+    const float* mu = mul + b * Ci;
     const double istd = (double)(b ? istd_r : istd_s)[o];
     const double gamma = (double)(b ? gr : gs)[o];
     double wp = 0.0, wmu = 0.0;
     for (int c = 0; c < Ci; ++c) {
-      wp += (double)W[o * Ci + c] * M[o * Ci + c];
-      wmu += (double)W[o * Ci + c] * (double)mu[c];
+      wp += (double)W[c] * M[c];
+      wmu += (double)W[c] * (double)mu[c];
     }
     const double sdus = wp - wmu * sdU[o];       // sum dU * (conv_out - mean)
     const double dgamma = istd * sdus;
@@ -143,61 +152,52 @@ __global__ __launch_bounds__(256) void k_bwd_fold(
     put((b ? dbr2 : dbs) + o, (float)sdU[o], accumulate);
     float* dbias = b ? dbr : dbt;
     if (dbias) put(dbias + o, 0.f, accumulate);  // conv bias in front of a train-mode BN: exactly 0
-    (b ? g1r : g1s)[o] = gamma * istd;
-    (b ? k2r : k2s)[o] = gamma * istd * dgamma * istd / npos;
+    const double g = gamma * istd;
+    const double kk = g * dgamma * istd / npos;
+    g1[i] = g;
+    k2[i] = kk;
+    hh[i] = g * sdU[o] / npos - kk * wmu;
   }
   __syncthreads();
-  // conv weight gradients: dW[o,c] = g1 (M[o,c] - sdU[o] mu[c]) - g1 dgamma istd WC[o,c]
-  //                                = g1 (M[o,c] - sdU[o] mu[c]) - k2 * n * WC[o,c]
+  // conv weight gradients: dW[o,c] = g1 (M[o,c] - sdU[o] mu[c]) - k2 * n * WC[o,c]
   for (int i = threadIdx.x; i < 2 * Co * Ci; i += blockDim.x) {
     const int b = i / (Co * Ci);
     if (b == 1 && ident) break;
     const int j = i - b * Co * Ci, o = j / Ci, c = j - o * Ci;
     const double* M = b ? Q : P;
-    const float* mu = b ? muX : muZ;
     const float* WC = b ? WCr : WCs;
-    const double g1 = (b ? g1r : g1s)[o], k2 = (b ? k2r : k2s)[o];
-    const double v = g1 * (M[j] - sdU[o] * (double)mu[c]) - k2 * npos * (double)WC[j];
+    const double v = g1[b * Co + o] * (M[j] - sdU[o] * (double)mul[b * Ci + c]) - k2[b * Co + o] * npos * (double)WC[j];
     put((b ? dWr : dWt) + j, (float)v, accumulate);
   }
-  // data-path coefficients.  rows 0..Co-1: B[c][o] = g1[o] W[o,c];  rows Co..Co+Ci-1: K[c][c'] = -sum_o W[o,c] k2[o] W[o,c']
+  // data-path coefficients.  rows 0..Co-1: B[c][o] = g1[o] W[o,c];  rows Co..: K[c][c'] = -sum_o W[o,c] k2[o] W[o,c']
   for (int i = threadIdx.x; i < 2 * (Co + Ci) * CiP; i += blockDim.x) {
     const int b = i / ((Co + Ci) * CiP);
     const int j = i - b * (Co + Ci) * CiP;
     const int row = j / CiP, c = j - row * CiP;
-    const float* W = b ? Wr : Wt;
+    const float* W = Wl + b * Co * Ci;
     float v = 0.f;
     if (c < Ci) {
       if (b == 1 && ident) {
         v = (row < Co && row == c) ? 1.f : 0.f;
       } else if (row < Co) {
-        v = (float)((b ? g1r : g1s)[row] * (double)W[row * Ci + c]);
+        v = (float)(g1[b * Co + row] * (double)W[row * Ci + c]);
       } else {
         const int c2 = row - Co;
-        const double* k2 = b ? k2r : k2s;
         double acc = 0.0;
-        for (int o = 0; o < Co; ++o) acc += (double)W[o * Ci + c] * k2[o] * (double)W[o * Ci + c2];
+        for (int o = 0; o < Co; ++o) acc += (double)W[o * Ci + c] * k2[b * Co + o] * (double)W[o * Ci + c2];
         v = (float)(-acc);
       }
     }
     (b ? wDX : wDZ)[j] = v;
   }
-  // constants: k[c] = -sum_o W[o,c] g1[o] sdU[o]/n - sum_c' K[c][c'] mu[c']
-  //                 = -sum_o W[o,c] (g1[o] sdU[o]/n - k2[o] (W[o] . mu))
+  // constants: k[c] = -sum_o W[o,c] (g1[o] sdU[o]/n - k2[o] (W[o] . mu)) = -sum_o W[o,c] h[o]
   for (int i = threadIdx.x; i < 2 * CiP; i += blockDim.x) {
     const int b = i / CiP, c = i - b * CiP;
     float v = 0.f;
     if (c < Ci && !(b == 1 && ident)) {
-      const float* W = b ? Wr : Wt;
-      const float* mu = b ? muX : muZ;
-      const double* g1 = b ? g1r : g1s;
-      const double* k2 = b ? k2r : k2s;
+      const float* W = Wl + b * Co * Ci;
       double acc = 0.0;
-      for (int o = 0; o < Co; ++o) {
-        double wmu = 0.0;
-        for (int c2 = 0; c2 < Ci; ++c2) wmu += (double)W[o * Ci + c2] * (double)mu[c2];
-        acc += (double)W[o * Ci + c] * (g1[o] * sdU[o] / npos - k2[o] * wmu);
-      }
+      for (int o = 0; o < Co; ++o) acc += (double)W[o * Ci + c] * hh[b * Co + o];
       v = (float)(-acc);
     }
     (b ? kr : kt)[c] = v;
@@ -484,15 +484,30 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
   }
 }
 
-// out[e] (+)= sum_p partials[p*Erow + offset + e],  e < count
+// out[e] (+)= sum_p partials[p*Erow + offset + e],  e < count.  block = 64 elements x 4 partial-slices.
 __global__ __launch_bounds__(256) void k_reduce_to_f32(const float* __restrict__ partials, int P, int Erow,
                                                         int offset, int count, float* __restrict__ out,
                                                         int accumulate) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= count) return;
+  __shared__ double sh[256];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
   double s = 0.0;
-  for (int p = 0; p < P; ++p) s += (double)partials[(size_t)p * Erow + offset + e];
-  out[e] = accumulate ? out[e] + (float)s : (float)s;
+  if (e < count) {
+    double s0 = 0.0, s1 = 0.0;
+    int p = slice;
+    for (; p + 4 < P; p += 8) {
+      s0 += (double)partials[(size_t)p * Erow + offset + e];
+      s1 += (double)partials[(size_t)(p + 4) * Erow + offset + e];
+    }
+    for (; p < P; p += 4) s0 += (double)partials[(size_t)p * Erow + offset + e];
+    s = s0 + s1;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (slice == 0 && e < count) {
+    const double t = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+    out[e] = accumulate ? out[e] + (float)t : (float)t;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_sum_to(const float* __restrict__ v, int n, float* __restrict__ out,
@@ -601,7 +616,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if ((rc = check_launch("bwd_reduce_partials"))) return rc;
   }
   // 2. fold
-  hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(256), 4 * Co * sizeof(double), st, w.red, (double)B * TV, stat,
+  hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(256), 6 * Co * sizeof(double) + (2 * Co * Ci + 2 * Ci) * sizeof(float), st, w.red, (double)B * TV, stat,
                      Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate);
   if ((rc = check_launch("bwd_fold"))) return rc;
   // 3. data path
@@ -638,9 +653,9 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB);
     if ((rc = check_launch("bwd_gcn_params"))) return rc;
-    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 256)), dim3(256), 0, st, w.partials, grid, E, 0,
+    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(256), 0, st, w.partials, grid, E, 0,
                        T * V * V, dA, accumulate);
-    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 256)), dim3(256), 0, st, w.partials, grid, E,
+    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(256), 0, st, w.partials, grid, E,
                        T * V * V, V * T * T, dT, accumulate);
     if ((rc = check_launch("bwd_gcn_reduce"))) return rc;
   }
@@ -663,8 +678,8 @@ static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* A
   auto k = k_bwd_gcn_params<T, V>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB);
-  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 256)), dim3(256), 0, st, partials, grid, E, 0, T * V * V, dA, accumulate);
-  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 256)), dim3(256), 0, st, partials, grid, E, T * V * V, V * T * T, dT, accumulate);
+  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(256), 0, st, partials, grid, E, 0, T * V * V, dA, accumulate);
+  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(256), 0, st, partials, grid, E, T * V * V, V * T * T, dT, accumulate);
   return check_launch("gcn_bwd_params");
 }
 }  // namespace coskad

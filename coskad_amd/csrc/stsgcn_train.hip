@@ -90,7 +90,13 @@ __global__ __launch_bounds__(256) void k_train_fold(
     const float* __restrict__ brr, float* __restrict__ rm_r, float* __restrict__ rv_r,
     long long* __restrict__ nbt_r, float momentum, float* __restrict__ wfold,
     float* __restrict__ bias, float* __restrict__ stat, int Ci, int Co, int CoP) {
+  // LDS: doubles C[2][Ci*Ci] (centred covariances: Z then X), mu[2][Ci]; floats W[2][Co*Ci], WC[2][Co*Ci]
+  extern __shared__ double shd[];
   const bool ident = Wr == nullptr;
+  double* Cl = shd;                       // [2][Ci*Ci]
+  double* mul = shd + 2 * Ci * Ci;        // [2][Ci]
+  float* Wl = reinterpret_cast<float*>(mul + 2 * Ci);   // [2][Co*Ci]
+  float* WCl = Wl + 2 * Co * Ci;                        // [2][Co*Ci]
   const double* MX = red;
   const double* SX = red + Ci * Ci;
   const double* MZ = red + Ci * Ci + Ci;
@@ -106,42 +112,54 @@ __global__ __launch_bounds__(256) void k_train_fold(
   const double inv_n = 1.0 / npos;
 
   for (int c = threadIdx.x; c < Ci; c += blockDim.x) {
-    muX[c] = (float)(SX[c] * inv_n);
-    muZ[c] = (float)(SZ[c] * inv_n);
+    const double mz = SZ[c] * inv_n, mx = SX[c] * inv_n;
+    mul[c] = mz;
+    mul[Ci + c] = mx;
+    muZ[c] = (float)mz;
+    muX[c] = (float)mx;
   }
-  // WC[o][c] = sum_c' W[o][c'] * C[c'][c],  C = M/n - mu mu^T   (fp64)
+  for (int i = threadIdx.x; i < Co * Ci; i += blockDim.x) {
+    Wl[i] = Wt[i];
+    Wl[Co * Ci + i] = ident ? 0.f : Wr[i];
+  }
+  for (int i = threadIdx.x; i < Ci * Ci; i += blockDim.x) {
+    const int k = i / Ci, c = i - k * Ci;
+    Cl[i] = MZ[i] * inv_n - (SZ[k] * inv_n) * (SZ[c] * inv_n);
+    Cl[Ci * Ci + i] = ident ? 0.0 : MX[i] * inv_n - (SX[k] * inv_n) * (SX[c] * inv_n);
+  }
+  __syncthreads();
+  // WC[o][c] = sum_k W[o][k] C[k][c]   (fp64 accumulate)
   for (int i = threadIdx.x; i < 2 * Co * Ci; i += blockDim.x) {
-    const int br_ = i / (Co * Ci);
-    if (br_ == 1 && ident) { WCr[i - Co * Ci] = 0.f; continue; }
-    const int j = i - br_ * Co * Ci;
+    const int b = i / (Co * Ci);
+    const int j = i - b * Co * Ci;
     const int o = j / Ci, c = j - o * Ci;
-    const float* W = br_ ? Wr : Wt;
-    const double* M = br_ ? MX : MZ;
-    const double* S = br_ ? SX : SZ;
-    const double muc = S[c] * inv_n;
     double acc = 0.0;
-    for (int k = 0; k < Ci; ++k) acc += (double)W[o * Ci + k] * (M[k * Ci + c] * inv_n - (S[k] * inv_n) * muc);
-    (br_ ? WCr : WCs)[j] = (float)acc;
+    if (!(b == 1 && ident)) {
+      const float* W = Wl + b * Co * Ci + o * Ci;
+      const double* C = Cl + b * Ci * Ci + c;
+      for (int k = 0; k < Ci; ++k) acc += (double)W[k] * C[k * Ci];
+    }
+    WCl[i] = (float)acc;
+    (b ? WCr : WCs)[j] = (float)acc;
   }
   __syncthreads();
   const double unbias = npos > 1.0 ? npos / (npos - 1.0) : 1.0;
   for (int i = threadIdx.x; i < 2 * Co; i += blockDim.x) {
-    const int br_ = i / Co, o = i - br_ * Co;
-    if (br_ == 1 && ident) { mean_r[o] = 0.f; istd_r[o] = 1.f; continue; }
-    const float* W = br_ ? Wr : Wt;
-    const float* b = br_ ? br : bt;
-    const double* S = br_ ? SX : SZ;
-    const float* WC = br_ ? WCr : WCs;
-    double m = b ? (double)b[o] : 0.0, var = 0.0;
+    const int b = i / Co, o = i - b * Co;
+    if (b == 1 && ident) { mean_r[o] = 0.f; istd_r[o] = 1.f; continue; }
+    const float* W = Wl + b * Co * Ci + o * Ci;
+    const float* WC = WCl + b * Co * Ci + o * Ci;
+    const float* bb = b ? br : bt;
+    double m = bb ? (double)bb[o] : 0.0, var = 0.0;
     for (int k = 0; k < Ci; ++k) {
-      m += (double)W[o * Ci + k] * (S[k] * inv_n);
-      var += (double)W[o * Ci + k] * (double)WC[o * Ci + k];
+      m += (double)W[k] * mul[b * Ci + k];
+      var += (double)W[k] * (double)WC[k];
     }
     var = var > 0.0 ? var : 0.0;
-    (br_ ? mean_r : mean_s)[o] = (float)m;
-    (br_ ? istd_r : istd_s)[o] = (float)(1.0 / sqrt(var + (double)kBnEps));
-    float* rm = br_ ? rm_r : rm_s;
-    float* rv = br_ ? rv_r : rv_s;
+    (b ? mean_r : mean_s)[o] = (float)m;
+    (b ? istd_r : istd_s)[o] = (float)(1.0 / sqrt(var + (double)kBnEps));
+    float* rm = b ? rm_r : rm_s;
+    float* rv = b ? rv_r : rv_s;
     if (rm) {  // nn.BatchNorm2d: running = (1-m) running + m batch ; unbiased variance
       rm[o] = (1.f - momentum) * rm[o] + momentum * (float)m;
       rv[o] = (1.f - momentum) * rv[o] + momentum * (float)(var * unbias);
@@ -157,10 +175,10 @@ __global__ __launch_bounds__(256) void k_train_fold(
     const int row = i / CoP, o = i - row * CoP;
     float w = 0.f;
     if (o < Co) {
-      if (row < Ci) w = gs[o] * istd_s[o] * Wt[o * Ci + row];
+      if (row < Ci) w = gs[o] * istd_s[o] * Wl[o * Ci + row];
       else {
         const int c = row - Ci;
-        w = ident ? (c == o ? 1.f : 0.f) : gr[o] * istd_r[o] * Wr[o * Ci + c];
+        w = ident ? (c == o ? 1.f : 0.f) : gr[o] * istd_r[o] * Wl[Co * Ci + o * Ci + c];
       }
     }
     wfold[i] = w;
@@ -223,7 +241,9 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(256), 0, st, partials, grid, E, red);
   rc = check_launch("reduce_partials");
   if (rc) return rc;
-  hipLaunchKernelGGL(k_train_fold, dim3(1), dim3(256), 0, st, red, (double)B * TV, Wt, bt, gs, bs, rm_s,
+  const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + 4 * (size_t)Co * Ci * sizeof(float);
+  if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_train_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
+  hipLaunchKernelGGL(k_train_fold, dim3(1), dim3(256), fold_lds, st, red, (double)B * TV, Wt, bt, gs, bs, rm_s,
                      rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r, nbt_r, momentum, wfold, bias, stat, Ci,
                      Co, round_up(Co, 16));
   return check_launch("train_fold");
