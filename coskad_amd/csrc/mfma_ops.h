@@ -34,34 +34,46 @@ template <int T, int V, bool ADJ>
 __device__ __forceinline__ void temporal_mfma(float* img, int rows, const float* TwL) {
   constexpr int LD = Geo<T, V>::LD;
   constexpr int KS = (T + 3) / 4;
+  constexpr int RP = 2;   // row tiles per item: they share the B operand and give independent MFMA chains
   static_assert(T <= 16, "temporal_mfma: one 16-wide column tile");
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int i = lane & 15, k = lane >> 4;
   const int RT = (rows + 15) >> 4;
+  const int RG = (RT + RP - 1) / RP;
   const int jc = i < T ? i : T - 1;  // column clamp (columns >= T are never stored)
-  for (int it = wave; it < RT * V; it += kBlock / 64) {
-    const int rt = it / V, v = it - rt * V;
-    const int rowA = 16 * rt + i;
-    const bool rokA = rowA < rows;
-    const float* ra = img + (rokA ? rowA : 0) * LD + v;
+  for (int it = wave; it < RG * V; it += kBlock / 64) {
+    const int rg = it / V, v = it - rg * V;
     const float* tb = TwL + v * T * T;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float b[KS], a[RP][KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int kk = 4 * s + k;
       const bool kok = kk < T;
       const int kc = kok ? kk : T - 1;
-      const float a = (rokA && kok) ? ra[kc * V] : 0.f;
       // forward: B[k = t][j = q] = T[v][t][q];  adjoint: B[k = q][j = t] = T[v][t][q]
-      const float b = ADJ ? tb[jc * T + kc] : tb[kc * T + jc];
-      acc = mfma4(a, b, acc);
+      b[s] = ADJ ? tb[jc * T + kc] : tb[kc * T + jc];
+#pragma unroll
+      for (int q = 0; q < RP; ++q) {
+        const int rowA = 16 * (rg * RP + q) + i;
+        const bool ok = rowA < rows && kok;
+        a[q][s] = ok ? img[rowA * LD + kc * V + v] : 0.f;
+      }
     }
+    f32x4 acc[RP];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int q = 0; q < RP; ++q) acc[q] = mfma4(a[q][s], b[s], acc[q]);
     if (i < T) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * rt + 4 * k + r;
-        if (row < rows) img[row * LD + i * V + v] = acc[r];
-      }
+      for (int q = 0; q < RP; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * (rg * RP + q) + 4 * k + r;
+          if (row < rows) img[row * LD + i * V + v] = acc[q][r];
+        }
     }
   }
 }
@@ -70,72 +82,89 @@ template <int T, int V, bool ADJ>
 __device__ __forceinline__ void spatial_mfma(float* img, int rows, const float* AwL) {
   constexpr int LD = Geo<T, V>::LD;
   constexpr int KS = (V + 3) / 4;
+  constexpr int RP = 2;   // row tiles per item (share B, independent chains)
   // column tiles on MFMA; up to 2 leftover columns (V = 17, 18) are cheaper on the VALU
   constexpr int VX = (V > 16 && V - 16 <= 2) ? V - 16 : ((V > 32 && V - 32 <= 2) ? V - 32 : 0);
   constexpr int NT = (V - VX + 15) / 16;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int i = lane & 15, k = lane >> 4;
   const int RT = (rows + 15) >> 4;
-  for (int it = wave; it < RT * T; it += kBlock / 64) {
-    const int rt = it / T, t = it - rt * T;
-    const int rowA = 16 * rt + i;
-    const bool rokA = rowA < rows;
-    float* ra = img + (rokA ? rowA : 0) * LD + t * V;
+  const int RG = (RT + RP - 1) / RP;
+  for (int it = wave; it < RG * T; it += kBlock / 64) {
+    const int rg = it / T, t = it - rg * T;
     const float* ab = AwL + t * V * V;
-    float a[KS];
+    float a[RP][KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int kk = 4 * s + k;
-      a[s] = (rokA && kk < V) ? ra[kk] : 0.f;
+    for (int q = 0; q < RP; ++q) {
+      const int rowA = 16 * (rg * RP + q) + i;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int kk = 4 * s + k;
+        a[q][s] = (rowA < rows && kk < V) ? img[rowA * LD + t * V + kk] : 0.f;
+      }
     }
-    f32x4 acc[NT];
+    f32x4 acc[RP][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int col = 16 * nt + i;
       const int jc = col < V ? col : V - 1;
+      float b[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int kk = 4 * s + k;
         const int kc = kk < V ? kk : V - 1;
         // forward: B[k = v][j = w] = A[t][v][w];  adjoint: B[k = w][j = v] = A[t][v][w]
-        const float b = ADJ ? ab[jc * V + kc] : ab[kc * V + jc];
-        acc[nt] = mfma4(a[s], b, acc[nt]);
+        b[s] = ADJ ? ab[jc * V + kc] : ab[kc * V + jc];
       }
+#pragma unroll
+      for (int q = 0; q < RP; ++q) acc[q][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int q = 0; q < RP; ++q) acc[q][nt] = mfma4(a[q][s], b[s], acc[q][nt]);
     }
-    float ex[VX > 0 ? VX : 1];
+    float ex[RP][VX > 0 ? VX : 1];
     if constexpr (VX > 0) {
 #pragma unroll
       for (int x = 0; x < VX; ++x) {
         const int col = V - VX + x;
-        float p = 0.f;
+        float bw[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const int kk = 4 * s + k;
           const int kc = kk < V ? kk : V - 1;
-          const float b = ADJ ? ab[col * V + kc] : ab[kc * V + col];
-          p = fmaf(a[s], b, p);   // a[s] is 0 for kk >= V
+          bw[s] = ADJ ? ab[col * V + kc] : ab[kc * V + col];
         }
-        p += __shfl_xor(p, 16, 64);
-        p += __shfl_xor(p, 32, 64);
-        ex[x] = p;                // every lane: value for row 16*rt + i
-      }
-    }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = 16 * nt + i;
-      if (col < V - VX) {
+        for (int q = 0; q < RP; ++q) {
+          float p = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * rt + 4 * k + r;
-          if (row < rows) img[row * LD + t * V + col] = acc[nt][r];
+          for (int s = 0; s < KS; ++s) p = fmaf(a[q][s], bw[s], p);   // a is 0 for kk >= V
+          p += __shfl_xor(p, 16, 64);
+          p += __shfl_xor(p, 32, 64);
+          ex[q][x] = p;             // every lane: value for row 16*tile + i
         }
       }
     }
-    if constexpr (VX > 0) {
-      if (k == 0 && rokA) {
 #pragma unroll
-        for (int x = 0; x < VX; ++x) ra[V - VX + x] = ex[x];
+    for (int q = 0; q < RP; ++q) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = 16 * nt + i;
+        if (col < V - VX) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * (rg * RP + q) + 4 * k + r;
+            if (row < rows) img[row * LD + t * V + col] = acc[q][nt][r];
+          }
+        }
+      }
+      if constexpr (VX > 0) {
+        const int rowA = 16 * (rg * RP + q) + i;
+        if (k == 0 && rowA < rows) {
+#pragma unroll
+          for (int x = 0; x < VX; ++x) img[rowA * LD + t * V + V - VX + x] = ex[q][x];
+        }
       }
     }
   }
@@ -151,6 +180,196 @@ __device__ __forceinline__ void gcn_mfma(float* img, int rows, const float* AwL,
     spatial_mfma<T, V, true>(img, rows, AwL);
     __syncthreads();
     temporal_mfma<T, V, true>(img, rows, TwL);
+  }
+}
+
+}  // namespace coskad
+
+// ---- 1x1 convolutions of one clip as an MFMA GEMM ---------------------------------------
+//   Out[o][p] = bias[o] + sum_k Wl[k][o] * In_k[p]
+// K-image of the clip: k in [0, KZ) = rows of the LDS image `zimg` (KZ = Ci rounded up to 4,
+// rows >= Ci have zero weights), k in [KZ, KZ+KX) = rows of the global tensor `xg`
+// (stride TV, optional PReLU on load; KX = 0: no second source).
+// Work items = (position tile of 16, group of OTI output tiles); the 4 waves take items
+// round-robin.  Store: out[o*TV + p] (+ optional PReLU), o < Co, p < TV.
+namespace coskad {
+
+template <int T, int V, int OTI, class Epilogue>
+__device__ __forceinline__ void conv_mfma(const float* zimg, int KZ, int nz, const float* __restrict__ xg,
+                                          int KX, int nx, bool pre, float a_in, const float* Wl, int CoP,
+                                          int item0, int item_step, Epilogue&& epi) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int PT = (TV + 15) / 16;
+  constexpr int XB = 8;   // global k-steps prefetched per item (covers C_in <= 32; more: second batch)
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kk = lane >> 4;
+  const int OG = (CoP / 16 + OTI - 1) / OTI;
+  const int nitems = PT * OG;
+  const int KXS = KX / 4, KZS = KZ / 4;
+
+  auto load_x = [&](int it, int s0, float (&xb)[XB]) {
+    const int pt = it / OG;
+    const int p = 16 * pt + j;
+    const int pc = p < TV ? p : TV - 1;
+#pragma unroll
+    for (int u = 0; u < XB; ++u) {
+      const int c = 4 * (s0 + u) + kk;
+      const int cc = c < nx ? c : nx - 1;
+      xb[u] = (s0 + u < KXS && it < nitems) ? xg[(size_t)cc * TV + pc] : 0.f;
+    }
+  };
+
+  float xcur[XB], xnext[XB];
+  if (KXS > 0) load_x(item0, 0, xcur);
+  for (int it = item0; it < nitems; it += item_step) {
+    const int pt = it / OG, og = it - pt * OG;
+    const int p = 16 * pt + j;
+    const int pc = p < TV ? p : TV - 1;
+    f32x4 acc[OTI];
+#pragma unroll
+    for (int t = 0; t < OTI; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wcol = Wl + 16 * og * OTI + j;
+    if (KXS > 0) load_x(it + item_step, 0, xnext);   // next item's X operands fly during this item
+    // LDS source: batches of 4 k-steps (12+ LDS reads in flight, then 4*OTI MFMAs)
+    for (int s0 = 0; s0 < KZS; s0 += 4) {
+      float b[4], a[4][OTI];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = 4 * (s0 + u) + kk;
+        const int cc = c < nz ? c : nz - 1;
+        const bool ok = s0 + u < KZS;
+        b[u] = ok ? zimg[cc * LD + pc] : 0.f;
+        const float* w = wcol + (ok ? c : 0) * CoP;
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) a[u][t] = w[16 * t];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) acc[t] = mfma4(a[u][t], b[u], acc[t]);
+    }
+    // global source (prefetched)
+    for (int s0 = 0; s0 < KXS; s0 += XB) {
+      if (s0 > 0) load_x(it, s0, xcur);
+#pragma unroll
+      for (int u0 = 0; u0 < XB; u0 += 4) {
+        float a[4][OTI];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int st = s0 + u0 + u;
+          const float* w = wcol + (KZ + 4 * (st < KXS ? st : 0) + kk) * CoP;
+#pragma unroll
+          for (int t = 0; t < OTI; ++t) a[u][t] = w[16 * t];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float x = pre ? prelu_f(xcur[u0 + u], a_in) : xcur[u0 + u];   // 0 stays 0 beyond KXS
+#pragma unroll
+          for (int t = 0; t < OTI; ++t) acc[t] = mfma4(a[u][t], x, acc[t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < XB; ++u) xcur[u] = xnext[u];
+    // D[row = 4*kk + r][col = j]
+#pragma unroll
+    for (int t = 0; t < OTI; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epi(16 * (og * OTI + t) + 4 * kk + r, p, acc[t][r]);
+  }
+}
+
+// Same GEMM with the weight (A) fragments held in registers: a wave works on ONE fixed output group
+// `og` for the whole kernel, so its fragments are loaded once per block.  KH = max k-steps per source
+// (8 covers C_in <= 32); callers fall back to conv_mfma for larger K.
+template <int OTI, int KH>
+struct ConvFrags {
+  float z[KH][OTI];   // weights of the LDS (Z) source, k-step s
+  float x[KH][OTI];   // weights of the global (X) source
+};
+
+template <int OTI, int KH>
+__device__ __forceinline__ void load_conv_frags(ConvFrags<OTI, KH>& f, const float* Wl, int CoP, int og, int KZ,
+                                                int KX) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < KH; ++s)
+#pragma unroll
+    for (int t = 0; t < OTI; ++t) {
+      const int o = 16 * (og * OTI + t) + i;
+      f.z[s][t] = (4 * s < KZ && o < CoP) ? Wl[(4 * s + kk) * CoP + o] : 0.f;
+      f.x[s][t] = (4 * s < KX && o < CoP) ? Wl[(KZ + 4 * s + kk) * CoP + o] : 0.f;
+    }
+}
+
+template <int T, int V, int OTI, int KH, class Epilogue>
+__device__ __forceinline__ void conv_mfma_r(const float* zimg, int KZ, int nz, const float* __restrict__ xg,
+                                            int KX, int nx, bool pre, float a_in, const ConvFrags<OTI, KH>& f,
+                                            int og, int pt0, int pt_step, Epilogue&& epi) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int PT = (TV + 15) / 16;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kk = lane >> 4;
+  const int KZS = KZ / 4, KXS = KX / 4;
+  float xcur[KH], xnext[KH];
+  auto load_x = [&](int pt, float (&xb)[KH]) {
+    const int p = 16 * pt + j;
+    const int pc = p < TV ? p : TV - 1;
+#pragma unroll
+    for (int u = 0; u < KH; ++u) {
+      const int c = 4 * u + kk;
+      const int cc = c < nx ? c : nx - 1;
+      xb[u] = (u < KXS && pt < PT) ? xg[(size_t)cc * TV + pc] : 0.f;
+    }
+  };
+  if (KXS > 0) load_x(pt0, xcur);
+  for (int pt = pt0; pt < PT; pt += pt_step) {
+    const int p = 16 * pt + j;
+    const int pc = p < TV ? p : TV - 1;
+    if (KXS > 0) load_x(pt + pt_step, xnext);
+    float b[KH];
+#pragma unroll
+    for (int u = 0; u < KH; ++u) {
+      const int c = 4 * u + kk;
+      const int cc = c < nz ? c : nz - 1;
+      b[u] = u < KZS ? zimg[cc * LD + pc] : 0.f;
+    }
+    f32x4 acc[OTI];
+#pragma unroll
+    for (int t = 0; t < OTI; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KH; ++u) {
+      if (u < KZS) {
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) acc[t] = mfma4(f.z[u][t], b[u], acc[t]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KH; ++u) {
+      if (u < KXS) {
+        const float x = pre ? prelu_f(xcur[u], a_in) : xcur[u];
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) acc[t] = mfma4(f.x[u][t], x, acc[t]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KH; ++u) xcur[u] = xnext[u];
+#pragma unroll
+    for (int t = 0; t < OTI; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epi(16 * (og * OTI + t) + 4 * kk + r, p, acc[t][r]);
+  }
+}
+
+// LDS weight table of the folded layer: Wl[k][o], k over the padded K-image (see conv_mfma).
+// src: [(2*Ci)][CoP] (rows 0..Ci-1: Z part, Ci..2Ci-1: X part)
+__device__ __forceinline__ void load_wfold_padded(float* Wl, const float* __restrict__ src, int Ci, int KZ,
+                                                  int CoP, int nsrc) {
+  for (int e = threadIdx.x; e < nsrc * KZ * CoP; e += kBlock) {
+    const int k = e / CoP, o = e - k * CoP;
+    const int part = k / KZ, c = k - part * KZ;
+    Wl[e] = c < Ci ? src[(part * Ci + c) * CoP + o] : 0.f;
   }
 }
 

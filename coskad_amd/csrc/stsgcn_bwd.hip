@@ -238,7 +238,9 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
 
   const int P = nb * TV;
   const int rounds = ceil_div(P, kBlock);
-  // position phase A: dZ[:,p] = kt + Bt dU[:,p] + Kt Z[:,p], in place over Z
+  // position phase A: dZ[:,p] = kt + Bt dU[:,p] + Kt Z[:,p], in place over Z.
+  // All CIP outputs of a position accumulate in registers; the input loops are ROLLED (wave-uniform
+  // weights stream through SGPRs, CIP per iteration) and Z[:,p] is fully read before it is overwritten.
   for (int r = 0; r < rounds; ++r) {
     const int pos = r * kBlock + threadIdx.x;
     const bool act = pos < P;
@@ -246,28 +248,25 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
     const int n = pc / TV, p = pc - n * TV;
     float* zcol = lds + (n * Ci) * LD + p;
     const float* ducol = gdu + (size_t)n * Co * TV + p;
-    float zr[CIP], out[CIP];
+    float out[CIP];
 #pragma unroll
-    for (int c = 0; c < CIP; ++c) {
-      zr[c] = c < Ci ? zcol[c * LD] : 0.f;
-      out[c] = kt[c < CiP ? c : 0];
-    }
-    for (int o0 = 0; o0 < Co; o0 += 8) {
-      float dr[8];
+    for (int c = 0; c < CIP; ++c) out[c] = kt[c < CiP ? c : 0];
+    for (int o0 = 0; o0 < Co; o0 += 4) {
+      float dr[4];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) dr[k] = (o0 + k < Co) ? ducol[(size_t)(o0 + k) * TV] : 0.f;
+      for (int k = 0; k < 4; ++k) dr[k] = (o0 + k < Co) ? ducol[(size_t)(o0 + k) * TV] : 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 4; ++k) {
         const float* w = wDZ + (o0 + k < Co ? o0 + k : 0) * CiP;
 #pragma unroll
         for (int c = 0; c < CIP; ++c) out[c] = fmaf(w[c < CiP ? c : 0], dr[k], out[c]);
       }
     }
+    for (int c2 = 0; c2 < Ci; ++c2) {
+      const float z = zcol[c2 * LD];
+      const float* w = wDZ + (Co + c2) * CiP;
 #pragma unroll
-    for (int c2 = 0; c2 < CIP; ++c2) {
-      const float* w = wDZ + (Co + (c2 < Ci ? c2 : 0)) * CiP;
-#pragma unroll
-      for (int c = 0; c < CIP; ++c) out[c] = fmaf(w[c < CiP ? c : 0], zr[c2], out[c]);
+      for (int c = 0; c < CIP; ++c) out[c] = fmaf(w[c < CiP ? c : 0], z, out[c]);
     }
     if (act) {
 #pragma unroll
@@ -291,9 +290,6 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
       const float* ducol = gdu + (size_t)n * Co * TV + p;
       const float* ucol = gin + (size_t)n * Ci * TV + p;
       float* dcol = dIn + ((size_t)(clip0 + n) * Ci) * TV + p;
-      float ur[CIP];
-#pragma unroll
-      for (int c = 0; c < CIP; ++c) ur[c] = c < Ci ? ucol[(size_t)c * TV] : 0.f;
       for (int c0 = 0; c0 < Ci; c0 += CH) {
         float acc[CH];
 #pragma unroll
@@ -309,25 +305,31 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
             for (int j = 0; j < CH; ++j) acc[j] = fmaf(w[j], dr[k], acc[j]);
           }
         }
+        for (int c2 = 0; c2 < Ci; c2 += 4) {
+          float xr[4];
 #pragma unroll
-        for (int c2 = 0; c2 < CIP; ++c2) {
-          const float x = pre ? prelu_f(ur[c2], a_in) : ur[c2];
-          const float* w = wDX + (Co + (c2 < Ci ? c2 : 0)) * CiP + c0;
+          for (int k = 0; k < 4; ++k) {
+            const float u = (c2 + k < Ci) ? ucol[(size_t)(c2 + k) * TV] : 0.f;
+            xr[k] = pre ? prelu_f(u, a_in) : u;
+          }
 #pragma unroll
-          for (int j = 0; j < CH; ++j) acc[j] = fmaf(w[j], c2 < Ci ? x : 0.f, acc[j]);
+          for (int k = 0; k < 4; ++k) {
+            const float* w = wDX + (Co + (c2 + k < Ci ? c2 + k : 0)) * CiP + c0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[j] = fmaf(w[j], (c2 + k < Ci) ? xr[k] : 0.f, acc[j]);
+          }
         }
-        // select ur[c0 + j] with static indices
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-          float u = 0.f;
-#pragma unroll
-          for (int c = 0; c < CIP; ++c) u = (c == c0 + j) ? ur[c] : u;
-          float g = acc[j];
-          if (pre) {
-            if (act && c0 + j < Ci && u < 0.f) da = fmaf(g, u, da);
-            g = u > 0.f ? g : a_in * g;
+          if (c0 + j < Ci) {
+            const float u = ucol[(size_t)(c0 + j) * TV];
+            float g = acc[j];
+            if (pre) {
+              if (act && u < 0.f) da = fmaf(g, u, da);
+              g = u > 0.f ? g : a_in * g;
+            }
+            if (act) dcol[(size_t)(c0 + j) * TV] = g;
           }
-          if (act && c0 + j < Ci) dcol[(size_t)(c0 + j) * TV] = g;
         }
       }
     }

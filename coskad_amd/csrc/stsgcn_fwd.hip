@@ -11,6 +11,7 @@
 // PRE-activation U; the consumer applies PReLU while staging (1 VALU op / element), which
 // hands the backward pass the PReLU mask and argument without storing anything extra.
 #include "tile_ops.h"
+#include <cstdlib>
 
 namespace coskad {
 
@@ -205,10 +206,28 @@ static int pick_nb(int Ci, int B, int LD) {
 }
 
 template <int T, int V>
+int launch_layer_apply_m(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold,
+                         const float* bias, const float* in_slope, const float* out_slope, int B, int Ci,
+                         int Co, hipStream_t st);  // stsgcn_fwd_mfma.hip
+
+static int use_mfma() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("COSKAD_VALU_FWD");
+    v = (e && e[0] == '1') ? 0 : 1;
+  }
+  return v;
+}
+
+template <int T, int V>
 static int launch_layer_apply(const float* in, float* out, const float* Aw, const float* Tw,
                               const float* wfold, const float* bias, const float* in_slope,
                               const float* out_slope, int B, int Ci, int Co, hipStream_t st) {
   constexpr int LD = Geo<T, V>::LD;
+  if (use_mfma()) {
+    const int rc = launch_layer_apply_m<T, V>(in, out, Aw, Tw, wfold, bias, in_slope, out_slope, B, Ci, Co, st);
+    if (rc <= 0) return rc;   // 1 = does not fit in LDS: VALU kernel below
+  }
   const int CoP = round_up(Co, 16);
   const int NB = pick_nb(Ci, B, LD);
   const size_t lds = (size_t)NB * Ci * LD * sizeof(float);

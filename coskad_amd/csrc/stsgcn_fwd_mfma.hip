@@ -1,0 +1,155 @@
+// MFMA version of the fused ST_GCNN layer forward (same contract as k_layer_apply in stsgcn_fwd.hip):
+//   U = Wz . gcn(PReLU_in(in)) + Wx . PReLU_in(in) + b
+// Persistent blocks; the mixing matrices and the folded conv weights are loaded into LDS once
+// per block; gcn and both 1x1 convs run on v_mfma_f32_16x16x4_f32.
+#include "mfma_ops.h"
+#include <cstdlib>
+
+namespace coskad {
+
+template <int T, int V, int OTI>
+__global__ __launch_bounds__(kBlock) void k_layer_apply_m(
+    const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Aw,
+    const float* __restrict__ Tw, const float* __restrict__ wfold, const float* __restrict__ bias,
+    const float* __restrict__ in_slope, const float* __restrict__ out_slope, int B, int Ci, int Co,
+    int CoP, int NB, int dbg) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int KZ = round_up(Ci, 4);
+  float* img = lds;
+  float* AwL = img + NB * Ci * LD;
+  float* TwL = AwL + T * V * V;
+  float* Wl = TwL + V * T * T;
+  float* bl = Wl + 2 * KZ * CoP;
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const bool post = out_slope != nullptr;
+  const float a_out = post ? out_slope[0] : 0.f;
+  copy_to_lds(AwL, Aw, T * V * V);
+  copy_to_lds(TwL, Tw, V * T * T);
+  load_wfold_padded(Wl, wfold, Ci, KZ, CoP, 2);
+  copy_to_lds(bl, bias, CoP);
+  const int wave = uniform(threadIdx.x >> 6);
+  // register-resident conv weights: wave -> fixed output group, position tiles strided over the
+  // waves that share the group (possible when both sources need <= KH k-steps and OG divides 4)
+  constexpr int KH = 8;
+  const int OG = (CoP / 16 + OTI - 1) / OTI;
+  const bool regw = KZ <= 4 * KH && (OG == 1 || OG == 2 || OG == 4);
+  ConvFrags<OTI, KH> frags;
+  const int my_og = wave % OG, pt_first = wave / OG, pt_stride = (kBlock / 64) / OG;
+
+  // Tile pipeline: the NEXT tile is fetched HBM -> registers while the current one is computed,
+  // and written to LDS after the conv phase has finished reading the image.
+  constexpr int PF = 8;  // float4 per thread in flight: covers tiles up to 8*256*4 floats = 32 KB
+  const int ntiles = ceil_div(B, NB);
+  float4 pf[PF];
+  auto fetch = [&](int tile) {
+    const int clip0 = tile * NB;
+    const int n4 = (min(NB, B - clip0) * Ci * TV) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(in + (size_t)clip0 * Ci * TV);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = threadIdx.x + u * kBlock;
+      pf[u] = (tile < ntiles && i < n4) ? g4[i] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto commit = [&](int tile) {
+    const int clip0 = tile * NB;
+    const int n4 = (min(NB, B - clip0) * Ci * TV) >> 2;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = threadIdx.x + u * kBlock;
+      if (i < n4) {
+        float4 v = pf[u];
+        const int e = i << 2, row = e / TV, col = e - row * TV;
+        if (pre) { v.x = prelu_f(v.x, a_in); v.y = prelu_f(v.y, a_in); v.z = prelu_f(v.z, a_in); v.w = prelu_f(v.w, a_in); }
+        float* d = img + row * LD + col;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+    // tiles larger than the register window: the rest goes the direct way
+    const int done = PF * kBlock * 4;
+    const int total = min(NB, B - clip0) * Ci * TV;
+    if (total > done) {
+      const float* g = in + (size_t)clip0 * Ci * TV;
+      for (int e = done + threadIdx.x; e < total; e += kBlock) {
+        const int row = e / TV, col = e - row * TV;
+        const float v = g[e];
+        img[row * LD + col] = pre ? prelu_f(v, a_in) : v;
+      }
+    }
+  };
+  static_assert(TV % 4 == 0, "tile prefetch uses float4");
+  if (!(dbg & 4)) fetch(blockIdx.x);
+  __syncthreads();
+  if (regw) load_conv_frags<OTI, KH>(frags, Wl, CoP, my_og, KZ, KZ);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int clip0 = tile * NB;
+    const int nb = min(NB, B - clip0);
+    const int rows = nb * Ci;
+    const float* gin = in + (size_t)clip0 * Ci * TV;
+    __syncthreads();  // tables ready / previous tile's conv reads done
+    if (!(dbg & 4)) commit(tile);
+    if (!(dbg & 4)) fetch(tile + gridDim.x);
+    __syncthreads();
+    if (!(dbg & 1)) gcn_mfma<T, V, false>(img, rows, AwL, TwL);
+    __syncthreads();
+    for (int n = 0; n < nb && !(dbg & 2); ++n) {
+      float* og = out + (size_t)(clip0 + n) * Co * TV;
+      auto epi = [&](int o, int p, float v) {
+        if (o < Co && p < TV && !(dbg & 8)) {
+          v += bl[o];
+          og[(size_t)o * TV + p] = post ? prelu_f(v, a_out) : v;
+        }
+      };
+      // rotate the starting wave per clip so the ragged tail spreads over the waves
+      if (regw)
+        conv_mfma_r<T, V, OTI, KH>(img + n * Ci * LD, (dbg & 32) ? 0 : KZ, Ci, gin + (size_t)n * Ci * TV, (dbg & 16) ? 0 : KZ, Ci, pre, a_in, frags,
+                                   my_og, (pt_first + n) % pt_stride, pt_stride, epi);
+      else
+        conv_mfma<T, V, OTI>(img + n * Ci * LD, KZ, Ci, gin + (size_t)n * Ci * TV, KZ, Ci, pre, a_in, Wl, CoP,
+                             (wave + n) & 3, kBlock / 64, epi);
+    }
+  }
+}
+
+size_t layer_apply_m_lds(int T, int V, int Ci, int CoP, int NB) {
+  const int TV = T * V, LD = TV % 2 == 0 ? TV + 1 : TV;
+  return ((size_t)NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T + 2 * (size_t)round_up(Ci, 4) * CoP + CoP) * sizeof(float);
+}
+
+template <int T, int V>
+int launch_layer_apply_m(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold,
+                         const float* bias, const float* in_slope, const float* out_slope, int B, int Ci,
+                         int Co, hipStream_t st) {
+  const int CoP = round_up(Co, 16);
+  int NB = Ci >= 32 ? 1 : 32 / Ci;   // 32 rows per tile: 2 row tiles of 16
+  if (NB > B) NB = B;
+  const size_t lds = layer_apply_m_lds(T, V, Ci, CoP, NB);
+  if (lds > (size_t)kMaxLdsBytes) return 1;  // caller falls back to the VALU kernel
+  const int ntiles = ceil_div(B, NB);
+  const int per_cu = (int)((size_t)kMaxLdsBytes / lds);
+  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+  if (grid > ntiles) grid = ntiles;
+#define LAUNCH_OTI(OTI)                                                                             \
+  do {                                                                                              \
+    auto k = k_layer_apply_m<T, V, OTI>;                                                            \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, out, Aw, Tw, wfold, bias, in_slope,   \
+                       out_slope, B, Ci, Co, CoP, NB, dbg);                                         \
+  } while (0)
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("COSKAD_DBG"); dbg = e ? atoi(e) : 0; }
+  if (CoP >= 32) LAUNCH_OTI(2);
+  else LAUNCH_OTI(1);
+#undef LAUNCH_OTI
+  return check_launch("layer_apply_m");
+}
+
+// explicit instantiations used by stsgcn_fwd.hip's dispatcher
+template int launch_layer_apply_m<12, 17>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
+template int launch_layer_apply_m<12, 25>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
+template int launch_layer_apply_m<12, 14>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
+template int launch_layer_apply_m<12, 18>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
+
+}  // namespace coskad
