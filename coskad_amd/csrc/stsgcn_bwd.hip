@@ -386,8 +386,12 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
                                                           int NB) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   constexpr int NW = kBlock / 64;
-  constexpr int NTV = (V + 15) / 16, NTT = (T + 15) / 16;
+  // dA is V x V per frame: MFMA tiles of 16 for the bulk; up to 2 leftover joints (V = 17, 18) on the VALU
+  constexpr int VX = (V > 16 && V - 16 <= 2) ? V - 16 : 0;
+  constexpr int VM = V - VX;                 // joints covered by MFMA tiles
+  constexpr int NTV = (VM + 15) / 16, NTT = (T + 15) / 16;
   constexpr int TPW = (T + NW - 1) / NW, VPW = (V + NW - 1) / NW;
+  constexpr int VXA = VX > 0 ? VX : 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img1 = lds;
   float* img2 = lds + NB * Ci * LD;
@@ -395,11 +399,22 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
   const float a_in = pre ? in_slope[0] : 0.f;
   const int wave = uniform(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  const int i = lane & 15, k = lane >> 4;
   const int tbeg = (T * wave) / NW, tend = (T * (wave + 1)) / NW;
   const int vbeg = (V * wave) / NW, vend = (V * (wave + 1)) / NW;
   f32x4 accA[TPW][NTV][NTV], accT[VPW][NTT][NTT];
+  float pcol[TPW][VXA][NTV], prow[TPW][VXA][NTV], pcor[TPW][VXA][VXA];
 #pragma unroll
-  for (int a = 0; a < TPW; ++a) zero_acc(accA[a]);
+  for (int a = 0; a < TPW; ++a) {
+    zero_acc(accA[a]);
+#pragma unroll
+    for (int x = 0; x < VXA; ++x) {
+#pragma unroll
+      for (int t2 = 0; t2 < NTV; ++t2) { pcol[a][x][t2] = 0.f; prow[a][x][t2] = 0.f; }
+#pragma unroll
+      for (int y = 0; y < VXA; ++y) pcor[a][x][y] = 0.f;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < VPW; ++a) zero_acc(accT[a]);
 
@@ -415,22 +430,58 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
     __syncthreads();
     mix_rows<T, V, true, false>(img1, rows, Tw);  // Y = temporal(X)
     __syncthreads();
-    // dA[t] += Y[:, t, :]^T dZ[:, t, :]
+    // dA[t] += Y[:, t, :]^T dZ[:, t, :]   (K = rows)
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
       const int t = tbeg + tt;
-      if (t < tend) rowk_accum<T, V, NTV, NTV>(img1, t * V, V, img2, t * V, V, rows, accA[tt]);
+      if (t < tend) {
+        for (int r0 = 0; r0 < rows; r0 += 4) {
+          const bool rok = r0 + k < rows;
+          const float* y = img1 + (rok ? r0 + k : 0) * LD + t * V;
+          const float* d = img2 + (rok ? r0 + k : 0) * LD + t * V;
+          float a[NTV], b[NTV];
+#pragma unroll
+          for (int q = 0; q < NTV; ++q) {
+            const int col = 16 * q + i;
+            const bool ok = rok && col < VM;
+            a[q] = ok ? y[col] : 0.f;
+            b[q] = ok ? d[col] : 0.f;
+          }
+#pragma unroll
+          for (int ta = 0; ta < NTV; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NTV; ++tb)
+              accA[tt][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], accA[tt][ta][tb], 0, 0, 0);
+          if constexpr (VX > 0) {
+            float yx[VXA], dx[VXA];
+#pragma unroll
+            for (int x = 0; x < VX; ++x) {
+              yx[x] = rok ? y[VM + x] : 0.f;   // same address for the 16 lanes of a k group: broadcast
+              dx[x] = rok ? d[VM + x] : 0.f;
+            }
+#pragma unroll
+            for (int x = 0; x < VX; ++x) {
+#pragma unroll
+              for (int q = 0; q < NTV; ++q) {
+                pcol[tt][x][q] = fmaf(a[q], dx[x], pcol[tt][x][q]);   // dA[t][v = 16q+i][VM+x]
+                prow[tt][x][q] = fmaf(yx[x], b[q], prow[tt][x][q]);   // dA[t][VM+x][w = 16q+i]
+              }
+#pragma unroll
+              for (int y2 = 0; y2 < VX; ++y2) pcor[tt][x][y2] = fmaf(yx[x], dx[y2], pcor[tt][x][y2]);
+            }
+          }
+        }
+      }
     }
     __syncthreads();
     mix_rows<T, V, false, true>(img2, rows, Aw);  // dY = spatial^T(dZ)
     stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);  // X again (img1 is free: dA is done)
     __syncthreads();
-    // dT[v][t][q] += sum_rows X[t*V+v] dY[q*V+v]: columns strided by V -> gather through a0 = v, stride V
+    // dT[v][t][q] += sum_rows X[t*V+v] dY[q*V+v]
 #pragma unroll
     for (int vv = 0; vv < VPW; ++vv) {
       const int v = vbeg + vv;
       if (v < vend) {
-        const int i = lane & 15, k = lane >> 4;
         for (int r0 = 0; r0 < rows; r0 += 4) {
           const bool rok = r0 + k < rows;
           const int row = rok ? r0 + k : 0;
@@ -465,8 +516,30 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int v = 16 * ta + 4 * rg + r, w = 16 * tb + col;
-            if (v < V && w < V) dstA[(t * V + v) * V + w] = accA[tt][ta][tb][r];
+            if (v < VM && w < VM) dstA[(t * V + v) * V + w] = accA[tt][ta][tb][r];
           }
+      if constexpr (VX > 0) {
+#pragma unroll
+        for (int x = 0; x < VX; ++x) {
+#pragma unroll
+          for (int q = 0; q < NTV; ++q) {
+            float pc = pcol[tt][x][q], pr = prow[tt][x][q];
+            pc += __shfl_xor(pc, 16, 64); pc += __shfl_xor(pc, 32, 64);
+            pr += __shfl_xor(pr, 16, 64); pr += __shfl_xor(pr, 32, 64);
+            const int idx = 16 * q + i;
+            if (k == 0 && idx < VM) {
+              dstA[(t * V + idx) * V + VM + x] = pc;
+              dstA[(t * V + VM + x) * V + idx] = pr;
+            }
+          }
+#pragma unroll
+          for (int y2 = 0; y2 < VX; ++y2) {
+            float c = pcor[tt][x][y2];   // identical in the 16 lanes of a k group
+            c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+            if (lane == 0) dstA[(t * V + VM + x) * V + VM + y2] = c;
+          }
+        }
+      }
     }
   }
 #pragma unroll
