@@ -18,7 +18,7 @@
 //                    Optionally stores dZ for step 4.
 //  4. k_bwd_gcn_params : dA[t,v,w] = sum_rows Y[t,v] dZ[t,w],  dT[v,t,q] = sum_rows X[t,v] dY[q,v]
 //                    (GEMMs with K = rows (clip,channel) -> MFMA f32).
-#include "tile_ops.h"
+#include "mfma_ops.h"
 
 namespace coskad {
 
@@ -225,15 +225,23 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
   const float* kr = wDX + (Co + Ci) * CiP;
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
-  const int clip0 = blockIdx.x * NB;
+  float* AwL = lds + NB * Ci * LD;
+  float* TwL = AwL + T * V * V;
+  copy_to_lds(AwL, Aw, T * V * V);
+  copy_to_lds(TwL, Tw, V * T * T);
+  float da = 0.f;
+  const int ntiles = ceil_div(B, NB);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int clip0 = tile * NB;
   const int nb = min(NB, B - clip0);
   const int rows = nb * Ci;
   const float* gin = in + (size_t)clip0 * Ci * TV;
   const float* gdu = dU + (size_t)clip0 * Co * TV;
 
+  __syncthreads();
   stage_rows<T, V>(gin, lds, rows * TV, pre, a_in);
   __syncthreads();
-  gcn_rows<T, V, false>(lds, rows, Aw, Tw);
+  gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
   __syncthreads();
 
   const int P = nb * TV;
@@ -276,9 +284,8 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
   }
   __syncthreads();
   if (dZout) unstage_rows<T, V>(dZout + (size_t)clip0 * Ci * TV, lds, rows * TV);
-  float da = 0.f;
   if (dIn) {
-    gcn_rows<T, V, true>(lds, rows, Aw, Tw);  // (barrier inside; unstage above only read)
+    gcn_mfma<T, V, true>(lds, rows, AwL, TwL);  // (barrier inside; unstage above only read)
     __syncthreads();
     // position phase B: dX = gcn^T(dZ) + kr + Br dU + Kr X ; dU_prev = dX * PReLU'(U_prev)
     for (int r = 0; r < rounds; ++r) {
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
       }
     }
   }
+  }  // tile loop
   if (da_partials) {
     da = wave_sum(da);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = da;
@@ -395,6 +403,10 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img1 = lds;
   float* img2 = lds + NB * Ci * LD;
+  float* AwL = img2 + NB * Ci * LD;
+  float* TwL = AwL + T * V * V;
+  copy_to_lds(AwL, Aw, T * V * V);
+  copy_to_lds(TwL, Tw, V * T * T);
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
   const int wave = uniform(threadIdx.x >> 6);
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
     stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
     stage_rows<T, V>(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
     __syncthreads();
-    mix_rows<T, V, true, false>(img1, rows, Tw);  // Y = temporal(X)
+    temporal_mfma<T, V, false>(img1, rows, TwL);  // Y = temporal(X)
     __syncthreads();
     // dA[t] += Y[:, t, :]^T dZ[:, t, :]   (K = rows)
 #pragma unroll
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
       }
     }
     __syncthreads();
-    mix_rows<T, V, false, true>(img2, rows, Aw);  // dY = spatial^T(dZ)
+    spatial_mfma<T, V, true>(img2, rows, AwL);  // dY = spatial^T(dZ)
     stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);  // X again (img1 is free: dA is done)
     __syncthreads();
     // dT[v][t][q] += sum_rows X[t*V+v] dY[q*V+v]
@@ -697,13 +709,22 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   // 3. data path
   int grid_d;
   {
-    const int NB = nb_for(Ci, B, LD, 60 * 1024);
-    const size_t lds = (size_t)NB * Ci * LD * sizeof(float);
-    grid_d = ceil_div(B, NB);
+    int NB = Ci >= 32 ? 1 : 32 / Ci;
+    if (NB > B) NB = B;
+    const size_t lds = ((size_t)NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
+    if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
+    const int ntl = ceil_div(B, NB);
+    const int per_cu = (int)((size_t)kMaxLdsBytes / lds);
+    grid_d = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if (grid_d > ntl) grid_d = ntl;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
 #define LAUNCH_D(CIP)                                                                                   \
-  hipLaunchKernelGGL((k_bwd_data<T, V, CIP>), dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw,       \
-                     w.coef, in_slope, dIn, w.dz, dap, B, Ci, Co, NB)
+  do {                                                                                                  \
+    auto k = k_bwd_data<T, V, CIP>;                                                                     \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
+                       w.dz, dap, B, Ci, Co, NB);                                                       \
+  } while (0)
     if (Ci <= 2) LAUNCH_D(2);
     else if (Ci <= 4) LAUNCH_D(4);
     else if (Ci <= 8) LAUNCH_D(8);
@@ -720,8 +741,10 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   // 4. gcn parameter gradients
   {
     const int E = T * V * V + V * T * T;
-    const int NB = nb_for(Ci, B, LD, 60 * 1024);
-    const size_t lds = (size_t)2 * NB * Ci * LD * sizeof(float);
+    int NB = Ci >= 32 ? 1 : 32 / Ci;
+    if (NB > B) NB = B;
+    const size_t lds = ((size_t)2 * NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
+    if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
     const int ntiles = ceil_div(B, NB);
     const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
     auto k = k_bwd_gcn_params<T, V>;
@@ -745,8 +768,8 @@ static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* A
                                  float* dT, void* ws, int accumulate, int rows, hipStream_t st) {
   constexpr int LD = Geo<T, V>::LD;
   const int E = T * V * V + V * T * T;
-  const int NB = rows < 64 ? rows : 64;
-  const size_t lds = (size_t)2 * NB * LD * sizeof(float);
+  const int NB = rows < 32 ? rows : 32;
+  const size_t lds = ((size_t)2 * NB * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
   const int ntiles = ceil_div(rows, NB);
   const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
   float* partials = reinterpret_cast<float*>(ws);

@@ -12,7 +12,7 @@
 //   k_fwd_moments   : per-block partials of  sum x x^T, sum x, sum z z^T, sum z
 //   k_reduce_partials: fp64 sum over blocks (deterministic: fixed order, no atomics)
 //   k_train_fold    : stats -> folded weights, saved stats for backward, running-stat update
-#include "tile_ops.h"
+#include "mfma_ops.h"
 
 namespace coskad {
 
@@ -28,6 +28,10 @@ __global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict_
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* scratch = lds + NB * Ci * LD;  // 1024 floats
+  float* AwL = scratch + 1024;
+  float* TwL = AwL + T * V * V;
+  copy_to_lds(AwL, Aw, T * V * V);
+  copy_to_lds(TwL, Tw, V * T * T);
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
   f32x4 mx[NTC][NTC], mz[NTC][NTC], sx[NTC], sz[NTC];
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict_
       }
       __syncthreads();
     }
-    gcn_rows<T, V, false>(lds, rows, Aw, Tw);
+    gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
     __syncthreads();
     for (int n = 0; n < nb; ++n) {
       const float* r = lds + n * Ci * LD;
@@ -220,8 +224,10 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   if (ws_bytes < train_stats_ws_bytes(Ci))
     return fail(COSKAD_ERR_WORKSPACE, "train_stats: workspace %zu < %zu bytes", ws_bytes, train_stats_ws_bytes(Ci));
   const int E = 2 * (Ci * Ci + Ci);
-  const int NB = pick_nb_rows(Ci, B, LD, 60 * 1024);
-  const size_t lds = ((size_t)NB * Ci * LD + 1024) * sizeof(float);
+  int NB = Ci >= 32 ? 1 : 32 / Ci;   // 32 rows per tile (2 MFMA row tiles)
+  if (NB > B) NB = B;
+  const size_t lds = ((size_t)NB * Ci * LD + 1024 + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
+  if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "train_stats: LDS %zu too large", lds);
   const int ntiles = ceil_div(B, NB);
   const int grid = ntiles < kMaxGrid ? ntiles : kMaxGrid;
   float* partials = reinterpret_cast<float*>(ws);
@@ -229,8 +235,11 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   const int need_x = Wr != nullptr;
   const int ntc = ceil_div(Ci, 16);
 #define LAUNCH_M(NTC)                                                                           \
-  hipLaunchKernelGGL((k_fwd_moments<T, V, NTC>), dim3(grid), dim3(kBlock), lds, st, in, Aw, Tw, \
-                     in_slope, partials, B, Ci, NB, need_x)
+  do {                                                                                          \
+    auto k = k_fwd_moments<T, V, NTC>;                                                          \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, Aw, Tw, in_slope, partials, B, Ci, NB, need_x); \
+  } while (0)
   if (ntc == 1) LAUNCH_M(1);
   else if (ntc == 2) LAUNCH_M(2);
   else if (ntc == 3) LAUNCH_M(3);
