@@ -28,6 +28,60 @@ constexpr int kMaxGridBwd = 512;
 // 1. reductions.  LDS: X image (nb*Ci rows) then dU image (nb*Co rows) then 1024 scratch.
 //    partial row: [P Co*Ci][Q Co*Ci][sdU Co]
 // ---------------------------------------------------------------------------------------
+// positions are processed in NCH chunks so that only a [Co x chunk] slab of dU sits in LDS
+template <int T, int V>
+struct RedGeo {
+  static constexpr int TV = T * V;
+  static constexpr int NCH = 3;
+  static constexpr int CH = ((TV + NCH - 1) / NCH + 3) / 4 * 4;   // 68 for 12x17
+  static constexpr int LDC = CH + 1;
+};
+
+// Out[a][b] += sum_{q < npos} A[a][offA + q] * B[b][offB + q]   (MFMA f32, waves split q)
+template <int NTA, int NTB, bool SUMS>
+__device__ __forceinline__ void outer_accum2(const float* ldsA, int ldA, int offA, int va, const float* ldsB,
+                                             int ldB, int offB, int vb, int npos, f32x4 (&acc)[NTA][NTB],
+                                             f32x4 (&sacc)[NTA]) {
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int i = lane & 15, k = lane >> 4;
+  for (int p0 = 4 * wave; p0 < npos; p0 += 4 * (kBlock / 64)) {
+    const bool pok = p0 + k < npos;
+    float a[NTA], b[NTB];
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) {
+      const int row = 16 * ta + i;
+      a[ta] = (pok && row < va) ? ldsA[row * ldA + offA + p0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+      const int row = 16 * tb + i;
+      b[tb] = (pok && row < vb) ? ldsB[row * ldB + offB + p0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) {
+#pragma unroll
+      for (int tb = 0; tb < NTB; ++tb)
+        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+      if constexpr (SUMS)
+        sacc[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], pok ? 1.0f : 0.f, sacc[ta], 0, 0, 0);
+    }
+  }
+}
+
+// stage rows x [pbeg, pbeg+npos) of a [rows][TV] global tile into a chunk image with stride LDC
+template <int T, int V>
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ g, float* lds, int rows, int pbeg, int npos) {
+  constexpr int TV = T * V, LDC = RedGeo<T, V>::LDC;
+  const int n4 = npos >> 2;               // pbeg and npos are multiples of 4, TV % 4 == 0
+  for (int e = threadIdx.x; e < rows * n4; e += kBlock) {
+    const int row = e / n4, q4 = e - row * n4;
+    const float4 v = *reinterpret_cast<const float4*>(g + (size_t)row * TV + pbeg + 4 * q4);
+    float* d = lds + row * LDC + 4 * q4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+
 template <int T, int V, int NTO, int NTC>
 __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__ in,
                                                       const float* __restrict__ dU,
@@ -37,10 +91,16 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__
                                                       float* __restrict__ partials, int B, int Ci,
                                                       int Co, int NB, int need_q) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int NCH = RedGeo<T, V>::NCH, CH = RedGeo<T, V>::CH, LDC = RedGeo<T, V>::LDC;
+  static_assert(TV % 4 == 0, "chunked staging uses float4");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* ldx = lds;
-  float* ldu = lds + NB * Ci * LD;
-  float* scratch = ldu + NB * Co * LD;
+  float* ldx = lds;                         // X / Z image: NB*Ci rows x LD
+  float* ldu = lds + NB * Ci * LD;          // dU slab: NB*Co rows x LDC
+  float* scratch = ldu + NB * Co * LDC;     // 1024
+  float* AwL = scratch + 1024;
+  float* TwL = AwL + T * V * V;
+  copy_to_lds(AwL, Aw, T * V * V);
+  copy_to_lds(TwL, Tw, V * T * T);
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
   f32x4 pacc[NTO][NTC], qacc[NTO][NTC], sacc[NTO], sdummy[NTO];
@@ -50,19 +110,29 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
+    const float* gdu = dU + (size_t)clip0 * Co * TV;
     __syncthreads();
     stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, pre, a_in);
-    stage_rows<T, V>(dU + (size_t)clip0 * Co * TV, ldu, nb * Co * TV, false, 0.f);
-    __syncthreads();
     if (need_q) {
-      for (int n = 0; n < nb; ++n)
-        outer_accum<T, V, NTO, NTC, false>(ldu + n * Co * LD, Co, ldx + n * Ci * LD, Ci, qacc, sdummy);
-      __syncthreads();
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
+        __syncthreads();
+        stage_chunk<T, V>(gdu, ldu, nb * Co, pbeg, npos);
+        __syncthreads();
+        for (int n = 0; n < nb; ++n)
+          outer_accum2<NTO, NTC, false>(ldu + n * Co * LDC, LDC, 0, Co, ldx + n * Ci * LD, LD, pbeg, Ci, npos, qacc, sdummy);
+      }
     }
-    gcn_rows<T, V, false>(ldx, nb * Ci, Aw, Tw);
     __syncthreads();
-    for (int n = 0; n < nb; ++n)
-      outer_accum<T, V, NTO, NTC, true>(ldu + n * Co * LD, Co, ldx + n * Ci * LD, Ci, pacc, sacc);
+    gcn_mfma<T, V, false>(ldx, nb * Ci, AwL, TwL);
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
+      __syncthreads();
+      stage_chunk<T, V>(gdu, ldu, nb * Co, pbeg, npos);
+      __syncthreads();
+      for (int n = 0; n < nb; ++n)
+        outer_accum2<NTO, NTC, true>(ldu + n * Co * LDC, LDC, 0, Co, ldx + n * Ci * LD, LD, pbeg, Ci, npos, pacc, sacc);
+    }
   }
   float* dst = partials + (size_t)blockIdx.x * (2 * Co * Ci + Co);
   store_outer<NTO, NTC>(pacc, scratch, dst, Ci, Co, Ci);
@@ -671,8 +741,14 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   // 1. reductions
   {
     const int E = 2 * Co * Ci + Co;
-    const int NB = nb_for(Ci + Co, B, LD, 150 * 1024);
-    const size_t lds = ((size_t)NB * (Ci + Co) * LD + 1024) * sizeof(float);
+    int NB = Ci >= 32 ? 1 : 32 / Ci;
+    if (NB > B) NB = B;
+    auto red_lds = [&](int nb_) {
+      return ((size_t)nb_ * Ci * LD + (size_t)nb_ * Co * RedGeo<T, V>::LDC + 1024 + (size_t)T * V * V +
+              (size_t)V * T * T) * sizeof(float);
+    };
+    while (NB > 1 && red_lds(NB) > 76 * 1024) --NB;   // keep two blocks per CU
+    const size_t lds = red_lds(NB);
     if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
     const int ntiles = ceil_div(B, NB);
     const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
