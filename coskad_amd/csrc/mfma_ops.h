@@ -374,3 +374,99 @@ __device__ __forceinline__ void load_wfold_padded(float* Wl, const float* __rest
 }
 
 }  // namespace coskad
+
+// ---- strip version of the conv GEMM: full-line global traffic ----------------------------
+// A work item is a STRIP of 32 consecutive positions, handled as two MFMA column tiles with the
+// position map  tile m, column j  <->  p = p0 + 2*j + m.  Then
+//   * a global B operand is ONE 8-byte load per lane (16 lanes = one contiguous 128-B line per row)
+//     feeding both tiles,
+//   * outputs leave as 8-byte stores (128-B lines),
+//   * LDS operands are two stride-2 ds_read_b32 (conflict-free on the odd-LD image).
+// K-image: [LDS rows KZ][global source 1 rows K1 (no activation)][global source 2 rows K2 (optional
+// PReLU)]; KZ, K1, K2 are multiples of 4 (weights of padded rows are zero); Wl[k][CoP] in LDS.
+namespace coskad {
+
+template <int T, int V, int OTI, class Epilogue>
+__device__ __forceinline__ void conv_mfma_s(const float* zimg, int KZ, int nz, const float* __restrict__ g1,
+                                            int K1, int n1, const float* __restrict__ g2, int K2, int n2,
+                                            bool act2, float a2, const float* Wl, int CoP, int og, int s0,
+                                            int sstep, Epilogue&& epi) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  static_assert(TV % 2 == 0, "strip conv needs an even number of positions");
+  constexpr int PS = (TV + 31) / 32;
+  constexpr int XB = 8;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kk = lane >> 4;
+  const int KZS = KZ / 4, KGS = (K1 + K2) / 4, K1S = K1 / 4;
+  const float* wcol = Wl + 16 * og * OTI + j;
+
+  for (int sp = s0; sp < PS; sp += sstep) {
+    const int p = 32 * sp + 2 * j;
+    const bool pok = p < TV;
+    const int pc = pok ? p : TV - 2;
+    auto gload = [&](int g) -> float2 {          // B operand of global k-step g for this lane
+      if (g >= KGS) return float2{0.f, 0.f};
+      const bool first = g < K1S;
+      const int c = first ? 4 * g + kk : 4 * (g - K1S) + kk;
+      const int nr = first ? n1 : n2;
+      const float* base = first ? g1 : g2;
+      const int cc = c < nr ? c : nr - 1;
+      float2 v = *reinterpret_cast<const float2*>(base + (size_t)cc * TV + pc);
+      if (!first && act2) { v.x = prelu_f(v.x, a2); v.y = prelu_f(v.y, a2); }
+      return v;
+    };
+    f32x4 acc[OTI][2];
+#pragma unroll
+    for (int t = 0; t < OTI; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float2 cur[XB], nxt[XB];
+#pragma unroll
+    for (int u = 0; u < XB; ++u) cur[u] = gload(u);
+    // LDS source while the first global batch is in flight
+    for (int s = 0; s < KZS; s += 2) {
+      float b[2][2], a[2][OTI];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = 4 * (s + u) + kk;
+        const int cc = c < nz ? c : nz - 1;
+        const bool ok = s + u < KZS;
+        b[u][0] = ok ? zimg[cc * LD + pc] : 0.f;
+        b[u][1] = ok ? zimg[cc * LD + pc + 1] : 0.f;
+        const float* w = wcol + (ok ? c : 0) * CoP;
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) a[u][t] = w[16 * t];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) {
+          acc[t][0] = mfma4(a[u][t], b[u][0], acc[t][0]);
+          acc[t][1] = mfma4(a[u][t], b[u][1], acc[t][1]);
+        }
+    }
+    for (int g0 = 0; g0 < KGS; g0 += XB) {
+#pragma unroll
+      for (int u = 0; u < XB; ++u) nxt[u] = gload(g0 + XB + u);
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        if (g0 + u < KGS) {
+          const float* w = wcol + (KZ + 4 * (g0 + u) + kk) * CoP;
+#pragma unroll
+          for (int t = 0; t < OTI; ++t) {
+            const float a = w[16 * t];
+            acc[t][0] = mfma4(a, cur[u].x, acc[t][0]);
+            acc[t][1] = mfma4(a, cur[u].y, acc[t][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < XB; ++u) cur[u] = nxt[u];
+    }
+    // D[row = 4*kk + r][col = j] of tile m  <->  (o, p + m)
+#pragma unroll
+    for (int t = 0; t < OTI; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epi(16 * (og * OTI + t) + 4 * kk + r, p, pok, acc[t][0][r], acc[t][1][r]);
+  }
+}
+
+}  // namespace coskad

@@ -278,17 +278,17 @@ __global__ __launch_bounds__(256) void k_bwd_fold(
 // 3. data path.  LDS: one Ci-row image per clip (+ 64 floats).  CIP = Ci rounded up to a
 //    power of two (register arrays need static bounds).
 // ---------------------------------------------------------------------------------------
-template <int T, int V, int CIP>
+template <int T, int V, int OTI>
 __global__ __launch_bounds__(kBlock) void k_bwd_data(
     const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
     float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
     int Co, int NB) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
-  constexpr int CH = CIP < 16 ? CIP : 16;  // output-channel chunk of the position phases
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sred[kBlock / 64];
   const int CiP = round_up(Ci, 16);
+  const int KZ = round_up(Ci, 4), K1 = round_up(Co, 4);
   const float* wDZ = coef;
   const float* kt = wDZ + (Co + Ci) * CiP;
   const float* wDX = kt + CiP;
@@ -297,120 +297,80 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
   const float a_in = pre ? in_slope[0] : 0.f;
   float* AwL = lds + NB * Ci * LD;
   float* TwL = AwL + T * V * V;
+  float* WlA = TwL + V * T * T;              // [(KZ + K1)][CiP]: Kt rows (LDS source Z), then Bt rows (dU)
+  float* WlB = WlA + (KZ + K1) * CiP;        // [(K1 + KZ)][CiP]: Br rows (dU), then Kr rows (X)
+  float* ktl = WlB + (K1 + KZ) * CiP;        // [CiP]
+  float* krl = ktl + CiP;                    // [CiP]
   copy_to_lds(AwL, Aw, T * V * V);
   copy_to_lds(TwL, Tw, V * T * T);
+  for (int e = threadIdx.x; e < (KZ + K1) * CiP; e += kBlock) {
+    const int k = e / CiP, c = e - k * CiP;
+    float va = 0.f, vb = 0.f;
+    if (k < KZ) { if (k < Ci) va = wDZ[(Co + k) * CiP + c]; }
+    else if (k - KZ < Co) va = wDZ[(k - KZ) * CiP + c];
+    if (k < K1) { if (k < Co) vb = wDX[k * CiP + c]; }
+    else if (k - K1 < Ci) vb = wDX[(Co + k - K1) * CiP + c];
+    WlA[e] = va;
+    WlB[e] = vb;
+  }
+  copy_to_lds(ktl, kt, CiP);
+  copy_to_lds(krl, kr, CiP);
+  const int wave = uniform(threadIdx.x >> 6);
   float da = 0.f;
   const int ntiles = ceil_div(B, NB);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const int clip0 = tile * NB;
-  const int nb = min(NB, B - clip0);
-  const int rows = nb * Ci;
-  const float* gin = in + (size_t)clip0 * Ci * TV;
-  const float* gdu = dU + (size_t)clip0 * Co * TV;
+    const int clip0 = tile * NB;
+    const int nb = min(NB, B - clip0);
+    const int rows = nb * Ci;
+    const float* gin = in + (size_t)clip0 * Ci * TV;
+    const float* gdu = dU + (size_t)clip0 * Co * TV;
 
-  __syncthreads();
-  stage_rows<T, V>(gin, lds, rows * TV, pre, a_in);
-  __syncthreads();
-  gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
-  __syncthreads();
-
-  const int P = nb * TV;
-  const int rounds = ceil_div(P, kBlock);
-  // position phase A: dZ[:,p] = kt + Bt dU[:,p] + Kt Z[:,p], in place over Z.
-  // All CIP outputs of a position accumulate in registers; the input loops are ROLLED (wave-uniform
-  // weights stream through SGPRs, CIP per iteration) and Z[:,p] is fully read before it is overwritten.
-  for (int r = 0; r < rounds; ++r) {
-    const int pos = r * kBlock + threadIdx.x;
-    const bool act = pos < P;
-    const int pc = act ? pos : 0;
-    const int n = pc / TV, p = pc - n * TV;
-    float* zcol = lds + (n * Ci) * LD + p;
-    const float* ducol = gdu + (size_t)n * Co * TV + p;
-    float out[CIP];
-#pragma unroll
-    for (int c = 0; c < CIP; ++c) out[c] = kt[c < CiP ? c : 0];
-    for (int o0 = 0; o0 < Co; o0 += 4) {
-      float dr[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dr[k] = (o0 + k < Co) ? ducol[(size_t)(o0 + k) * TV] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float* w = wDZ + (o0 + k < Co ? o0 + k : 0) * CiP;
-#pragma unroll
-        for (int c = 0; c < CIP; ++c) out[c] = fmaf(w[c < CiP ? c : 0], dr[k], out[c]);
-      }
-    }
-    for (int c2 = 0; c2 < Ci; ++c2) {
-      const float z = zcol[c2 * LD];
-      const float* w = wDZ + (Co + c2) * CiP;
-#pragma unroll
-      for (int c = 0; c < CIP; ++c) out[c] = fmaf(w[c < CiP ? c : 0], z, out[c]);
-    }
-    if (act) {
-#pragma unroll
-      for (int c = 0; c < CIP; ++c)
-        if (c < Ci) zcol[c * LD] = out[c];
-    }
-  }
-  __syncthreads();
-  if (dZout) unstage_rows<T, V>(dZout + (size_t)clip0 * Ci * TV, lds, rows * TV);
-  if (dIn) {
-    gcn_mfma<T, V, true>(lds, rows, AwL, TwL);  // (barrier inside; unstage above only read)
     __syncthreads();
-    // position phase B: dX = gcn^T(dZ) + kr + Br dU + Kr X ; dU_prev = dX * PReLU'(U_prev)
-    for (int r = 0; r < rounds; ++r) {
-      const int pos = r * kBlock + threadIdx.x;
-      const bool act = pos < P;
-      const int pc = act ? pos : 0;
-      const int n = pc / TV, p = pc - n * TV;
-      const float* gcol = lds + (n * Ci) * LD + p;
-      const float* ducol = gdu + (size_t)n * Co * TV + p;
-      const float* ucol = gin + (size_t)n * Ci * TV + p;
-      float* dcol = dIn + ((size_t)(clip0 + n) * Ci) * TV + p;
-      for (int c0 = 0; c0 < Ci; c0 += CH) {
-        float acc[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) acc[j] = kr[c0 + j] + ((c0 + j < Ci) ? gcol[(c0 + j) * LD] : 0.f);
-        for (int o0 = 0; o0 < Co; o0 += 8) {
-          float dr[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) dr[k] = (o0 + k < Co) ? ducol[(size_t)(o0 + k) * TV] : 0.f;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float* w = wDX + (o0 + k < Co ? o0 + k : 0) * CiP + c0;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) acc[j] = fmaf(w[j], dr[k], acc[j]);
-          }
+    stage_rows<T, V>(gin, lds, rows * TV, pre, a_in);
+    __syncthreads();
+    gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
+    __syncthreads();
+    // phase A (MFMA): dZ[:,p] = kt + Kt Z[:,p] + Bt dU[:,p], in place over Z.  One item = all channels of a
+    // strip, so every Z column is fully read before it is overwritten.
+    for (int n = 0; n < nb; ++n) {
+      float* img = lds + n * Ci * LD;
+      auto epiA = [&](int o, int p, bool pok, float v0, float v1) {
+        if (o < Ci && pok) {
+          img[o * LD + p] = v0 + ktl[o];
+          img[o * LD + p + 1] = v1 + ktl[o];
         }
-        for (int c2 = 0; c2 < Ci; c2 += 4) {
-          float xr[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float u = (c2 + k < Ci) ? ucol[(size_t)(c2 + k) * TV] : 0.f;
-            xr[k] = pre ? prelu_f(u, a_in) : u;
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float* w = wDX + (Co + (c2 + k < Ci ? c2 + k : 0)) * CiP + c0;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) acc[j] = fmaf(w[j], (c2 + k < Ci) ? xr[k] : 0.f, acc[j]);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          if (c0 + j < Ci) {
-            const float u = ucol[(size_t)(c0 + j) * TV];
-            float g = acc[j];
+      };
+      conv_mfma_s<T, V, OTI>(img, KZ, Ci, gdu + (size_t)n * Co * TV, K1, Co, nullptr, 0, 1, false, 0.f, WlA, CiP, 0,
+                             (wave + n) & 3, kBlock / 64, epiA);
+    }
+    __syncthreads();
+    if (dZout) unstage_rows<T, V>(dZout + (size_t)clip0 * Ci * TV, lds, rows * TV);
+    if (dIn) {
+      gcn_mfma<T, V, true>(lds, rows, AwL, TwL);  // (barrier inside; unstage above only read)
+      __syncthreads();
+      // phase B (MFMA): dX = gcn^T(dZ) + kr + Br dU + Kr X ; dU_prev = dX * PReLU'(U_prev)
+      for (int n = 0; n < nb; ++n) {
+        const float* img = lds + n * Ci * LD;
+        const float* ug = gin + (size_t)n * Ci * TV;
+        float* dg = dIn + (size_t)(clip0 + n) * Ci * TV;
+        auto epiB = [&](int o, int p, bool pok, float v0, float v1) {
+          if (o < Ci && pok) {
+            float g0 = v0 + krl[o] + img[o * LD + p];
+            float g1 = v1 + krl[o] + img[o * LD + p + 1];
             if (pre) {
-              if (act && u < 0.f) da = fmaf(g, u, da);
-              g = u > 0.f ? g : a_in * g;
+              const float2 u = *reinterpret_cast<const float2*>(ug + (size_t)o * TV + p);
+              if (u.x < 0.f) da = fmaf(g0, u.x, da);
+              if (u.y < 0.f) da = fmaf(g1, u.y, da);
+              g0 = u.x > 0.f ? g0 : a_in * g0;
+              g1 = u.y > 0.f ? g1 : a_in * g1;
             }
-            if (act) dcol[(size_t)(c0 + j) * TV] = g;
+            *reinterpret_cast<float2*>(dg + (size_t)o * TV + p) = float2{g0, g1};
           }
-        }
+        };
+        conv_mfma_s<T, V, OTI>(nullptr, 0, 1, gdu + (size_t)n * Co * TV, K1, Co, ug, KZ, Ci, pre, a_in, WlB, CiP, 0,
+                               (wave + n) & 3, kBlock / 64, epiB);
       }
     }
-  }
   }  // tile loop
   if (da_partials) {
     da = wave_sum(da);
@@ -787,26 +747,26 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   {
     int NB = Ci >= 32 ? 1 : 32 / Ci;
     if (NB > B) NB = B;
-    const size_t lds = ((size_t)NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
+    const int CiP = round_up(Ci, 16), KZ = round_up(Ci, 4), K1 = round_up(Co, 4);
+    const size_t lds = ((size_t)NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T + 2 * (size_t)(KZ + K1) * CiP +
+                        2 * CiP) * sizeof(float);
     if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
     const int ntl = ceil_div(B, NB);
     const int per_cu = (int)((size_t)kMaxLdsBytes / lds);
     grid_d = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     if (grid_d > ntl) grid_d = ntl;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
-#define LAUNCH_D(CIP)                                                                                   \
+#define LAUNCH_D(OTI)                                                                                   \
   do {                                                                                                  \
-    auto k = k_bwd_data<T, V, CIP>;                                                                     \
+    auto k = k_bwd_data<T, V, OTI>;                                                                     \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
                        w.dz, dap, B, Ci, Co, NB);                                                       \
   } while (0)
-    if (Ci <= 2) LAUNCH_D(2);
-    else if (Ci <= 4) LAUNCH_D(4);
-    else if (Ci <= 8) LAUNCH_D(8);
-    else if (Ci <= 16) LAUNCH_D(16);
-    else if (Ci <= 32) LAUNCH_D(32);
-    else LAUNCH_D(64);
+    if (CiP == 16) LAUNCH_D(1);
+    else if (CiP == 32) LAUNCH_D(2);
+    else if (CiP == 48) LAUNCH_D(3);
+    else LAUNCH_D(4);
 #undef LAUNCH_D
     if ((rc = check_launch("bwd_data"))) return rc;
     if (dap) {
