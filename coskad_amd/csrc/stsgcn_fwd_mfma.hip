@@ -30,13 +30,6 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
   load_wfold_padded(Wl, wfold, Ci, KZ, CoP, 2);
   copy_to_lds(bl, bias, CoP);
   const int wave = uniform(threadIdx.x >> 6);
-  // register-resident conv weights: wave -> fixed output group, position tiles strided over the
-  // waves that share the group (possible when both sources need <= KH k-steps and OG divides 4)
-  constexpr int KH = 8;
-  const int OG = (CoP / 16 + OTI - 1) / OTI;
-  const bool regw = KZ <= 4 * KH && (OG == 1 || OG == 2 || OG == 4);
-  ConvFrags<OTI, KH> frags;
-  const int my_og = wave % OG, pt_first = wave / OG, pt_stride = (kBlock / 64) / OG;
 
   // Tile pipeline: the NEXT tile is fetched HBM -> registers while the current one is computed,
   // and written to LDS after the conv phase has finished reading the image.
@@ -81,8 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
   };
   static_assert(TV % 4 == 0, "tile prefetch uses float4");
   if (!(dbg & 4)) fetch(blockIdx.x);
-  __syncthreads();
-  if (regw) load_conv_frags<OTI, KH>(frags, Wl, CoP, my_og, KZ, KZ);
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
@@ -96,19 +88,18 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
     __syncthreads();
     for (int n = 0; n < nb && !(dbg & 2); ++n) {
       float* og = out + (size_t)(clip0 + n) * Co * TV;
-      auto epi = [&](int o, int p, float v) {
-        if (o < Co && p < TV && !(dbg & 8)) {
-          v += bl[o];
-          og[(size_t)o * TV + p] = post ? prelu_f(v, a_out) : v;
+      auto epi = [&](int o, int p, bool pok, float v0, float v1) {
+        if (o < Co && pok && !(dbg & 8)) {
+          v0 += bl[o];
+          v1 += bl[o];
+          if (post) { v0 = prelu_f(v0, a_out); v1 = prelu_f(v1, a_out); }
+          *reinterpret_cast<float2*>(og + (size_t)o * TV + p) = float2{v0, v1};
         }
       };
-      // rotate the starting wave per clip so the ragged tail spreads over the waves
-      if (regw)
-        conv_mfma_r<T, V, OTI, KH>(img + n * Ci * LD, (dbg & 32) ? 0 : KZ, Ci, gin + (size_t)n * Ci * TV, (dbg & 16) ? 0 : KZ, Ci, pre, a_in, frags,
-                                   my_og, (pt_first + n) % pt_stride, pt_stride, epi);
-      else
-        conv_mfma<T, V, OTI>(img + n * Ci * LD, KZ, Ci, gin + (size_t)n * Ci * TV, KZ, Ci, pre, a_in, Wl, CoP,
-                             (wave + n) & 3, kBlock / 64, epi);
+      const int NOG = (CoP / 16 + OTI - 1) / OTI;
+      for (int g = 0; g < NOG; ++g)
+        conv_mfma_s<T, V, OTI>(img + n * Ci * LD, (dbg & 32) ? 0 : KZ, Ci, nullptr, 0, 1, gin + (size_t)n * Ci * TV,
+                               (dbg & 16) ? 0 : KZ, Ci, pre, a_in, Wl, CoP, g, (wave + n + g) & 3, kBlock / 64, epi);
     }
   }
 }
@@ -140,8 +131,10 @@ int launch_layer_apply_m(const float* in, float* out, const float* Aw, const flo
   } while (0)
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("COSKAD_DBG"); dbg = e ? atoi(e) : 0; }
-  if (CoP >= 32) LAUNCH_OTI(2);
-  else LAUNCH_OTI(1);
+  if (CoP == 16) LAUNCH_OTI(1);
+  else if (CoP == 32) LAUNCH_OTI(2);
+  else if (CoP == 48) LAUNCH_OTI(3);
+  else LAUNCH_OTI(4);
 #undef LAUNCH_OTI
   return check_launch("layer_apply_m");
 }
