@@ -15,13 +15,14 @@
 namespace coskad {
 
 constexpr int kBtlWaves = kBlock / 64;
+constexpr int kBtlFwdWaves = 8;   // forward: 8 waves split K (more loads in flight per CU)
 
-__global__ __launch_bounds__(kBlock) void k_btlnk_fwd(const float* __restrict__ U,
+__global__ __launch_bounds__(64 * kBtlFwdWaves) void k_btlnk_fwd(const float* __restrict__ U,
                                                      const float* __restrict__ W,
                                                      const float* __restrict__ bias,
                                                      const float* __restrict__ slope,
                                                      float* __restrict__ z, int B, int K, int L) {
-  __shared__ float red[kBtlWaves][256];
+  __shared__ float red[kBtlFwdWaves][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kk = lane >> 4;
   const int n = blockIdx.x * 16 + i;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(kBlock) void k_btlnk_fwd(const float* __restrict__ 
   const float* up = U + (size_t)(rowok ? n : 0) * K;
   const float* wp = W + (size_t)(colok ? i : 0) * K;
   const int nsteps = ceil_div(K, 16);
-  const int per = ceil_div(nsteps, kBtlWaves);
+  const int per = ceil_div(nsteps, kBtlFwdWaves);
   const int s0 = wave * per, s1 = min(nsteps, s0 + per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
@@ -51,10 +52,12 @@ __global__ __launch_bounds__(kBlock) void k_btlnk_fwd(const float* __restrict__ 
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][(4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
   __syncthreads();
-  const int e = threadIdx.x, row = e >> 4, col = e & 15;
+  const int e = threadIdx.x, row = (e >> 4) & 15, col = e & 15;
   const int nn = blockIdx.x * 16 + row;
-  if (nn < B && col < L) {
-    float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  if (e < 256 && nn < B && col < L) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kBtlFwdWaves; ++w) s += red[w][e];
     z[(size_t)nn * L + col] = s + (bias ? bias[col] : 0.f);
   }
 }
@@ -201,7 +204,7 @@ int coskad_btlnk_fwd_f32(const float* U, const float* W, const float* bias, cons
   if (B <= 0 || K <= 0 || L <= 0) return fail(COSKAD_ERR_ARG, "btlnk_fwd: B=%d K=%d L=%d", B, K, L);
   if (L > 16) return fail(COSKAD_ERR_SHAPE, "btlnk_fwd: latent_dim=%d > 16 not supported", L);
   if (K % 4) return fail(COSKAD_ERR_SHAPE, "btlnk_fwd: K=%d must be a multiple of 4", K);
-  hipLaunchKernelGGL(k_btlnk_fwd, dim3(ceil_div(B, 16)), dim3(kBlock), 0, stream, U, W, bias, slope, z, B, K, L);
+  hipLaunchKernelGGL(k_btlnk_fwd, dim3(ceil_div(B, 16)), dim3(64 * kBtlFwdWaves), 0, stream, U, W, bias, slope, z, B, K, L);
   return check_launch("btlnk_fwd");
 }
 

@@ -140,18 +140,30 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__
   store_sums<NTO>(sacc, scratch, dst + 2 * Co * Ci, Co);
 }
 
-__global__ __launch_bounds__(256) void k_reduce_partials_d(const float* __restrict__ partials, int P, int E,
-                                                            double* __restrict__ out) {
-  __shared__ double sh[256];
+__global__ __launch_bounds__(1024) void k_reduce_partials_d(const float* __restrict__ partials, int P, int E,
+                                                             double* __restrict__ out) {
+  __shared__ double sh[1024];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
-  double s = 0.0;
-  if (e < E)
-    for (int p = slice; p < P; p += 4) s += (double)partials[(size_t)p * E + e];
-  sh[threadIdx.x] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < E) {
+    int p = slice;
+    for (; p + 48 < P; p += 64) {
+      s0 += (double)partials[(size_t)p * E + e];
+      s1 += (double)partials[(size_t)(p + 16) * E + e];
+      s2 += (double)partials[(size_t)(p + 32) * E + e];
+      s3 += (double)partials[(size_t)(p + 48) * E + e];
+    }
+    for (; p < P; p += 16) s0 += (double)partials[(size_t)p * E + e];
+  }
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (slice == 0 && e < E)
-    out[e] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+  if (slice == 0 && e < E) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+    out[e] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -601,28 +613,31 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
   }
 }
 
-// out[e] (+)= sum_p partials[p*Erow + offset + e],  e < count.  block = 64 elements x 4 partial-slices.
-__global__ __launch_bounds__(256) void k_reduce_to_f32(const float* __restrict__ partials, int P, int Erow,
-                                                        int offset, int count, float* __restrict__ out,
-                                                        int accumulate) {
-  __shared__ double sh[256];
+// out[e] (+)= sum_p partials[p*Erow + offset + e],  e < count.  block = 64 elements x 16 partial-slices.
+__global__ __launch_bounds__(1024) void k_reduce_to_f32(const float* __restrict__ partials, int P, int Erow,
+                                                         int offset, int count, float* __restrict__ out,
+                                                         int accumulate) {
+  __shared__ double sh[1024];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
-  double s = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (e < count) {
-    double s0 = 0.0, s1 = 0.0;
+    const float* base = partials + offset + e;
     int p = slice;
-    for (; p + 4 < P; p += 8) {
-      s0 += (double)partials[(size_t)p * Erow + offset + e];
-      s1 += (double)partials[(size_t)(p + 4) * Erow + offset + e];
+    for (; p + 48 < P; p += 64) {
+      s0 += (double)base[(size_t)p * Erow];
+      s1 += (double)base[(size_t)(p + 16) * Erow];
+      s2 += (double)base[(size_t)(p + 32) * Erow];
+      s3 += (double)base[(size_t)(p + 48) * Erow];
     }
-    for (; p < P; p += 4) s0 += (double)partials[(size_t)p * Erow + offset + e];
-    s = s0 + s1;
+    for (; p < P; p += 16) s0 += (double)base[(size_t)p * Erow];
   }
-  sh[threadIdx.x] = s;
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (slice == 0 && e < count) {
-    const double t = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
     out[e] = accumulate ? out[e] + (float)t : (float)t;
   }
 }
@@ -735,7 +750,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
 #undef LAUNCH_R_O
 #undef LAUNCH_R
     if ((rc = check_launch("bwd_reduce"))) return rc;
-    hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(256), 0, st, w.partials, grid, E, w.red);
+    hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, grid, E, w.red);
     if ((rc = check_launch("bwd_reduce_partials"))) return rc;
   }
   // 2. fold
@@ -787,9 +802,9 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB);
     if ((rc = check_launch("bwd_gcn_params"))) return rc;
-    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(256), 0, st, w.partials, grid, E, 0,
+    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, w.partials, grid, E, 0,
                        T * V * V, dA, accumulate);
-    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(256), 0, st, w.partials, grid, E,
+    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(1024), 0, st, w.partials, grid, E,
                        T * V * V, V * T * T, dT, accumulate);
     if ((rc = check_launch("bwd_gcn_reduce"))) return rc;
   }
@@ -812,8 +827,8 @@ static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* A
   auto k = k_bwd_gcn_params<T, V>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB);
-  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(256), 0, st, partials, grid, E, 0, T * V * V, dA, accumulate);
-  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(256), 0, st, partials, grid, E, T * V * V, V * T * T, dT, accumulate);
+  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, partials, grid, E, 0, T * V * V, dA, accumulate);
+  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(1024), 0, st, partials, grid, E, T * V * V, V * T * T, dT, accumulate);
   return check_launch("gcn_bwd_params");
 }
 }  // namespace coskad

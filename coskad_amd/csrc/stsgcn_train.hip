@@ -67,19 +67,32 @@ __global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict_
   store_sums<NTC>(sz, scratch, dst + 2 * Ci * Ci + Ci, Ci);
 }
 
-// out[e] = sum_p partials[p][e] in fp64.  block = 64 elements x 4 partial-slices.
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials, int P, int E,
-                                                          double* __restrict__ out) {
-  __shared__ double sh[256];
+// out[e] = sum_p partials[p][e] in fp64 (fixed order).  block = 64 elements x 16 partial-slices, 4 loads in
+// flight per thread: the table is tiny (<= 512 x E floats) and the kernel is latency-bound.
+__global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int P, int E,
+                                                           double* __restrict__ out) {
+  __shared__ double sh[1024];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
-  double s = 0.0;
-  if (e < E)
-    for (int p = slice; p < P; p += 4) s += (double)partials[(size_t)p * E + e];
-  sh[threadIdx.x] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < E) {
+    int p = slice;
+    for (; p + 48 < P; p += 64) {
+      s0 += (double)partials[(size_t)p * E + e];
+      s1 += (double)partials[(size_t)(p + 16) * E + e];
+      s2 += (double)partials[(size_t)(p + 32) * E + e];
+      s3 += (double)partials[(size_t)(p + 48) * E + e];
+    }
+    for (; p < P; p += 16) s0 += (double)partials[(size_t)p * E + e];
+  }
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (slice == 0 && e < E)
-    out[e] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+  if (slice == 0 && e < E) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+    out[e] = t;
+  }
 }
 
 // stat block (floats), saved for the backward pass:
@@ -247,7 +260,7 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
 #undef LAUNCH_M
   int rc = check_launch("fwd_moments");
   if (rc) return rc;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(256), 0, st, partials, grid, E, red);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, grid, E, red);
   rc = check_launch("reduce_partials");
   if (rc) return rc;
   const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + 4 * (size_t)Co * Ci * sizeof(float);
