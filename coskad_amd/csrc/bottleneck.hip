@@ -14,7 +14,8 @@
 
 namespace coskad {
 
-constexpr int kBtlWaves = kBlock / 64;
+constexpr int kBtlBlock = 256;
+constexpr int kBtlWaves = kBtlBlock / 64;
 constexpr int kBtlFwdWaves = 8;   // forward: 8 waves split K (more loads in flight per CU)
 
 __global__ __launch_bounds__(64 * kBtlFwdWaves) void k_btlnk_fwd(const float* __restrict__ U,
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(64 * kBtlFwdWaves) void k_btlnk_fwd(const float* __
 }
 
 // grid = (ceil(K/256), S clip-chunks).  dWp: [S][L][K] partials, dap: [gridDim.x*gridDim.y].
-__global__ __launch_bounds__(kBlock) void k_btlnk_bwd(const float* __restrict__ U,
+__global__ __launch_bounds__(kBtlBlock) void k_btlnk_bwd(const float* __restrict__ U,
                                                      const float* __restrict__ W,
                                                      const float* __restrict__ dz,
                                                      const float* __restrict__ slope,
@@ -227,7 +228,7 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
   const int gx = ceil_div(K, 256);
   float* dWp = reinterpret_cast<float*>(ws);
   float* dap = dWp + (size_t)S * L * K;
-  hipLaunchKernelGGL(k_btlnk_bwd, dim3(gx, S), dim3(kBlock), 0, stream, U, W, dz, slope, dU, dWp, dap, B, K, L, chunk);
+  hipLaunchKernelGGL(k_btlnk_bwd, dim3(gx, S), dim3(kBtlBlock), 0, stream, U, W, dz, slope, dU, dWp, dap, B, K, L, chunk);
   int rc = check_launch("btlnk_bwd");
   if (rc) return rc;
   const size_t E = (size_t)L * K;

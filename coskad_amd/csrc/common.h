@@ -21,7 +21,11 @@ char* err_buf();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
-constexpr int kBlock = 256;          // every tile kernel runs 4 waves of 64
+#ifndef COSKAD_BLOCK
+#define COSKAD_BLOCK 512
+#endif
+constexpr int kBlock = COSKAD_BLOCK;   // threads per block of every tile kernel
+constexpr int kScratchFloats = (kBlock / 64) * 256;
 constexpr int kMaxLdsBytes = 160 * 1024;
 constexpr float kBnEps = 1e-5f;      // nn.BatchNorm2d default (reference stsgcn.py:65,76)
 

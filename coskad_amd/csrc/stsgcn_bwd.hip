@@ -96,8 +96,8 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldx = lds;                         // X / Z image: NB*Ci rows x LD
   float* ldu = lds + NB * Ci * LD;          // dU slab: NB*Co rows x LDC
-  float* scratch = ldu + NB * Co * LDC;     // 1024
-  float* AwL = scratch + 1024;
+  float* scratch = ldu + NB * Co * LDC;     // kScratchFloats
+  float* AwL = scratch + kScratchFloats;
   float* TwL = AwL + T * V * V;
   copy_to_lds(AwL, Aw, T * V * V);
   copy_to_lds(TwL, Tw, V * T * T);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
         }
       };
       conv_mfma_s<T, V, OTI>(img, KZ, Ci, gdu + (size_t)n * Co * TV, K1, Co, nullptr, 0, 1, false, 0.f, WlA, CiP, 0,
-                             (wave + n) & 3, kBlock / 64, epiA);
+                             (wave + n) % (kBlock / 64), kBlock / 64, epiA);
     }
     __syncthreads();
     if (dZout) unstage_rows<T, V>(dZout + (size_t)clip0 * Ci * TV, lds, rows * TV);
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
           }
         };
         conv_mfma_s<T, V, OTI>(nullptr, 0, 1, gdu + (size_t)n * Co * TV, K1, Co, ug, KZ, Ci, pre, a_in, WlB, CiP, 0,
-                               (wave + n) & 3, kBlock / 64, epiB);
+                               (wave + n) % (kBlock / 64), kBlock / 64, epiB);
       }
     }
   }  // tile loop
@@ -388,7 +388,11 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
     da = wave_sum(da);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = da;
     __syncthreads();
-    if (threadIdx.x == 0) da_partials[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < kBlock / 64; ++w) t += sred[w];
+      da_partials[blockIdx.x] = t;
+    }
   }
 }
 
@@ -719,7 +723,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     int NB = Ci >= 32 ? 1 : 32 / Ci;
     if (NB > B) NB = B;
     auto red_lds = [&](int nb_) {
-      return ((size_t)nb_ * Ci * LD + (size_t)nb_ * Co * RedGeo<T, V>::LDC + 1024 + (size_t)T * V * V +
+      return ((size_t)nb_ * Ci * LD + (size_t)nb_ * Co * RedGeo<T, V>::LDC + kScratchFloats + (size_t)T * V * V +
               (size_t)V * T * T) * sizeof(float);
     };
     while (NB > 1 && red_lds(NB) > 76 * 1024) --NB;   // keep two blocks per CU

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
       const int NOG = (CoP / 16 + OTI - 1) / OTI;
       for (int g = 0; g < NOG; ++g)
         conv_mfma_s<T, V, OTI>(img + n * Ci * LD, (dbg & 32) ? 0 : KZ, Ci, nullptr, 0, 1, gin + (size_t)n * Ci * TV,
-                               (dbg & 16) ? 0 : KZ, Ci, pre, a_in, Wl, CoP, g, (wave + n + g) & 3, kBlock / 64, epi);
+                               (dbg & 16) ? 0 : KZ, Ci, pre, a_in, Wl, CoP, g, (wave + n + g) % (kBlock / 64), kBlock / 64, epi);
     }
   }
 }

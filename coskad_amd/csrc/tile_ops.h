@@ -214,7 +214,7 @@ __device__ __forceinline__ void outer_accum(const float* ldsA, int va, const flo
 
 // Cross-wave reduction of MFMA accumulators and store of this block's partial.
 //   dst[(16*ta + row) * ldd + 16*tb + col]  (only row < va, col < vb are written)
-// scratch: LDS, >= 4 waves * 256 floats.  Contains barriers; all threads must call.
+// scratch: LDS, >= kScratchFloats.  Contains barriers; all threads must call.
 template <int NTA, int NTB>
 __device__ __forceinline__ void store_outer(const f32x4 (&acc)[NTA][NTB], float* scratch, float* dst,
                                             int ldd, int va, int vb) {
@@ -227,10 +227,14 @@ __device__ __forceinline__ void store_outer(const f32x4 (&acc)[NTA][NTB], float*
 #pragma unroll
       for (int r = 0; r < 4; ++r) scratch[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[ta][tb][r];
       __syncthreads();
-      const int e = threadIdx.x;  // 256 threads <-> 16x16 tile elements
-      const int row = e >> 4, col = e & 15;
-      const float s = (scratch[e] + scratch[256 + e]) + (scratch[512 + e] + scratch[768 + e]);
-      if (16 * ta + row < va && 16 * tb + col < vb) dst[(16 * ta + row) * ldd + 16 * tb + col] = s;
+      const int e = threadIdx.x;  // first 256 threads <-> 16x16 tile elements
+      if (e < 256) {
+        const int row = e >> 4, col = e & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += scratch[w * 256 + e];
+        if (16 * ta + row < va && 16 * tb + col < vb) dst[(16 * ta + row) * ldd + 16 * tb + col] = s;
+      }
     }
 }
 
@@ -247,8 +251,12 @@ __device__ __forceinline__ void store_sums(const f32x4 (&sacc)[NTA], float* scra
     }
     __syncthreads();
     const int e = threadIdx.x;
-    if (e < 16 && 16 * ta + e < va)
-      dst[16 * ta + e] = (scratch[e] + scratch[16 + e]) + (scratch[32 + e] + scratch[48 + e]);
+    if (e < 16 && 16 * ta + e < va) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) s += scratch[w * 16 + e];
+      dst[16 * ta + e] = s;
+    }
   }
 }
 
