@@ -17,6 +17,10 @@
 #pragma once
 #include "tile_ops.h"
 
+#ifndef COSKAD_RP
+#define COSKAD_RP 1
+#endif
+
 namespace coskad {
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -34,7 +38,7 @@ template <int T, int V, bool ADJ>
 __device__ __forceinline__ void temporal_mfma(float* img, int rows, const float* TwL) {
   constexpr int LD = Geo<T, V>::LD;
   constexpr int KS = (T + 3) / 4;
-  constexpr int RP = 2;   // row tiles per item: they share the B operand and give independent MFMA chains
+  constexpr int RP = COSKAD_RP;   // row tiles per item: they share the B operand and give independent MFMA chains
   static_assert(T <= 16, "temporal_mfma: one 16-wide column tile");
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int i = lane & 15, k = lane >> 4;
@@ -82,7 +86,7 @@ template <int T, int V, bool ADJ>
 __device__ __forceinline__ void spatial_mfma(float* img, int rows, const float* AwL) {
   constexpr int LD = Geo<T, V>::LD;
   constexpr int KS = (V + 3) / 4;
-  constexpr int RP = 2;   // row tiles per item (share B, independent chains)
+  constexpr int RP = COSKAD_RP;   // row tiles per item (share B, independent chains)
   // column tiles on MFMA; up to 2 leftover columns (V = 17, 18) are cheaper on the VALU
   constexpr int VX = (V > 16 && V - 16 <= 2) ? V - 16 : ((V > 32 && V - 32 <= 2) ? V - 32 : 0);
   constexpr int NT = (V - VX + 15) / 16;
