@@ -1,0 +1,258 @@
+"""Lightning-style wrapper of the one-class STSE training (mirror of the reference's
+models/euclidean_encoder_staticCenter.py, models/euclidean_encoder_dynamicCenter.py and
+models/hyperbolic_encoder.py `LitEncoder`, which cannot be imported from the snapshot -- SURVEY fact 1 --
+and a minimal `Trainer` replacing pytorch_lightning, which is not installed).
+
+Same hooks and config keys (flat yaml -> argparse.Namespace): `forward(x: list[4])`, `setup(stage)`,
+`training_step`, `on_train_epoch_end`, `validation_step`, `validation_epoch_end`, `configure_optimizers`,
+`post_processing`.  Differences, all deliberate:
+  * the optimisation step is the fused HIP sequence of coskad_amd.trainer.STSETrainStep (forward, loss,
+    backward, L2 reg, Adam in one call), so `training_step` has already stepped when it returns the loss;
+  * centre statistics are device-side running sums (and all-reduced over ranks) instead of python lists /
+    torch.cat of every latent (hyperbolic_encoder.py:148-153);
+  * post_processing is the vectorised scoring of coskad_amd.utils.eval_utils.
+Parity of these wrappers against the reference is unpinned (no importable reference, no recorded numbers).
+"""
+from __future__ import annotations
+
+import os
+from argparse import Namespace
+from typing import Callable, Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, parallel
+from .models.sts.ae import STSE
+from .trainer import STSETrainStep
+from .utils import eval_utils
+
+
+def _joints(args) -> int:
+    if getattr(args, "dataset_headless", False):
+        return 14
+    if getattr(args, "dataset_kp18_format", False):
+        return 18
+    return 17
+
+
+class LitEncoder(nn.Module):
+    def __init__(self, args: Namespace, hyperbolic: Optional[bool] = None) -> None:
+        super().__init__()
+        self.args = args
+        self.hparams = Namespace(args=args)                  # save_hyperparameters()
+        self.hyperbolic = bool(getattr(args, "hyperbolic", False) if hyperbolic is None else hyperbolic)
+        self.static_center = bool(getattr(args, "static_center", False))
+        channels = list(getattr(args, "channels", [32, 16, 32]))
+        self.eps = float(getattr(args, "center_tolerance", 1e-3))
+        self.model = STSE(c_in=args.num_coords, h_dim=args.h_dim, latent_dim=args.latent_dim,
+                          n_frames=args.dataset_seg_len, dropout=args.dropout, n_joints=_joints(args),
+                          channels=channels, projector=getattr(args, "projector", "linear"),
+                          encoder_type=getattr(args, "encoder_type", "STS_GCN"))
+        self.learning_rate = args.opt_lr
+        self.batch_size = getattr(args, "dataset_batch_size", 2048)
+        self.logged: Dict[str, float] = {}
+        self._engine: Optional[STSETrainStep] = None
+        self._epoch = 0
+        self._temp = None
+        self.gts: Optional[Dict[Tuple[int, int], np.ndarray]] = None   # frame masks; else read from args.gt_path
+
+    # ---- inference ---------------------------------------------------------------------
+    def forward(self, x):
+        tensor_data, transformation_idx, metadata, actual_frames = x[0], x[1], x[2], x[3]
+        hidden_out = self.model(tensor_data)
+        return hidden_out, transformation_idx, metadata, actual_frames
+
+    def log(self, name: str, value) -> None:
+        self.logged[name] = float(value)
+
+    # ---- centre initialisation (staticCenter.py:95-130, dynamicCenter.py:76-102, hyperbolic_encoder.py:85-135)
+    def setup(self, stage: str = None, train_loader: Optional[Callable[[], Iterable]] = None) -> None:
+        if stage != "fit":
+            return
+        dev = next(self.model.parameters()).device
+        acc = torch.zeros(ops.HEAD_SLOTS, device=dev)
+        self.model.eval()
+        with torch.no_grad():
+            for batch in train_loader():
+                z = self.model(batch[0].to(dev))
+                if self.hyperbolic:
+                    ops.poincare_head(z, None, need_grad=False, acc=acc)
+                else:
+                    ops.mse_head(z, self.model.c, need_grad=False, acc=acc)
+        parallel.allreduce_sum_(acc)
+        L = self.model.latent_dim
+        self.n_samples = float(acc[17]) if not self.hyperbolic else None
+        if self.hyperbolic:
+            c = ops.midpoint_finalize(acc, L)
+            assert bool((c < 1).all()), f"center is out of the ball\nc = {c}"        # hyperbolic_encoder.py:123
+            self.model.c.copy_(c)
+        elif self.static_center:
+            self.model.c.copy_(ops.center_finalize(acc, self.eps, L))                 # staticCenter.py:118-123
+        else:
+            # dynamicCenter.py:96-100: the initial centre is stored but model.c stays 0 during the first epoch
+            self._temp = ops.center_finalize(acc, 0.0, L)
+        self.model.train()
+        self._engine = STSETrainStep(self.model, lr=self.learning_rate, alpha=float(getattr(self.args, "alpha", 0.0)),
+                                     head="poincare" if self.hyperbolic else "euclidean")
+        self._epoch = 0
+
+    # ---- one optimisation step -----------------------------------------------------------
+    def training_step(self, batch, batch_idx: int) -> torch.Tensor:
+        dev = self._engine.fp.flat.device
+        stats = self._engine.step(batch[0].to(dev, non_blocking=True))
+        if batch_idx % 20 == 0:                           # log_every_n_steps=20 (train_COSKAD.py:76)
+            reg = self._engine.reg_loss()
+            name = "poincare_loss" if self.hyperbolic else "hypersphere_loss"
+            self.log(name, stats[0]); self.log("regularization", reg)
+            self.log("loss", float(stats[0]) + self._engine.alpha * float(reg))
+        return stats[0]
+
+    def on_train_epoch_end(self) -> None:
+        eng = self._engine
+        if self.hyperbolic:
+            if not self.static_center:                     # hyperbolic_encoder.py:175-183
+                c = eng.refresh_center()
+                self.log("center/eucl", torch.linalg.norm(c))
+            else:
+                eng.center_acc.zero_()
+        elif self.static_center:
+            eng.center_acc.zero_()
+        else:                                              # dynamicCenter.py:125-142
+            if self._epoch == 0:
+                parallel.allreduce_sum_(eng.center_acc)
+                self.model.c.copy_(self._temp)
+                eng.center_acc.zero_()
+            else:
+                eng.refresh_center(eps=self.eps)
+        self._epoch += 1
+
+    training_epoch_end = on_train_epoch_end
+
+    def configure_optimizers(self) -> Dict:
+        """Adam(lr=opt_lr) (+ ReduceLROnPlateau(mode='max', factor=0.2, min_lr=1e-6) on validation_auc when
+        args.validation); the HIP engine owns the Adam state, the Trainer applies the plateau rule."""
+        return {"optimizer": "adam", "lr": self.learning_rate,
+                "lr_scheduler": {"name": "ReduceLROnPlateau", "mode": "max", "factor": 0.2,
+                                 "patience": 2 if not self.static_center and not self.hyperbolic else 100,
+                                 "min_lr": 1e-6},
+                "monitor": "validation_auc"}
+
+    # ---- validation / scoring --------------------------------------------------------------
+    def validation_step(self, batch, batch_idx: int = 0):
+        dev = next(self.model.parameters()).device
+        with torch.no_grad():
+            return self.forward([batch[0].to(dev), batch[1], batch[2], batch[3]])
+
+    predict_step = validation_step
+
+    def validation_epoch_end(self, outputs: List) -> float:
+        hidden = torch.cat([o[0] for o in outputs], 0)
+        trans = torch.cat([o[1] for o in outputs], 0)
+        meta = torch.cat([o[2] for o in outputs], 0)
+        frames = torch.cat([o[3] for o in outputs], 0)
+        return self.post_processing(hidden, trans, meta, frames)
+
+    def window_scores(self, hidden: torch.Tensor) -> torch.Tensor:
+        """per-window anomaly score on the device (eval_utils.py:63-67)."""
+        if self.hyperbolic:
+            _, _, _, score = ops.poincare_head(hidden.contiguous(), self.model.c, need_grad=False, need_score=True)
+        else:
+            _, _, score = ops.mse_head(hidden.contiguous(), self.model.c, need_grad=False, need_score=True)
+        return score
+
+    def _load_gts(self) -> Dict[Tuple[int, int], np.ndarray]:
+        if self.gts is not None:
+            return self.gts
+        out = {}
+        for fn in sorted(os.listdir(self.args.gt_path)):
+            if fn.endswith(".npy"):
+                sc, cl = int(fn.split("_")[0]), int(fn.split("_")[1].split(".")[0])
+                out[(sc, cl)] = np.load(os.path.join(self.args.gt_path, fn))
+        return out
+
+    def post_processing(self, hidden_out, trans, meta, frames) -> float:
+        num_transform = max(1, int(getattr(self.args, "dataset_num_transform", 1)))
+        scores = self.window_scores(hidden_out)
+        auc, per_t, gt = eval_utils.score_dataset(scores, trans, meta, frames, self._load_gts(), num_transform,
+                                                  smoothing=int(getattr(self.args, "smoothing", 50)),
+                                                  dataname=getattr(self.args, "dataset_choice", "UBnormal"))
+        self.log("validation_auc", auc)
+        self.last_scores = per_t
+        return auc
+
+
+class Trainer:
+    """The few pytorch_lightning.Trainer behaviours the reference relies on (train_COSKAD.py:70-85,
+    eval_COSKAD.py:110-116): fit with per-epoch validation, top-k checkpoints on the monitored value,
+    ReduceLROnPlateau, predict from a checkpoint.  Loaders are zero-argument callables returning an iterable of
+    [x, trans, meta, frames] batches (each rank builds its own shard)."""
+
+    def __init__(self, max_epochs: int = 1, ckpt_dir: Optional[str] = None, save_top_k: int = 2,
+                 monitor: str = "validation_auc") -> None:
+        self.max_epochs, self.ckpt_dir, self.save_top_k, self.monitor = max_epochs, ckpt_dir, save_top_k, monitor
+        self.history: List[Dict[str, float]] = []
+        self._best: List[Tuple[float, str]] = []
+
+    def fit(self, model: LitEncoder, train_loader, val_loader=None) -> None:
+        model.setup("fit", train_loader)
+        sched = model.configure_optimizers()["lr_scheduler"]
+        best, bad, lr = -float("inf"), 0, model.learning_rate
+        for epoch in range(self.max_epochs):
+            model.model.train()
+            for i, batch in enumerate(train_loader()):
+                model.training_step(batch, i)
+            model.on_train_epoch_end()
+            rec = dict(model.logged, epoch=epoch)
+            if val_loader is not None:
+                auc = self.validate(model, val_loader)
+                rec["validation_auc"] = auc
+                if auc > best:
+                    best, bad = auc, 0
+                else:
+                    bad += 1
+                    if bad > sched["patience"]:
+                        lr = max(lr * sched["factor"], sched["min_lr"])
+                        model._engine.set_lr(lr)
+                        bad = 0
+                self._checkpoint(model, epoch, auc)
+            self.history.append(rec)
+
+    def validate(self, model: LitEncoder, loader) -> float:
+        model.model.eval()
+        outs = [model.validation_step(b, i) for i, b in enumerate(loader())]
+        outs = [(parallel.gather_rows(o[0]), parallel.gather_rows(o[1].to(o[0].device)),
+                 parallel.gather_rows(o[2].to(o[0].device)), parallel.gather_rows(o[3].to(o[0].device))) for o in outs]
+        return model.validation_epoch_end(outs)
+
+    def predict(self, model: LitEncoder, loader, ckpt_path: Optional[str] = None):
+        if ckpt_path:
+            load_checkpoint(model, ckpt_path)
+        model.model.eval()
+        return [model.predict_step(b, i) for i, b in enumerate(loader())]
+
+    def _checkpoint(self, model: LitEncoder, epoch: int, value: float) -> None:
+        if not self.ckpt_dir or parallel.rank() != 0:
+            return
+        os.makedirs(self.ckpt_dir, exist_ok=True)
+        path = os.path.join(self.ckpt_dir, f"epoch={epoch}-{self.monitor}={value:.4f}.ckpt")
+        save_checkpoint(model, path, epoch)
+        self._best.append((value, path))
+        self._best.sort(key=lambda t: -t[0])
+        for _, p in self._best[self.save_top_k:]:
+            if os.path.exists(p):
+                os.remove(p)
+        self._best = self._best[:self.save_top_k]
+
+
+def save_checkpoint(model: LitEncoder, path: str, epoch: int = 0) -> None:
+    """Lightning layout: state_dict keys prefixed `model.`, hyper_parameters = the args Namespace."""
+    sd = {"model." + k: v.detach().cpu().clone() for k, v in model.model.state_dict().items()}
+    torch.save({"state_dict": sd, "hyper_parameters": {"args": vars(model.args)}, "epoch": epoch}, path)
+
+
+def load_checkpoint(model: LitEncoder, path: str) -> None:
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")}
+    model.model.load_state_dict(sd, strict=True)

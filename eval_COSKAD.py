@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""eval_COSKAD.py -- reference CLI (eval_COSKAD.py:46-253): load <exp_dir>/<dataset>/<dir_name>/<load_ckpt>,
+predict latents on the test split, score windows -> frames -> clips, print the AUC."""
+import argparse
+import os
+
+import torch
+import yaml
+
+from coskad_amd.lit import LitEncoder, Trainer
+from coskad_amd.utils.argparser import init_sub_args
+from coskad_amd.utils.synthetic import batches, make_dataset
+
+
+def main():
+    parser = argparse.ArgumentParser(description='Pose_AD_Experiment')
+    parser.add_argument('-c', '--config', type=str, required=True)
+    args = argparse.Namespace(**yaml.load(open(parser.parse_args().config), Loader=yaml.FullLoader))
+    args, dataset_args, ae_args, res_args, opt_args = init_sub_args(args)
+    torch.cuda.set_device(0)
+    model = LitEncoder(args).cuda()
+    path = os.path.join(args.exp_dir, args.dataset_choice, args.dir_name, args.load_ckpt)
+    print('Loading model from {}'.format(path))
+    if args.data_dir != 'synthetic':
+        raise NotImplementedError("only `data_dir: synthetic` is wired (SURVEY 8f rank 2)")
+    test, gts = make_dataset(n_scenes=2, n_clips=3, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
+                             anomaly=True, seed=args.seed + 1)
+    model.gts = gts
+    trainer = Trainer()
+    out = trainer.predict(model, lambda: batches(test, args.dataset_batch_size), ckpt_path=path)
+    auc = model.validation_epoch_end(out)
+    print('final AUC score: {}'.format(auc))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,78 @@
+"""End to end on the GPU: LitEncoder + Trainer on synthetic windows -> per-frame anomaly scores and AUC,
+against the CPU oracle evaluating the SAME trained weights (north_star: scores within 1e-4, AUC within 0.1)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from oracle import ref_scoring as RS
+
+pytestmark = pytest.mark.gpu
+
+
+def make_args(**kw):
+    a = dict(num_coords=2, h_dim=16, latent_dim=8, dataset_seg_len=12, dropout=0, channels=[16, 8, 16],
+             projector="linear", encoder_type="STS_GCN", hyperbolic=False, static_center=False,
+             center_tolerance=1e-3, opt_lr=2e-3, alpha=1e-6, dataset_batch_size=256, dataset_num_transform=2,
+             dataset_headless=False, dataset_kp18_format=False, smoothing=50, dataset_choice="UBnormal", validation=True)
+    a.update(kw)
+    return Namespace(**a)
+
+
+@pytest.mark.parametrize("mode", ["euclid_dynamic", "euclid_static", "hyperbolic"])
+def test_train_score_auc_parity(mode, tmp_path):
+    from coskad_amd.lit import LitEncoder, Trainer, load_checkpoint
+    from coskad_amd.utils.synthetic import batches, make_dataset
+    torch.manual_seed(0)
+    train, _ = make_dataset(n_scenes=2, n_clips=3, n_persons=2, clip_len=100, num_transform=2, anomaly=False, seed=1)
+    test, gts = make_dataset(n_scenes=1, n_clips=3, n_persons=2, clip_len=100, num_transform=2, anomaly=True, seed=2)
+    args = make_args(hyperbolic=(mode == "hyperbolic"), static_center=(mode == "euclid_static"))
+    lit = LitEncoder(args).cuda()
+    lit.gts = gts
+    tr = Trainer(max_epochs=3, ckpt_dir=str(tmp_path))
+    tr.fit(lit, lambda: batches(train, 256, shuffle=True, seed=0), lambda: batches(test, 512))
+    auc = tr.history[-1]["validation_auc"]
+    assert 0.0 <= auc <= 1.0 and len(tr.history) == 3
+    # ---- oracle on the same weights / centre
+    st = {k: v.detach().cpu().clone() for k, v in lit.model.state_dict().items()}
+    x, trans, meta, frames = test
+    with torch.no_grad():
+        z = R.stse_encode(x, st, training=False)
+        if mode == "hyperbolic":
+            s_ref = R.dist(st["c"][None], R.project(R.expmap0(z)))
+        else:
+            s_ref = R.euclid_window_score(z, st["c"])
+    auc_ref, per_t_ref, _ = RS.score_dataset(s_ref.double().numpy(), trans.numpy(), meta.numpy(), frames.numpy(), gts, 2)
+    # HIP window scores vs oracle
+    lit.model.eval()
+    with torch.no_grad():
+        z_hip = lit.model(x.cuda())
+        s_hip = lit.window_scores(z_hip).cpu()
+    np.testing.assert_allclose(z_hip.cpu().numpy(), z.numpy(), rtol=1e-4, atol=1e-4)           # latents: 1e-4
+    if mode == "hyperbolic":
+        # the Poincare distance amplifies latent rounding by ~1/(1-|zh|^2) near the ball boundary: check the head
+        # on the HIP latents tightly, and the full chain at the amplified tolerance
+        # (fp32 conditioning of the reference formula itself: a centre close to the boundary makes the Moebius
+        # addition lose digits).  The HIP head must be as close to the fp64 truth as the fp32 oracle is.
+        zc = z_hip.cpu()
+        s64 = R.dist(st["c"][None].double(), R.project(R.expmap0(zc.double())))
+        s32 = R.dist(st["c"][None], R.project(R.expmap0(zc)))
+        err_oracle = float(((s32.double() - s64) / s64).abs().max())
+        err_hip = float(((s_hip.double() - s64) / s64).abs().max())
+        assert err_hip <= 2 * err_oracle + 1e-4, (err_hip, err_oracle)
+        tol = dict(rtol=1e-2, atol=1e-2)
+    else:
+        tol = dict(rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(s_hip.numpy(), s_ref.numpy(), **tol)
+    for t in per_t_ref:
+        np.testing.assert_allclose(lit.last_scores[t], per_t_ref[t], **tol)                    # per-frame scores
+    assert abs(auc - auc_ref) < 1e-2                                                            # north_star: +-0.1
+    # checkpoint round trip in the Lightning layout
+    import glob
+    ck = sorted(glob.glob(str(tmp_path / "*.ckpt")))
+    assert 1 <= len(ck) <= 2
+    lit2 = LitEncoder(args).cuda()
+    load_checkpoint(lit2, ck[-1])
+    assert all(k.startswith("model.") for k in torch.load(ck[-1], weights_only=False)["state_dict"])

@@ -88,3 +88,21 @@ def test_bench_byte_model():
     fwd, bwd = bench.algorithmic_bytes_per_clip()
     assert fwd == 236704
     assert abs(bwd - 354208) <= 64  # SURVEY 8d (+ the dz read)
+
+
+def test_config_contract():
+    """flat yaml -> Namespace -> init_sub_args (reference utils/argparser.py:10-45)."""
+    import argparse
+    import yaml
+    from coskad_amd.utils.argparser import init_sub_args
+    raw = yaml.safe_load(open("config/synthetic/euclidean_encoder.yaml"))
+    raw["create_experiment_dir"] = False
+    raw["data_dir"] = "/data/UBnormal"
+    args, data_args, ae_args, res_args, opt_args = init_sub_args(argparse.Namespace(**raw))
+    assert args.ckpt_dir == "./checkpoints/UBnormal/STSE_euclidean_dynamic_synthetic"
+    assert args.gt_path == "/data/UBnormal/validating/test_frame_mask"          # UBnormal + validation
+    assert data_args.seg_len == 12 and data_args.batch_size == 2048 and ae_args.epochs == 3 and opt_args.lr == 1e-4
+    # the wrapper builds the encoder the yaml describes
+    from coskad_amd.lit import LitEncoder
+    lit = LitEncoder(args)
+    assert lit.model.n_joints == 17 and lit.model.latent_dim == 16 and not lit.hyperbolic

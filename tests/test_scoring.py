@@ -27,7 +27,7 @@ def test_score_process_matches_reference_formula():
 
 
 def test_ragged_persons_and_missing_clip():
-    (x, trans, meta, frames), gts = make_dataset(n_scenes=1, n_clips=2, n_persons=2, clip_len=60, seed=5)
+    (x, trans, meta, frames), gts = make_dataset(n_scenes=1, n_clips=2, n_persons=2, clip_len=80, seed=5)
     keep = ~((meta[:, 1] == 2) & (meta[:, 2] == 1))  # clip 2 keeps a single person
     keep &= ~((meta[:, 1] == 1) & (meta[:, 3] > 30))  # clip 1: no window covers the late frames
     x, trans, meta, frames = x[keep], trans[keep], meta[keep], frames[keep]

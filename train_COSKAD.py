@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""train_COSKAD.py -- same CLI / yaml contract as the reference (train_COSKAD.py:15-85) on the MI355X path.
+
+  python train_COSKAD.py --config config/synthetic/euclidean_encoder.yaml
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_COSKAD.py --config ...
+
+`data_dir: synthetic` uses coskad_amd.utils.synthetic (no datasets are reachable from this environment); the
+Morais-CSV data pipeline of the reference (utils/dataset.py) is the next scope row."""
+import argparse
+import os
+import shutil
+
+import torch
+import torch.distributed as dist
+import yaml
+
+from coskad_amd.lit import LitEncoder, Trainer
+from coskad_amd.utils.argparser import init_sub_args
+from coskad_amd.utils.synthetic import batches, make_dataset
+
+
+def main():
+    parser = argparse.ArgumentParser(description='Pose_AD_Experiment')
+    parser.add_argument('-c', '--config', type=str, required=True)
+    config_path = parser.parse_args().config
+    args = argparse.Namespace(**yaml.load(open(config_path), Loader=yaml.FullLoader))
+    args, dataset_args, ae_args, res_args, opt_args = init_sub_args(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        dist.init_process_group("nccl")
+    if rank == 0:
+        os.makedirs(args.ckpt_dir, exist_ok=True)
+        shutil.copy(config_path, os.path.join(args.ckpt_dir, "config.yaml"))      # train_COSKAD.py:33
+    if args.use_decoder or args.use_vae:
+        raise NotImplementedError("autoencoder / VAE wrappers are outside this round's scope (SURVEY 8f)")
+    model = LitEncoder(args).cuda()                  # hyperbolic / static_center switches: train_COSKAD.py:36-55
+    if args.data_dir != 'synthetic':
+        raise NotImplementedError("only `data_dir: synthetic` is wired; the reference's CSV pipeline is SURVEY 8f rank 2")
+    train, _ = make_dataset(n_scenes=4, n_clips=4, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
+                            anomaly=False, seed=args.seed)
+    val, gts = make_dataset(n_scenes=2, n_clips=3, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
+                            anomaly=True, seed=args.seed + 1)
+    model.gts = gts
+    bs = args.dataset_batch_size
+    trainer = Trainer(max_epochs=args.ae_epochs, ckpt_dir=args.ckpt_dir, save_top_k=2)
+    trainer.fit(model, lambda: batches(train, bs, shuffle=True, seed=args.seed, rank=rank, world=world),
+                (lambda: batches(val, bs, rank=rank, world=world)) if args.validation else None)
+    if rank == 0:
+        for rec in trainer.history:
+            print(rec)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
