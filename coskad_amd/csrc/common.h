@@ -26,6 +26,10 @@ int check_launch(const char* what);
 #endif
 constexpr int kBlock = COSKAD_BLOCK;   // threads per block of every tile kernel
 constexpr int kScratchFloats = (kBlock / 64) * 256;
+#ifndef COSKAD_MINWAVES
+#define COSKAD_MINWAVES 4
+#endif
+constexpr int kMinWaves = COSKAD_MINWAVES;   // waves per SIMD the big tile kernels are compiled for (4 = two 512-thread blocks per CU)
 constexpr int kMaxLdsBytes = 160 * 1024;
 constexpr float kBnEps = 1e-5f;      // nn.BatchNorm2d default (reference stsgcn.py:65,76)
 

@@ -17,6 +17,9 @@
 #pragma once
 #include "tile_ops.h"
 
+#ifndef COSKAD_XB
+#define COSKAD_XB 4
+#endif
 #ifndef COSKAD_RP
 #define COSKAD_RP 1
 #endif
@@ -398,7 +401,7 @@ __device__ __forceinline__ void conv_mfma_s(const float* zimg, int KZ, int nz, c
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   static_assert(TV % 2 == 0, "strip conv needs an even number of positions");
   constexpr int PS = (TV + 31) / 32;
-  constexpr int XB = 8;
+  constexpr int XB = COSKAD_XB;
   const int lane = threadIdx.x & 63;
   const int j = lane & 15, kk = lane >> 4;
   const int KZS = KZ / 4, KGS = (K1 + K2) / 4, K1S = K1 / 4;

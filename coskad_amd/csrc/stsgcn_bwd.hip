@@ -107,17 +107,12 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__
   zero_acc(pacc); zero_acc(qacc); zero_acc(sacc); zero_acc(sdummy);
 
   const int ntiles = ceil_div(B, NB);
-  TilePrefetch<T, V, 4> pf;
-  auto tile_ptr = [&](int tile) { return in + (size_t)min(tile, ntiles - 1) * NB * Ci * TV; };
-  auto tile_n = [&](int tile) { return tile < ntiles ? min(NB, B - tile * NB) * Ci * TV : 0; };
-  pf.fetch(tile_ptr(blockIdx.x), tile_n(blockIdx.x));
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
     const float* gdu = dU + (size_t)clip0 * Co * TV;
     __syncthreads();
-    pf.commit(tile_ptr(tile), ldx, nb * Ci * TV, pre, a_in);
-    pf.fetch(tile_ptr(tile + gridDim.x), tile_n(tile + gridDim.x));
+    stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, pre, a_in);
     if (need_q) {
       for (int ch = 0; ch < NCH; ++ch) {
         const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
@@ -335,10 +330,6 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
   const int wave = uniform(threadIdx.x >> 6);
   float da = 0.f;
   const int ntiles = ceil_div(B, NB);
-  TilePrefetch<T, V, 4> pf;
-  auto tile_ptr = [&](int tile) { return in + (size_t)min(tile, ntiles - 1) * NB * Ci * TV; };
-  auto tile_n = [&](int tile) { return tile < ntiles ? min(NB, B - tile * NB) * Ci * TV : 0; };
-  pf.fetch(tile_ptr(blockIdx.x), tile_n(blockIdx.x));
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
@@ -347,8 +338,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_data(
     const float* gdu = dU + (size_t)clip0 * Co * TV;
 
     __syncthreads();
-    pf.commit(gin, lds, rows * TV, pre, a_in);
-    pf.fetch(tile_ptr(tile + gridDim.x), tile_n(tile + gridDim.x));
+    stage_rows<T, V>(gin, lds, rows * TV, pre, a_in);
     __syncthreads();
     gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
     __syncthreads();
@@ -487,21 +477,14 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
   for (int a = 0; a < VPW; ++a) zero_acc(accT[a]);
 
   const int ntiles = ceil_div(B, NB);
-  TilePrefetch<T, V, 4> pfx, pfz;
-  auto tile_off = [&](int tile) { return (size_t)min(tile, ntiles - 1) * NB * Ci * TV; };
-  auto tile_n = [&](int tile) { return tile < ntiles ? min(NB, B - tile * NB) * Ci * TV : 0; };
-  pfx.fetch(in + tile_off(blockIdx.x), tile_n(blockIdx.x));
-  pfz.fetch(dZ + tile_off(blockIdx.x), tile_n(blockIdx.x));
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
     const int rows = nb * Ci;
     const float* gin = in + (size_t)clip0 * Ci * TV;
     __syncthreads();
-    pfx.commit(gin, img1, rows * TV, pre, a_in);
-    pfz.commit(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
-    pfx.fetch(in + tile_off(tile + gridDim.x), tile_n(tile + gridDim.x));
-    pfz.fetch(dZ + tile_off(tile + gridDim.x), tile_n(tile + gridDim.x));
+    stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
+    stage_rows<T, V>(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
     __syncthreads();
     temporal_mfma<T, V, false>(img1, rows, TwL);  // Y = temporal(X)
     __syncthreads();

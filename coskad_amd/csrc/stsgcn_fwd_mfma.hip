@@ -31,58 +31,14 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
   copy_to_lds(bl, bias, CoP);
   const int wave = uniform(threadIdx.x >> 6);
 
-  // Tile pipeline: the NEXT tile is fetched HBM -> registers while the current one is computed,
-  // and written to LDS after the conv phase has finished reading the image.
-  constexpr int PF = 8;  // float4 per thread in flight: covers tiles up to 8*256*4 floats = 32 KB
   const int ntiles = ceil_div(B, NB);
-  float4 pf[PF];
-  auto fetch = [&](int tile) {
-    const int clip0 = tile * NB;
-    const int n4 = (min(NB, B - clip0) * Ci * TV) >> 2;
-    const float4* g4 = reinterpret_cast<const float4*>(in + (size_t)clip0 * Ci * TV);
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int i = threadIdx.x + u * kBlock;
-      pf[u] = (tile < ntiles && i < n4) ? g4[i] : float4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  auto commit = [&](int tile) {
-    const int clip0 = tile * NB;
-    const int n4 = (min(NB, B - clip0) * Ci * TV) >> 2;
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int i = threadIdx.x + u * kBlock;
-      if (i < n4) {
-        float4 v = pf[u];
-        const int e = i << 2, row = e / TV, col = e - row * TV;
-        if (pre) { v.x = prelu_f(v.x, a_in); v.y = prelu_f(v.y, a_in); v.z = prelu_f(v.z, a_in); v.w = prelu_f(v.w, a_in); }
-        float* d = img + row * LD + col;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
-    }
-    // tiles larger than the register window: the rest goes the direct way
-    const int done = PF * kBlock * 4;
-    const int total = min(NB, B - clip0) * Ci * TV;
-    if (total > done) {
-      const float* g = in + (size_t)clip0 * Ci * TV;
-      for (int e = done + threadIdx.x; e < total; e += kBlock) {
-        const int row = e / TV, col = e - row * TV;
-        const float v = g[e];
-        img[row * LD + col] = pre ? prelu_f(v, a_in) : v;
-      }
-    }
-  };
-  static_assert(TV % 4 == 0, "tile prefetch uses float4");
-  if (!(dbg & 4)) fetch(blockIdx.x);
-
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
     const int rows = nb * Ci;
     const float* gin = in + (size_t)clip0 * Ci * TV;
     __syncthreads();  // tables ready / previous tile's conv reads done
-    if (!(dbg & 4)) commit(tile);
-    if (!(dbg & 4)) fetch(tile + gridDim.x);
+    if (!(dbg & 4)) stage_rows<T, V>(gin, img, rows * TV, pre, a_in);
     __syncthreads();
     if (!(dbg & 1)) gcn_mfma<T, V, false>(img, rows, AwL, TwL);
     __syncthreads();

@@ -38,17 +38,12 @@ __global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict_
   zero_acc(mx); zero_acc(mz); zero_acc(sx); zero_acc(sz);
 
   const int ntiles = ceil_div(B, NB);
-  TilePrefetch<T, V, 4> pf;
-  auto tile_ptr = [&](int tile) { return in + (size_t)min(tile, ntiles - 1) * NB * Ci * TV; };
-  auto tile_n = [&](int tile) { return tile < ntiles ? min(NB, B - tile * NB) * Ci * TV : 0; };
-  pf.fetch(tile_ptr(blockIdx.x), tile_n(blockIdx.x));
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
     const int rows = nb * Ci;
     __syncthreads();  // previous tile's MFMA reads are done
-    pf.commit(tile_ptr(tile), lds, rows * TV, pre, a_in);
-    pf.fetch(tile_ptr(tile + gridDim.x), tile_n(tile + gridDim.x));
+    stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, lds, rows * TV, pre, a_in);
     __syncthreads();
     if (need_x) {
       for (int n = 0; n < nb; ++n) {
