@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_bwd_fold(
 //    power of two (register arrays need static bounds).
 // ---------------------------------------------------------------------------------------
 template <int T, int V, int OTI>
-__global__ __launch_bounds__(kBlock) void k_bwd_data(
+__global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
     const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
     float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
