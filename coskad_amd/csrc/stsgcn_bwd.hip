@@ -177,7 +177,7 @@ __host__ __device__ inline int coef_floats(int Ci, int Co) {
 
 __device__ __forceinline__ void put(float* dst, float v, int accumulate) { *dst = accumulate ? *dst + v : v; }
 
-__global__ __launch_bounds__(256) void k_bwd_fold(
+__global__ __launch_bounds__(1024) void k_bwd_fold(
     const double* __restrict__ red, double npos, const float* __restrict__ stat,
     const float* __restrict__ Wt, const float* __restrict__ gs, const float* __restrict__ Wr,
     const float* __restrict__ gr, float* __restrict__ dWt, float* __restrict__ dbt,
@@ -758,7 +758,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if ((rc = check_launch("bwd_reduce_partials"))) return rc;
   }
   // 2. fold
-  hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(256), 6 * Co * sizeof(double) + (2 * Co * Ci + 2 * Ci) * sizeof(float), st, w.red, (double)B * TV, stat,
+  hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(1024), 6 * Co * sizeof(double) + (2 * Co * Ci + 2 * Ci) * sizeof(float), st, w.red, (double)B * TV, stat,
                      Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate);
   if ((rc = check_launch("bwd_fold"))) return rc;
   // 3. data path

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restric
 //   [muX Ci][muZ Ci][WCs Co*Ci = Wt C_Z][WCr Co*Ci = Wr C_X][mean_s Co][istd_s Co][mean_r Co][istd_r Co]
 __host__ __device__ inline int stat_floats(int Ci, int Co) { return 2 * Ci + 2 * Co * Ci + 4 * Co; }
 
-__global__ __launch_bounds__(256) void k_train_fold(
+__global__ __launch_bounds__(1024) void k_train_fold(
     const double* __restrict__ red, double npos, const float* __restrict__ Wt,
     const float* __restrict__ bt, const float* __restrict__ gs, const float* __restrict__ bs,
     float* __restrict__ rm_s, float* __restrict__ rv_s, long long* __restrict__ nbt_s,
@@ -265,7 +265,7 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   if (rc) return rc;
   const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + 4 * (size_t)Co * Ci * sizeof(float);
   if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_train_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
-  hipLaunchKernelGGL(k_train_fold, dim3(1), dim3(256), fold_lds, st, red, (double)B * TV, Wt, bt, gs, bs, rm_s,
+  hipLaunchKernelGGL(k_train_fold, dim3(1), dim3(1024), fold_lds, st, red, (double)B * TV, Wt, bt, gs, bs, rm_s,
                      rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r, nbt_r, momentum, wfold, bias, stat, Ci,
                      Co, round_up(Co, 16));
   return check_launch("train_fold");
