@@ -114,16 +114,32 @@ def main():
     for _ in range(args.warmup):
         eng.step(x)
     sync()
-    # dominant kernel probe: the layer-4 forward kernel (32 -> 64 channels), one kernel per C-ABI call
-    probe = {"name": "coskad_layer_apply_f32", "tag": (CHANNELS[-1], HID), "events": []}
-    if not args.graph:
-        _lib.PROBE = probe
+    # dominant kernel (rocprof, profiles/): k_bwd_data of layer 4 (C_in 32 -> C_out 64).  The library brackets each
+    # of its launches with HIP events on the launch stream (coskad_probe_*), inside the timed region.
+    import ctypes
+    lib = _lib.lib()
+    KID_LAYER_APPLY, KID_BWD_DATA = 1, 2
+    probing = not args.graph
+    if probing:
+        lib.coskad_probe_begin(KID_BWD_DATA, CHANNELS[-1], HID)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = eng.step(x)
     sync()
     dt = time.perf_counter() - t0
-    _lib.PROBE = None
+    probe_ms, probe_n = ctypes.c_float(0), ctypes.c_int(0)
+    if probing:
+        lib.coskad_probe_end(ctypes.byref(probe_ms), ctypes.byref(probe_n))
+    # secondary (outside the timed region): the layer-4 forward kernel, for the forward-roofline target
+    fwd_ms, fwd_n = ctypes.c_float(0), ctypes.c_int(0)
+    if probing and rank == 0:
+        lib.coskad_probe_begin(KID_LAYER_APPLY, CHANNELS[-1], HID)
+        for _ in range(5):
+            eng.step(x)
+        torch.cuda.synchronize()
+        lib.coskad_probe_end(ctypes.byref(fwd_ms), ctypes.byref(fwd_n))
+    if world > 1:
+        dist.barrier()
     if world > 1:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -132,14 +148,23 @@ def main():
 
     if rank == 0:
         fwd_b, bwd_b = algorithmic_bytes_per_clip()
-        roof = None
-        if probe["events"]:
-            ms = sum(a.elapsed_time(b) for a, b in probe["events"]) / len(probe["events"])
-            byts = B * 4 * T * V * (CHANNELS[-1] + HID)      # layer 4: read 32 ch, write 64 ch, per launch
-            ach = byts / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_layer_apply<12,17,8> (layer 4, 32->64)", "achieved": round(ach, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_us": round(ms * 1e3, 2), "launches": len(probe["events"])}
+        roof = roof_fwd = None
+        tvb = 4 * T * V
+        if probe_n.value:
+            # SURVEY 8d, backward of one layer: read dOut (C_out), read the saved input (C_in), write dIn (C_in)
+            byts = B * tvb * (HID + 2 * CHANNELS[-1])
+            ach = byts / (probe_ms.value * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_bwd_data<12,17,2> (layer 4 backward data path, 64 -> 32 channels)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": None, "algorithmic_bytes_per_launch": byts,
+                    "avg_launch_us": round(probe_ms.value * 1e3, 2), "launches": probe_n.value}
+        if fwd_n.value:
+            byts = B * tvb * (CHANNELS[-1] + HID)        # layer 4 forward: read 32 channels, write 64
+            ach = byts / (fwd_ms.value * 1e-3) / 1e9
+            roof_fwd = {"bound": "hbm", "kernel": "k_layer_apply_m<12,17,4> (layer 4 forward, 32 -> 64 channels)",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": byts,
+                        "avg_launch_us": round(fwd_ms.value * 1e3, 2), "launches": fwd_n.value}
         out = {
             "metric": "pose_clips_per_sec_fwd_bwd", "value": round(world * B * args.steps / dt, 1), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,6 +178,7 @@ def main():
             "step_hbm_frac": round(world * B * args.steps / dt * (fwd_b + bwd_b) / world / (HBM_PEAK_GBS * 1e9), 4),
             "final_loss": round(loss, 6),
             "roofline": roof,
+            "roofline_fwd_layer4": roof_fwd,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 8)

@@ -41,6 +41,15 @@ struct Geo {
   static constexpr int LD = (TV % 2 == 0) ? TV + 1 : TV;
 };
 
+// kernel ids of the timing probe (api.hip)
+enum { KID_LAYER_APPLY = 1, KID_BWD_DATA = 2, KID_BWD_REDUCE = 3, KID_FWD_MOMENTS = 4, KID_GCN_PARAMS = 5 };
+struct ProbeScope {   // brackets ONE kernel launch with events when the probe is armed for it
+  ProbeScope(int kernel, int ci, int co, hipStream_t st);
+  ~ProbeScope();
+  hipStream_t st_;
+  bool armed_ = false;
+};
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

@@ -747,10 +747,13 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     else if (ntc == 3) LAUNCH_R(NTO, 3);                         \
     else LAUNCH_R(NTO, 4);                                       \
   } while (0)
+    {
+    ProbeScope probe(KID_BWD_REDUCE, Ci, Co, st);
     if (nto == 1) LAUNCH_R_O(1);
     else if (nto == 2) LAUNCH_R_O(2);
     else if (nto == 3) LAUNCH_R_O(3);
     else LAUNCH_R_O(4);
+    }
 #undef LAUNCH_R_O
 #undef LAUNCH_R
     if ((rc = check_launch("bwd_reduce"))) return rc;
@@ -782,10 +785,13 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
                        w.dz, dap, B, Ci, Co, NB);                                                       \
   } while (0)
+    {
+    ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
     if (CiP == 16) LAUNCH_D(1);
     else if (CiP == 32) LAUNCH_D(2);
     else if (CiP == 48) LAUNCH_D(3);
     else LAUNCH_D(4);
+    }
 #undef LAUNCH_D
     if ((rc = check_launch("bwd_data"))) return rc;
     if (dap) {

@@ -87,6 +87,7 @@ int launch_layer_apply_m(const float* in, float* out, const float* Aw, const flo
   } while (0)
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("COSKAD_DBG"); dbg = e ? atoi(e) : 0; }
+  ProbeScope probe(KID_LAYER_APPLY, Ci, Co, st);
   if (CoP == 16) LAUNCH_OTI(1);
   else if (CoP == 32) LAUNCH_OTI(2);
   else if (CoP == 48) LAUNCH_OTI(3);

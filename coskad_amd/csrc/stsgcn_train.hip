@@ -253,10 +253,13 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, Aw, Tw, in_slope, partials, B, Ci, NB, need_x); \
   } while (0)
+  {
+  ProbeScope probe(KID_FWD_MOMENTS, Ci, Co, st);
   if (ntc == 1) LAUNCH_M(1);
   else if (ntc == 2) LAUNCH_M(2);
   else if (ntc == 3) LAUNCH_M(3);
   else LAUNCH_M(4);
+  }
 #undef LAUNCH_M
   int rc = check_launch("fwd_moments");
   if (rc) return rc;

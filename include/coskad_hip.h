@@ -22,6 +22,12 @@ extern "C" {
 int coskad_abi_version(void);
 const char* coskad_last_error(void);
 
+/* Timing probe for benchmarks: after coskad_probe_begin(kernel, Ci, Co) every launch of that tile kernel
+ * (1 = layer_apply, 2 = bwd_data, 3 = bwd_reduce, 4 = fwd_moments) with those channel counts is bracketed by
+ * HIP events on its launch stream; coskad_probe_end() waits for them and returns the average duration. */
+int coskad_probe_begin(int kernel, int Ci, int Co);
+int coskad_probe_end(float* avg_ms, int* launches);
+
 /* ---- forward ------------------------------------------------------------------------ */
 
 /* ConvTemporalGraphical.forward (models/graph_layers/stsgcn.py:143-156) on rows = N*C rows
