@@ -150,13 +150,22 @@ def main():
         fwd_b, bwd_b = algorithmic_bytes_per_clip()
         roof = roof_fwd = None
         tvb = 4 * T * V
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this script)
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+                traffic = json.load(f)
+        except OSError:
+            pass
         if probe_n.value:
             # SURVEY 8d, backward of one layer: read dOut (C_out), read the saved input (C_in), write dIn (C_in)
             byts = B * tvb * (HID + 2 * CHANNELS[-1])
             ach = byts / (probe_ms.value * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_bwd_data<12,17,2> (layer 4 backward data path, 64 -> 32 channels)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "algorithmic_bytes_per_launch": byts,
+                    "traffic": (traffic.get("k_bwd_data<12,17,2> layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
+                    "traffic_source": "profiles/r01_hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE, B=4096)",
+                    "algorithmic_bytes_per_launch": byts,
                     "avg_launch_us": round(probe_ms.value * 1e3, 2), "launches": probe_n.value}
         if fwd_n.value:
             byts = B * tvb * (CHANNELS[-1] + HID)        # layer 4 forward: read 32 channels, write 64
@@ -164,6 +173,7 @@ def main():
             roof_fwd = {"bound": "hbm", "kernel": "k_layer_apply_m<12,17,4> (layer 4 forward, 32 -> 64 channels)",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": byts,
+                        "traffic": (traffic.get("k_layer_apply_m<12,17,4> layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
                         "avg_launch_us": round(fwd_ms.value * 1e3, 2), "launches": fwd_n.value}
         out = {
             "metric": "pose_clips_per_sec_fwd_bwd", "value": round(world * B * args.steps / dt, 1), "unit": "clips/s",
