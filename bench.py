@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--head", default="euclidean", choices=["euclidean", "poincare"])
     ap.add_argument("--graph", type=int, default=int(os.environ.get("COSKAD_GRAPH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to "
+                    "rehearse the multi-rank control flow on a single GPU)")
     ap.add_argument("--cpu-sample", type=int, default=512)
     args = ap.parse_args()
 
@@ -93,9 +95,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     if world > 1:
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group(args.backend)  # "nccl" = RCCL on ROCm
 
     B = args.batch
     st = R.init_stse_state(C_IN, CHANNELS, HID, LATENT, T, V, seed=0)   # same weights on every rank
@@ -132,14 +134,13 @@ def main():
         lib.coskad_probe_end(ctypes.byref(probe_ms), ctypes.byref(probe_n))
     # secondary (outside the timed region): the layer-4 forward kernel, for the forward-roofline target
     fwd_ms, fwd_n = ctypes.c_float(0), ctypes.c_int(0)
-    if probing and rank == 0:
+    if probing:
+        # every rank runs these steps (they contain the gradient all-reduce); only rank 0 reads its probe
         lib.coskad_probe_begin(KID_LAYER_APPLY, CHANNELS[-1], HID)
         for _ in range(5):
             eng.step(x)
-        torch.cuda.synchronize()
+        sync()
         lib.coskad_probe_end(ctypes.byref(fwd_ms), ctypes.byref(fwd_n))
-    if world > 1:
-        dist.barrier()
     if world > 1:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

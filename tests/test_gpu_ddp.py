@@ -1,0 +1,90 @@
+"""Two ranks on ONE GPU (gloo carries the collectives; RCCL refuses two ranks per device): the data-parallel train
+step -- shard clips r::W, per-rank BatchNorm statistics, ONE all-reduce of the flat gradient buffer, Adam with the
+1/W scale -- must equal the oracle's two-shard computation (mean of shard gradients, torch Adam)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+CFG = dict(input_dim=2, layer_channels=(16, 8, 16), hidden=16, latent=8, T=12, V=17)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from coskad_amd import parallel
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import STSETrainStep
+    st = R.init_stse_state(CFG["input_dim"], CFG["layer_channels"], CFG["hidden"], CFG["latent"], seed=0)
+    st["c"] = torch.linspace(-0.1, 0.1, CFG["latent"])
+    x = R.synthetic_clips(48, seed=9)
+    m = STSE(2, list(CFG["layer_channels"]), CFG["hidden"], CFG["latent"], 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    m.load_state_dict(st, strict=True)
+    m.cuda().train()
+    eng = STSETrainStep(m, lr=1e-3, alpha=0.0, head='euclidean')
+    assert eng.world == world
+    idx = parallel.shard_indices(48, rank, world)
+    stats = eng.step(x[idx].cuda())
+    c = eng.refresh_center(eps=1e-3).cpu()
+    torch.cuda.synchronize()
+    q.put((rank, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if v.is_floating_point()}, float(stats[0]), c.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_oracle():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # oracle: per-shard autograd, mean of gradients, torch Adam
+    from coskad_amd import parallel
+    st = R.init_stse_state(CFG["input_dim"], CFG["layer_channels"], CFG["hidden"], CFG["latent"], seed=0)
+    cvec = torch.linspace(-0.1, 0.1, CFG["latent"])
+    x = R.synthetic_clips(48, seed=9)
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
+    zs, total = [], None
+    for r in range(world):
+        s2 = {k: v.clone() for k, v in st.items()}
+        s2.update(params)
+        z = R.stse_encode(x[parallel.shard_indices(48, r, world)], s2, training=True)
+        zs.append(z.detach())
+        loss = R.mse_to_center(z, cvec) / world
+        loss.backward()
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    opt.step()
+    for r in range(world):
+        got = res[r][1]
+        for k, p in params.items():
+            if k.endswith(("tcn.0.bias", "residual.0.bias")):
+                continue   # analytically zero gradient; autograd noise makes torch's Adam move them
+            np.testing.assert_allclose(got[k], p.detach().numpy(), rtol=2e-3, atol=3e-4, err_msg=f"rank {r} {k}")
+    # both ranks hold identical parameters and the same all-reduced centre = mean over ALL clips
+    for k in res[0][1]:
+        if "running" not in k:
+            np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
+    zall = torch.cat(zs).mean(0)
+    np.testing.assert_allclose(res[0][3], R.clamp_center(zall, 1e-3).numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_array_equal(res[0][3], res[1][3])
