@@ -19,6 +19,7 @@
 //  4. k_bwd_gcn_params : dA[t,v,w] = sum_rows Y[t,v] dZ[t,w],  dT[v,t,q] = sum_rows X[t,v] dY[q,v]
 //                    (GEMMs with K = rows (clip,channel) -> MFMA f32).
 #include "mfma_ops.h"
+#include <cstdlib>
 
 namespace coskad {
 
@@ -384,6 +385,193 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
       }
     }
   }  // tile loop
+  if (da_partials) {
+    da = wave_sum(da);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = da;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < kBlock / 64; ++w) t += sred[w];
+      da_partials[blockIdx.x] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// 3b. data path, single-read variant for C_in >= 32 (one clip per tile, one strip per wave):
+//     * Kr.X is taken from the LDS image BEFORE the mixing overwrites it,
+//     * dU is read ONCE: each 8-byte operand feeds both Bt.dU (-> dZ) and Br.dU (-> dX_res),
+//     * the dX_res accumulators stay in registers across the two mixing phases.
+// ---------------------------------------------------------------------------------------
+template <int T, int V, int OTI>
+__global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
+    const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
+    const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
+    float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
+    int Co) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int PS = (TV + 31) / 32;
+  constexpr int XB = 4;
+  static_assert(PS <= kBlock / 64, "one strip per wave");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float sred[kBlock / 64];
+  const int CiP = round_up(Ci, 16);
+  const int KZ = round_up(Ci, 4), K1 = round_up(Co, 4);
+  const float* wDZ = coef;
+  const float* kt = wDZ + (Co + Ci) * CiP;
+  const float* wDX = kt + CiP;
+  const float* kr = wDX + (Co + Ci) * CiP;
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  float* img = lds;
+  float* AwL = lds + Ci * LD;
+  float* TwL = AwL + T * V * V;
+  float* WlA = TwL + V * T * T;              // [(KZ + K1)][CiP]: Kt rows (Z), then Bt rows (dU)
+  float* WlB = WlA + (KZ + K1) * CiP;        // [(K1 + KZ)][CiP]: Br rows (dU), then Kr rows (X)
+  float* ktl = WlB + (K1 + KZ) * CiP;
+  float* krl = ktl + CiP;
+  copy_to_lds(AwL, Aw, T * V * V);
+  copy_to_lds(TwL, Tw, V * T * T);
+  for (int e = threadIdx.x; e < (KZ + K1) * CiP; e += kBlock) {
+    const int k = e / CiP, c = e - k * CiP;
+    float va = 0.f, vb = 0.f;
+    if (k < KZ) { if (k < Ci) va = wDZ[(Co + k) * CiP + c]; }
+    else if (k - KZ < Co) va = wDZ[(k - KZ) * CiP + c];
+    if (k < K1) { if (k < Co) vb = wDX[k * CiP + c]; }
+    else if (k - K1 < Ci) vb = wDX[(Co + k - K1) * CiP + c];
+    WlA[e] = va;
+    WlB[e] = vb;
+  }
+  copy_to_lds(ktl, kt, CiP);
+  copy_to_lds(krl, kr, CiP);
+  const int wave = uniform(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kk = lane >> 4;
+  const bool mine = wave < PS;                 // this wave's strip
+  const int p = 32 * wave + 2 * j;
+  const bool pok = mine && p < TV;
+  const int pc = p < TV ? p : TV - 2;
+  const int KZS = KZ / 4, K1S = K1 / 4;
+  float da = 0.f;
+
+  for (int clip = blockIdx.x; clip < B; clip += gridDim.x) {
+    const float* gin = in + (size_t)clip * Ci * TV;
+    const float* gdu = dU + (size_t)clip * Co * TV;
+    f32x4 accA[OTI][2], accB[OTI][2];
+#pragma unroll
+    for (int t = 0; t < OTI; ++t) {
+      accA[t][0] = accA[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accB[t][0] = accB[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    stage_rows<T, V>(gin, img, Ci * TV, pre, a_in);
+    __syncthreads();
+    // phase 0: accB = Kr . X  (LDS, before the mixing overwrites X)
+    if (mine) {
+      for (int s = 0; s < KZS; ++s) {
+        const int c = 4 * s + kk;
+        const int cc = c < Ci ? c : Ci - 1;
+        const float b0 = img[cc * LD + pc], b1 = img[cc * LD + pc + 1];
+        const float* w = WlB + (K1 + c) * CiP + j;
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) {
+          const float a = w[16 * t];
+          accB[t][0] = mfma4(a, b0, accB[t][0]);
+          accB[t][1] = mfma4(a, b1, accB[t][1]);
+        }
+      }
+    }
+    __syncthreads();
+    gcn_mfma<T, V, false>(img, Ci, AwL, TwL);
+    __syncthreads();
+    // phase A: accA = Kt.Z (LDS) + Bt.dU ; accB += Br.dU -- ONE pass over dU
+    if (mine) {
+      float2 cur[XB], nxt[XB];
+      auto gload = [&](int g) -> float2 {
+        if (g >= K1S) return float2{0.f, 0.f};
+        const int c = 4 * g + kk;
+        const int cc = c < Co ? c : Co - 1;
+        return *reinterpret_cast<const float2*>(gdu + (size_t)cc * TV + pc);
+      };
+#pragma unroll
+      for (int u = 0; u < XB; ++u) cur[u] = gload(u);
+      for (int s = 0; s < KZS; ++s) {
+        const int c = 4 * s + kk;
+        const int cc = c < Ci ? c : Ci - 1;
+        const float b0 = img[cc * LD + pc], b1 = img[cc * LD + pc + 1];
+        const float* w = WlA + c * CiP + j;
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) {
+          const float a = w[16 * t];
+          accA[t][0] = mfma4(a, b0, accA[t][0]);
+          accA[t][1] = mfma4(a, b1, accA[t][1]);
+        }
+      }
+      for (int g0 = 0; g0 < K1S; g0 += XB) {
+#pragma unroll
+        for (int u = 0; u < XB; ++u) nxt[u] = gload(g0 + XB + u);
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+          if (g0 + u < K1S) {
+            const float* wa = WlA + (KZ + 4 * (g0 + u) + kk) * CiP + j;
+            const float* wb = WlB + (4 * (g0 + u) + kk) * CiP + j;
+#pragma unroll
+            for (int t = 0; t < OTI; ++t) {
+              const float a1 = wa[16 * t], a2 = wb[16 * t];
+              accA[t][0] = mfma4(a1, cur[u].x, accA[t][0]);
+              accA[t][1] = mfma4(a1, cur[u].y, accA[t][1]);
+              if (dIn) {
+                accB[t][0] = mfma4(a2, cur[u].x, accB[t][0]);
+                accB[t][1] = mfma4(a2, cur[u].y, accB[t][1]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < XB; ++u) cur[u] = nxt[u];
+      }
+      // dZ in place (all of this strip's Z columns were read above)
+      if (pok) {
+#pragma unroll
+        for (int t = 0; t < OTI; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 16 * t + 4 * kk + r;
+            if (o < Ci) {
+              img[o * LD + p] = accA[t][0][r] + ktl[o];
+              img[o * LD + p + 1] = accA[t][1][r] + ktl[o];
+            }
+          }
+      }
+    }
+    __syncthreads();
+    if (dZout) unstage_rows<T, V>(dZout + (size_t)clip * Ci * TV, img, Ci * TV);
+    if (dIn) {
+      gcn_mfma<T, V, true>(img, Ci, AwL, TwL);
+      __syncthreads();
+      if (pok) {
+        float* dg = dIn + (size_t)clip * Ci * TV;
+#pragma unroll
+        for (int t = 0; t < OTI; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 16 * t + 4 * kk + r;
+            if (o < Ci) {
+              float g0 = accB[t][0][r] + krl[o] + img[o * LD + p];
+              float g1 = accB[t][1][r] + krl[o] + img[o * LD + p + 1];
+              if (pre) {
+                const float2 u = *reinterpret_cast<const float2*>(gin + (size_t)o * TV + p);
+                if (u.x < 0.f) da = fmaf(g0, u.x, da);
+                if (u.y < 0.f) da = fmaf(g1, u.y, da);
+                g0 = u.x > 0.f ? g0 : a_in * g0;
+                g1 = u.y > 0.f ? g1 : a_in * g1;
+              }
+              *reinterpret_cast<float2*>(dg + (size_t)o * TV + p) = float2{g0, g1};
+            }
+          }
+      }
+    }
+  }
   if (da_partials) {
     da = wave_sum(da);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = da;
@@ -785,6 +973,24 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
                        w.dz, dap, B, Ci, Co, NB);                                                       \
   } while (0)
+#define LAUNCH_DF(OTI)                                                                                  \
+  do {                                                                                                  \
+    auto k = k_bwd_data_f<T, V, OTI>;                                                                   \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
+                       w.dz, dap, B, Ci, Co);                                                           \
+  } while (0)
+    static int fused_ok = -1;
+    if (fused_ok < 0) { const char* e = getenv("COSKAD_BWD_UNFUSED"); fused_ok = (e && e[0] == '1') ? 0 : 1; }
+    constexpr bool strips_fit = (Geo<T, V>::TV + 31) / 32 <= kBlock / 64;
+    if (fused_ok && strips_fit && NB == 1 && dIn != nullptr && CiP <= 64) {
+      ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
+      if constexpr (strips_fit) {
+        if (CiP == 32) LAUNCH_DF(2);
+        else if (CiP == 48) LAUNCH_DF(3);
+        else LAUNCH_DF(4);
+      }
+    } else
     {
     ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
     if (CiP == 16) LAUNCH_D(1);
