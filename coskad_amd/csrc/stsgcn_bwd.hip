@@ -411,7 +411,10 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
     int Co) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   constexpr int PS = (TV + 31) / 32;
-  constexpr int XB = 4;
+#ifndef COSKAD_XBF
+#define COSKAD_XBF 2
+#endif
+  constexpr int XB = COSKAD_XBF;
   static_assert(PS <= kBlock / 64, "one strip per wave");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sred[kBlock / 64];
