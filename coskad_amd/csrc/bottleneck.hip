@@ -36,19 +36,26 @@ __global__ __launch_bounds__(64 * kBtlFwdWaves) void k_btlnk_fwd(const float* __
   const int per = ceil_div(nsteps, kBtlFwdWaves);
   const int s0 = wave * per, s1 = min(nsteps, s0 + per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int s = s0; s < s1; ++s) {
-    const int k = s * 16 + 4 * kk;
-    float4 x = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
-    if (k < K) {
-      if (rowok) x = *reinterpret_cast<const float4*>(up + k);
-      if (colok) w = *reinterpret_cast<const float4*>(wp + k);
+  // batches of UB k-steps: 2*UB 16-byte loads in flight per lane (the kernel must stream U at HBM rate)
+  constexpr int UB = 4;
+  for (int sb = s0; sb < s1; sb += UB) {
+    float4 x[UB], w[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int k = (sb + u) * 16 + 4 * kk;
+      const bool ok = sb + u < s1 && k < K;
+      x[u] = (ok && rowok) ? *reinterpret_cast<const float4*>(up + k) : float4{0.f, 0.f, 0.f, 0.f};
+      w[u] = (ok && colok) ? *reinterpret_cast<const float4*>(wp + k) : float4{0.f, 0.f, 0.f, 0.f};
     }
-    if (pre) { x.x = prelu_f(x.x, a); x.y = prelu_f(x.y, a); x.z = prelu_f(x.z, a); x.w = prelu_f(x.w, a); }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, w.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, w.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, w.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, w.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      float4 xv = x[u];
+      if (pre) { xv.x = prelu_f(xv.x, a); xv.y = prelu_f(xv.y, a); xv.z = prelu_f(xv.z, a); xv.w = prelu_f(xv.w, a); }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, w[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, w[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, w[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, w[u].w, acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][(4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
