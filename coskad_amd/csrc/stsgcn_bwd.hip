@@ -357,9 +357,12 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
                              (wave + n) % (kBlock / 64), kBlock / 64, epiA);
     }
     __syncthreads();
-    if (dZout) unstage_rows<T, V>(dZout + (size_t)clip0 * Ci * TV, lds, rows * TV);
+    if (dZout) {
+      unstage_rows<T, V>(dZout + (size_t)clip0 * Ci * TV, lds, rows * TV);
+      __syncthreads();   // the adjoint mixing below overwrites dZ in place: every wave must have copied it out
+    }
     if (dIn) {
-      gcn_mfma<T, V, true>(lds, rows, AwL, TwL);  // (barrier inside; unstage above only read)
+      gcn_mfma<T, V, true>(lds, rows, AwL, TwL);
       __syncthreads();
       // phase B (MFMA): dX = gcn^T(dZ) + kr + Br dU + Kr X ; dU_prev = dX * PReLU'(U_prev)
       for (int n = 0; n < nb; ++n) {
@@ -548,7 +551,10 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
       }
     }
     __syncthreads();
-    if (dZout) unstage_rows<T, V>(dZout + (size_t)clip * Ci * TV, img, Ci * TV);
+    if (dZout) {
+      unstage_rows<T, V>(dZout + (size_t)clip * Ci * TV, img, Ci * TV);
+      __syncthreads();   // the adjoint mixing below overwrites dZ in place: every wave must have copied it out
+    }
     if (dIn) {
       gcn_mfma<T, V, true>(img, Ci, AwL, TwL);
       __syncthreads();

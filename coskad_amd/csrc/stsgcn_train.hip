@@ -34,8 +34,11 @@ __global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict_
   copy_to_lds(TwL, Tw, V * T * T);
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
-  f32x4 mx[NTC][NTC], mz[NTC][NTC], sx[NTC], sz[NTC];
-  zero_acc(mx); zero_acc(mz); zero_acc(sx); zero_acc(sz);
+  f32x4 mx[NTC][NTC], mz[NTC][NTC];
+  float sx[NTC], sz[NTC];
+  zero_acc(mx); zero_acc(mz);
+#pragma unroll
+  for (int t = 0; t < NTC; ++t) { sx[t] = 0.f; sz[t] = 0.f; }
 
   const int ntiles = ceil_div(B, NB);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -46,25 +49,17 @@ __global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict_
     stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, lds, rows * TV, pre, a_in);
     __syncthreads();
     if (need_x) {
-      for (int n = 0; n < nb; ++n) {
-        const float* r = lds + n * Ci * LD;
-        outer_accum<T, V, NTC, NTC, true>(r, Ci, r, Ci, mx, sx);
-      }
+      for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC>(lds + n * Ci * LD, Ci, mx, sx);
       __syncthreads();
     }
     gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
     __syncthreads();
-    for (int n = 0; n < nb; ++n) {
-      const float* r = lds + n * Ci * LD;
-      outer_accum<T, V, NTC, NTC, true>(r, Ci, r, Ci, mz, sz);
-    }
+    for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC>(lds + n * Ci * LD, Ci, mz, sz);
   }
   // partial layout: [MX Ci*Ci][sumX Ci][MZ Ci*Ci][sumZ Ci]
   float* dst = partials + (size_t)blockIdx.x * (2 * (Ci * Ci + Ci));
-  store_outer<NTC, NTC>(mx, scratch, dst, Ci, Ci, Ci);
-  store_sums<NTC>(sx, scratch, dst + Ci * Ci, Ci);
-  store_outer<NTC, NTC>(mz, scratch, dst + Ci * Ci + Ci, Ci, Ci, Ci);
-  store_sums<NTC>(sz, scratch, dst + 2 * Ci * Ci + Ci, Ci);
+  store_moments<NTC>(mx, sx, scratch, dst, Ci, dst + Ci * Ci, Ci);
+  store_moments<NTC>(mz, sz, scratch, dst + Ci * Ci + Ci, Ci, dst + 2 * Ci * Ci + Ci, Ci);
 }
 
 // out[e] = sum_p partials[p][e] in fp64 (fixed order).  block = 64 elements x 16 partial-slices, 4 loads in

@@ -254,6 +254,79 @@ __device__ __forceinline__ void outer_accum(const float* ldsA, int va, const flo
   }
 }
 
+// Second moments of ONE row image: M[a][b] += sum_p X[a][p] X[b][p], rs[a] += sum_p X[a][p].
+// Symmetric: only tiles tb >= ta are computed, and the A fragment of tile t IS the B fragment of tile t
+// (lane (i,k) holds X[16t+i][p0+k] either way), so one LDS read per tile and k-step feeds everything.
+// Row sums ride along on the VALU (one add per tile and k-step) instead of an extra MFMA against ones.
+template <int T, int V, int NT>
+__device__ __forceinline__ void moment_accum(const float* img, int valid, f32x4 (&acc)[NT][NT], float (&rs)[NT]) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  static_assert(TV % 4 == 0, "positions must be a multiple of the MFMA K step");
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int i = lane & 15, k = lane >> 4;
+  for (int p0 = 4 * wave; p0 < TV; p0 += 4 * (kBlock / 64)) {
+    float a[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int row = 16 * t + i;
+      a[t] = row < valid ? img[row * LD + p0 + k] : 0.f;
+      rs[t] += a[t];
+    }
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+      for (int tb = ta; tb < NT; ++tb)
+        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], a[tb], acc[ta][tb], 0, 0, 0);
+  }
+}
+
+// Store of moment_accum results: tiles tb >= ta are mirrored into the full [valid x valid] matrix at dst
+// (row stride ldd); row sums (per lane: row 16t + (lane&15), partial over its k group) go to sums[].
+template <int NT>
+__device__ __forceinline__ void store_moments(const f32x4 (&acc)[NT][NT], const float (&rs)[NT], float* scratch,
+                                              float* dst, int ldd, float* sums, int valid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = kBlock / 64;
+#pragma unroll
+  for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+    for (int tb = ta; tb < NT; ++tb) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scratch[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[ta][tb][r];
+      __syncthreads();
+      const int e = threadIdx.x;
+      if (e < 256) {
+        const int row = e >> 4, col = e & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += scratch[w * 256 + e];
+        const int ra = 16 * ta + row, cb = 16 * tb + col;
+        if (ra < valid && cb < valid) {
+          dst[ra * ldd + cb] = s;
+          if (ta != tb) dst[cb * ldd + ra] = s;
+        }
+      }
+    }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float v = rs[t];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    __syncthreads();
+    if (lane < 16) scratch[wave * 16 + lane] = v;
+    __syncthreads();
+    const int e = threadIdx.x;
+    if (e < 16 && 16 * t + e < valid) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += scratch[w * 16 + e];
+      sums[16 * t + e] = s;
+    }
+  }
+}
+
 // Cross-wave reduction of MFMA accumulators and store of this block's partial.
 //   dst[(16*ta + row) * ldd + 16*tb + col]  (only row < va, col < vb are written)
 // scratch: LDS, >= kScratchFloats.  Contains barriers; all threads must call.
