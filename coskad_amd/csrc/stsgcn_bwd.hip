@@ -42,7 +42,7 @@ struct RedGeo {
 template <int NTA, int NTB, bool SUMS>
 __device__ __forceinline__ void outer_accum2(const float* ldsA, int ldA, int offA, int va, const float* ldsB,
                                              int ldB, int offB, int vb, int npos, f32x4 (&acc)[NTA][NTB],
-                                             f32x4 (&sacc)[NTA]) {
+                                             float (&rs)[NTA]) {
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
   const int i = lane & 15, k = lane >> 4;
@@ -64,8 +64,7 @@ __device__ __forceinline__ void outer_accum2(const float* ldsA, int ldA, int off
 #pragma unroll
       for (int tb = 0; tb < NTB; ++tb)
         acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
-      if constexpr (SUMS)
-        sacc[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], pok ? 1.0f : 0.f, sacc[ta], 0, 0, 0);
+      if constexpr (SUMS) rs[ta] += a[ta];   // a is 0 outside the valid rows / positions
     }
   }
 }
@@ -104,8 +103,11 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__
   copy_to_lds(TwL, Tw, V * T * T);
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
-  f32x4 pacc[NTO][NTC], qacc[NTO][NTC], sacc[NTO], sdummy[NTO];
-  zero_acc(pacc); zero_acc(qacc); zero_acc(sacc); zero_acc(sdummy);
+  f32x4 pacc[NTO][NTC], qacc[NTO][NTC];
+  float srow[NTO], sdummy[NTO];
+  zero_acc(pacc); zero_acc(qacc);
+#pragma unroll
+  for (int t = 0; t < NTO; ++t) { srow[t] = 0.f; sdummy[t] = 0.f; }
 
   const int ntiles = ceil_div(B, NB);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -132,13 +134,13 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__
       stage_chunk<T, V>(gdu, ldu, nb * Co, pbeg, npos);
       __syncthreads();
       for (int n = 0; n < nb; ++n)
-        outer_accum2<NTO, NTC, true>(ldu + n * Co * LDC, LDC, 0, Co, ldx + n * Ci * LD, LD, pbeg, Ci, npos, pacc, sacc);
+        outer_accum2<NTO, NTC, true>(ldu + n * Co * LDC, LDC, 0, Co, ldx + n * Ci * LD, LD, pbeg, Ci, npos, pacc, srow);
     }
   }
   float* dst = partials + (size_t)blockIdx.x * (2 * Co * Ci + Co);
   store_outer<NTO, NTC>(pacc, scratch, dst, Ci, Co, Ci);
   store_outer<NTO, NTC>(qacc, scratch, dst + Co * Ci, Ci, Co, Ci);
-  store_sums<NTO>(sacc, scratch, dst + 2 * Co * Ci, Co);
+  store_rowsums<NTO>(srow, scratch, dst + 2 * Co * Ci, Co);
 }
 
 __global__ __launch_bounds__(1024) void k_reduce_partials_d(const float* __restrict__ partials, int P, int E,

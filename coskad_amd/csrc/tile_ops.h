@@ -375,6 +375,29 @@ __device__ __forceinline__ void store_sums(const f32x4 (&sacc)[NTA], float* scra
   }
 }
 
+// Row sums accumulated per lane on the VALU (lane (i,k): row 16t+i, partial over its k group and k-steps):
+// reduce over the k groups, then over the waves, store sums[16t + i] for rows < valid.
+template <int NT>
+__device__ __forceinline__ void store_rowsums(const float (&rs)[NT], float* scratch, float* sums, int valid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float v = rs[t];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    __syncthreads();
+    if (lane < 16) scratch[wave * 16 + lane] = v;
+    __syncthreads();
+    const int e = threadIdx.x;
+    if (e < 16 && 16 * t + e < valid) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) s += scratch[w * 16 + e];
+      sums[16 * t + e] = s;
+    }
+  }
+}
+
 template <int N, int M>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[N][M]) {
 #pragma unroll
