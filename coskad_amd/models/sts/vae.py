@@ -1,0 +1,129 @@
+"""Mirror of the reference's models/sts/vae.py (STSVAE) on the HIP path.
+
+Encoder / decoder run on the gfx950 kernels (STSAE); the two small heads (`fc_mean`, `fc_var`) and the
+sampler are torch ops on [B, latent] tensors.  The reference imports `power_spherical` (nicola-decao), which is
+neither vendored nor pinned: `PowerSpherical` / `HypersphericalUniform` below restate the published
+algorithm (De Cao & Aziz, "The Power Spherical distribution", 2020) -- parity unpinned, checked by moments.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..common.components import MLP
+from ..graph_layers.stsgcn import _PReLUFn
+from .ae import STSAE
+
+Tensor = torch.Tensor
+
+
+class HypersphericalUniform:
+    """Uniform distribution on S^{dim} (dim = latent_dim - 1)."""
+
+    def __init__(self, dim: int, device="cpu") -> None:
+        self.dim, self.device = dim, device
+
+    def entropy(self) -> Tensor:
+        d = self.dim + 1
+        return torch.tensor(math.log(2) + (d / 2) * math.log(math.pi) - math.lgamma(d / 2), device=self.device)
+
+
+class PowerSpherical:
+    """p(x; mu, kappa) ∝ (1 + mu^T x)^kappa on S^{d-1}; rsample via t ~ 2 Beta(a,b) - 1 and a Householder
+    reflection of e1 onto mu (reparameterised through the Beta sample)."""
+
+    def __init__(self, loc: Tensor, scale: Tensor) -> None:
+        self.loc, self.scale = loc, scale
+        d = loc.shape[-1]
+        self.alpha = (d - 1) / 2 + scale
+        self.beta = torch.full_like(scale, (d - 1) / 2)
+
+    def rsample(self) -> Tensor:
+        d = self.loc.shape[-1]
+        z = torch.distributions.Beta(self.alpha, self.beta).rsample()
+        t = (2 * z - 1).unsqueeze(-1)
+        v = F.normalize(torch.randn(*self.loc.shape[:-1], d - 1, device=self.loc.device, dtype=self.loc.dtype), dim=-1)
+        y = torch.cat([t, torch.sqrt(torch.clamp(1 - t * t, min=0)) * v], -1)
+        e1 = torch.zeros_like(self.loc)
+        e1[..., 0] = 1
+        u = F.normalize(e1 - self.loc, dim=-1)
+        return y - 2 * (y * u).sum(-1, keepdim=True) * u
+
+    def log_normalizer(self) -> Tensor:
+        return -((self.alpha + self.beta) * math.log(2) + torch.lgamma(self.alpha) - torch.lgamma(self.alpha + self.beta)
+                 + self.beta * math.log(math.pi))
+
+    def entropy(self) -> Tensor:
+        return -(self.log_normalizer() + self.scale * (math.log(2) + torch.digamma(self.alpha)
+                                                       - torch.digamma(self.alpha + self.beta)))
+
+
+def kl_ps_uniform(q: PowerSpherical, p: HypersphericalUniform) -> Tensor:
+    """KL(PowerSpherical || HypersphericalUniform) = -H(q) + H(p)  (the term at spherical_vae.py:92)."""
+    return -q.entropy() + p.entropy().to(q.scale.device)
+
+
+class STSVAE(STSAE):
+    """STSAE + mean / concentration heads + reparameterised sample (reference vae.py:13-170).
+    forward -> (Z, X_rec, (q_Z, p_Z, Z_var))."""
+
+    def __init__(self, *args, distribution: str = 'ps', **kwargs) -> None:
+        self.distribution = distribution.lower()
+        super().__init__(*args, **kwargs)
+
+    def build_model(self) -> None:
+        super().build_model()
+        if self.distribution == 'normal':
+            self.register_buffer('mean_vector', torch.zeros((1, self.latent_dim)))
+        self.register_buffer('threshold_dist', torch.tensor(0, dtype=torch.float32))
+
+    def _set_projector_type(self) -> None:
+        input_size = self.hidden_dimension * self.n_frames * self.n_joints
+        if self.projector == 'mlp':
+            self.btlnk = MLP(input_size=input_size, output_size=self.latent_dim, hidden_size=[self.latent_dim])
+            input_size = self.latent_dim
+        else:
+            self.btlnk = nn.Identity()
+            assert self.projector == 'linear', f'Projector type {self.projector} not supported.'
+        self.fc_mean = nn.Linear(in_features=input_size, out_features=self.latent_dim)
+        if self.distribution == 'normal':
+            var_out_features = self.latent_dim
+        elif self.distribution == 'ps':
+            var_out_features = 1
+        else:
+            raise ValueError(f'Distribution {self.distribution} not supported.')
+        self.fc_var = nn.Linear(in_features=input_size, out_features=var_out_features)
+
+    def encode(self, X: Tensor, return_shape: bool = False):
+        assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
+        B = X.shape[0]
+        U, slope = self.encoder.forward_preact(X)
+        Z = self.btlnk(_PReLUFn.apply(U, slope).reshape(B, -1))
+        X_shape = (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)
+        Z_mean = self.fc_mean(Z)
+        if self.distribution == 'ps':
+            Z_mean = Z_mean / torch.norm(Z_mean, dim=-1, keepdim=True)
+        Z_var = F.softplus(self.fc_var(Z)) + 1          # the `+ 1` prevents collapse (vae.py:85)
+        if return_shape:
+            return Z_mean, Z_var, X_shape
+        return Z_mean, Z_var
+
+    def reparameterize(self, Z_mean: Tensor, Z_var: Tensor):
+        if self.distribution == 'normal':
+            q_Z = torch.distributions.normal.Normal(Z_mean, Z_var)
+            p_Z = torch.distributions.normal.Normal(torch.zeros_like(Z_mean), torch.ones_like(Z_var))
+        else:
+            q_Z = PowerSpherical(loc=Z_mean, scale=torch.squeeze(Z_var, dim=-1))
+            p_Z = HypersphericalUniform(self.latent_dim - 1, device=Z_mean.device)
+        return q_Z, p_Z
+
+    def forward(self, X: Tensor):
+        Z_mean, Z_var, input_shape = self.encode(X, return_shape=True)
+        q_Z, p_Z = self.reparameterize(Z_mean, Z_var)
+        Z = q_Z.rsample()
+        X_rec = self.decode(Z, input_shape=input_shape)
+        return Z, X_rec, (q_Z, p_Z, Z_var)

@@ -89,3 +89,27 @@ def test_cpu_tensor_fails_loudly():
     m = STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
     with pytest.raises(CoskadHipError):
         m(torch.zeros(2, 2, 12, 17))
+
+
+def test_stsvae_forward_backward():
+    """STSVAE: deterministic heads against the oracle, sampled latent on the sphere, gradients flow."""
+    from coskad_amd.models.sts.vae import STSVAE, kl_ps_uniform
+    from oracle import ref_cpu as R
+    torch.manual_seed(0)
+    m = STSVAE(2, [16, 8, 16], 16, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='ps').cuda()
+    x = R.synthetic_clips(6, seed=3).cuda()
+    m.eval()
+    with torch.no_grad():
+        zm, zv = m.encode(x)
+    st = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        flat = R.stse_encode(x.cpu(), st, training=False)          # btlnk = Identity -> flattened encoder output
+        zm_ref, zv_ref = R.stsvae_heads(flat, st, 'ps')
+    np.testing.assert_allclose(zm.cpu().numpy(), zm_ref.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(zv.cpu().numpy(), zv_ref.numpy(), rtol=1e-3, atol=1e-4)
+    m.train()
+    z, xr, (q, p, kappa) = m(x)
+    np.testing.assert_allclose(z.norm(dim=-1).detach().cpu().numpy(), 1.0, atol=1e-4)
+    loss = ((xr - x) ** 2).mean() + kl_ps_uniform(q, p).mean() + (1 / kappa).mean()    # spherical_vae.py:81-107
+    loss.backward()
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in m.parameters())

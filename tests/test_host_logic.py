@@ -106,3 +106,33 @@ def test_config_contract():
     from coskad_amd.lit import LitEncoder
     lit = LitEncoder(args)
     assert lit.model.n_joints == 17 and lit.model.latent_dim == 16 and not lit.hyperbolic
+
+
+def test_power_spherical_sampler_moments():
+    """power_spherical is un-vendored in the reference -> statistical checks of the restated sampler."""
+    from coskad_amd.models.sts.vae import HypersphericalUniform, PowerSpherical, kl_ps_uniform
+    torch.manual_seed(0)
+    d, n = 8, 200000
+    mu = torch.nn.functional.normalize(torch.randn(d), dim=0)
+    for kappa in (2.0, 20.0):
+        q = PowerSpherical(mu.expand(n, d), torch.full((n,), kappa))
+        x = q.rsample()
+        np.testing.assert_allclose(x.norm(dim=-1).numpy(), 1.0, atol=1e-5)            # on the sphere
+        a, b = (d - 1) / 2 + kappa, (d - 1) / 2
+        np.testing.assert_allclose(float((x @ mu).mean()), (a - b) / (a + b), atol=5e-3)  # E[mu.x] = 2E[Beta]-1
+        resid = x - (x @ mu)[:, None] * mu
+        assert float(resid.mean(0).abs().max()) < 5e-3                                 # symmetric around mu
+    # KL to the uniform: >= 0, grows with the concentration, ~0 for kappa -> 0
+    p = HypersphericalUniform(d - 1)
+    kl = kl_ps_uniform(PowerSpherical(mu.expand(3, d), torch.tensor([1e-4, 5.0, 50.0])), p)
+    assert abs(float(kl[0])) < 1e-3 and 0 < float(kl[1]) < float(kl[2])
+
+
+def test_stsvae_surface():
+    from coskad_amd.models.sts.vae import STSVAE
+    m = STSVAE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='ps')
+    keys = set(m.state_dict().keys())
+    assert {"fc_mean.weight", "fc_var.weight", "rev_btlnk.weight", "decoder.model.0.gcn.A", "threshold_dist", "c"} <= keys
+    assert m.fc_var.out_features == 1 and isinstance(m.btlnk, torch.nn.Identity)     # vae.py:150,161
+    with pytest.raises(ValueError):
+        STSVAE(2, [8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='nope')
