@@ -116,7 +116,7 @@ def main():
     for _ in range(args.warmup):
         eng.step(x)
     sync()
-    # dominant kernel (rocprof, profiles/): k_bwd_data of layer 4 (C_in 32 -> C_out 64).  The library brackets each
+    # dominant kernel (rocprof, profiles/r01_kernel_instances.csv): k_bwd_data_f of layer 4 (C_in 32 -> C_out 64).  The library brackets each
     # of its launches with HIP events on the launch stream (coskad_probe_*), inside the timed region.
     import ctypes
     lib = _lib.lib()
@@ -162,9 +162,9 @@ def main():
             # SURVEY 8d, backward of one layer: read dOut (C_out), read the saved input (C_in), write dIn (C_in)
             byts = B * tvb * (HID + 2 * CHANNELS[-1])
             ach = byts / (probe_ms.value * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_bwd_data<12,17,2> (layer 4 backward data path, 64 -> 32 channels)",
+            roof = {"bound": "hbm", "kernel": "k_bwd_data_f<12,17,2> (layer 4 backward data path, 64 -> 32 channels, fused single-read variant)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": (traffic.get("k_bwd_data<12,17,2> layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
+                    "traffic": (traffic.get("bwd_data layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
                     "traffic_source": "profiles/r01_hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE, B=4096)",
                     "algorithmic_bytes_per_launch": byts,
                     "avg_launch_us": round(probe_ms.value * 1e3, 2), "launches": probe_n.value}
@@ -174,7 +174,7 @@ def main():
             roof_fwd = {"bound": "hbm", "kernel": "k_layer_apply_m<12,17,4> (layer 4 forward, 32 -> 64 channels)",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": byts,
-                        "traffic": (traffic.get("k_layer_apply_m<12,17,4> layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
+                        "traffic": (traffic.get("layer_apply layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
                         "avg_launch_us": round(fwd_ms.value * 1e3, 2), "launches": fwd_n.value}
         out = {
             "metric": "pose_clips_per_sec_fwd_bwd", "value": round(world * B * args.steps / dt, 1), "unit": "clips/s",

@@ -461,6 +461,30 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
   const int pc = p < TV ? p : TV - 2;
   const int KZS = KZ / 4, K1S = K1 / 4;
   float da = 0.f;
+  // acc += W[0:Ci] . img over this wave's strip; 4 k-steps of LDS operands in flight before their MFMAs
+  auto lds_conv = [&](const float* Wk, f32x4 (&acc)[OTI][2]) {
+    for (int s0 = 0; s0 < KZS; s0 += 4) {
+      float b0[4], b1[4], a[4][OTI];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = 4 * (s0 + u) + kk;
+        const bool ok = s0 + u < KZS;                  // beyond KZ: zero data, any (valid) weight
+        const int cc = (ok && c < Ci) ? c : Ci - 1;
+        b0[u] = ok ? img[cc * LD + pc] : 0.f;
+        b1[u] = ok ? img[cc * LD + pc + 1] : 0.f;
+        const float* w = Wk + (ok ? c : 0) * CiP + j;
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) a[u][t] = w[16 * t];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < OTI; ++t) {
+          acc[t][0] = mfma4(a[u][t], b0[u], acc[t][0]);
+          acc[t][1] = mfma4(a[u][t], b1[u], acc[t][1]);
+        }
+    }
+  };
 
   for (int clip = blockIdx.x; clip < B; clip += gridDim.x) {
     const float* gin = in + (size_t)clip * Ci * TV;
@@ -476,18 +500,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
     __syncthreads();
     // phase 0: accB = Kr . X  (LDS, before the mixing overwrites X)
     if (mine) {
-      for (int s = 0; s < KZS; ++s) {
-        const int c = 4 * s + kk;
-        const int cc = c < Ci ? c : Ci - 1;
-        const float b0 = img[cc * LD + pc], b1 = img[cc * LD + pc + 1];
-        const float* w = WlB + (K1 + c) * CiP + j;
-#pragma unroll
-        for (int t = 0; t < OTI; ++t) {
-          const float a = w[16 * t];
-          accB[t][0] = mfma4(a, b0, accB[t][0]);
-          accB[t][1] = mfma4(a, b1, accB[t][1]);
-        }
-      }
+      lds_conv(WlB + K1 * CiP, accB);
     }
     __syncthreads();
     gcn_mfma<T, V, false>(img, Ci, AwL, TwL);
@@ -503,18 +516,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
       };
 #pragma unroll
       for (int u = 0; u < XB; ++u) cur[u] = gload(u);
-      for (int s = 0; s < KZS; ++s) {
-        const int c = 4 * s + kk;
-        const int cc = c < Ci ? c : Ci - 1;
-        const float b0 = img[cc * LD + pc], b1 = img[cc * LD + pc + 1];
-        const float* w = WlA + c * CiP + j;
-#pragma unroll
-        for (int t = 0; t < OTI; ++t) {
-          const float a = w[16 * t];
-          accA[t][0] = mfma4(a, b0, accA[t][0]);
-          accA[t][1] = mfma4(a, b1, accA[t][1]);
-        }
-      }
+      lds_conv(WlA, accA);
       for (int g0 = 0; g0 < K1S; g0 += XB) {
 #pragma unroll
         for (int u = 0; u < XB; ++u) nxt[u] = gload(g0 + XB + u);

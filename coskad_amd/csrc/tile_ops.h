@@ -28,17 +28,29 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* l
   if constexpr (TV % 4 == 0) {
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const int n4 = nfloats >> 2;
-    for (int i = threadIdx.x; i < n4; i += kBlock) {
-      float4 v = g4[i];
-      const int e = i << 2;
-      const int row = e / TV;
-      const int col = e - row * TV;
-      if (do_prelu) {
-        v.x = prelu_f(v.x, slope); v.y = prelu_f(v.y, slope);
-        v.z = prelu_f(v.z, slope); v.w = prelu_f(v.w, slope);
+    constexpr int UB = 4;   // HBM loads in flight per thread before the first LDS write
+    for (int i0 = threadIdx.x; i0 < n4; i0 += UB * kBlock) {
+      float4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i = i0 + u * kBlock;
+        v[u] = i < n4 ? g4[i] : float4{0.f, 0.f, 0.f, 0.f};
       }
-      float* d = lds + row * LD + col;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i = i0 + u * kBlock;
+        if (i < n4) {
+          const int e = i << 2;
+          const int row = e / TV;
+          const int col = e - row * TV;
+          if (do_prelu) {
+            v[u].x = prelu_f(v[u].x, slope); v[u].y = prelu_f(v[u].y, slope);
+            v[u].z = prelu_f(v[u].z, slope); v[u].w = prelu_f(v[u].w, slope);
+          }
+          float* d = lds + row * LD + col;
+          d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+      }
     }
   } else {
     for (int e = threadIdx.x; e < nfloats; e += kBlock) {
@@ -97,10 +109,23 @@ struct TilePrefetch {
 template <int T, int V>
 __device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* lds, int nfloats) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
-  for (int e = threadIdx.x; e < nfloats; e += kBlock) {
-    const int row = e / TV;
-    const int col = e - row * TV;
-    g[e] = lds[row * LD + col];
+  if constexpr (TV % 4 == 0) {
+    float4* g4 = reinterpret_cast<float4*>(g);
+    const int n4 = nfloats >> 2;
+#pragma unroll 2
+    for (int i = threadIdx.x; i < n4; i += kBlock) {
+      const int e = i << 2;
+      const int row = e / TV;
+      const int col = e - row * TV;
+      const float* s = lds + row * LD + col;
+      g4[i] = float4{s[0], s[1], s[2], s[3]};
+    }
+  } else {
+    for (int e = threadIdx.x; e < nfloats; e += kBlock) {
+      const int row = e / TV;
+      const int col = e - row * TV;
+      g[e] = lds[row * LD + col];
+    }
   }
 }
 

@@ -1,0 +1,101 @@
+"""Turns the rocprofv3 output of tools/collect_profiles.sh (under gpurun_out/<tag>/) into the committed summaries:
+  profiles/<tag>_bench_kernel_stats.csv   rocprofv3's own --stats table (per kernel symbol)
+  profiles/<tag>_kernel_instances.csv     per (kernel, k-th launch of that kernel inside a step, grid) = per layer: calls, avg/min us, share of GPU time
+  profiles/<tag>_hbm_traffic_pmc.csv      FETCH_SIZE / WRITE_SIZE per instance (KB, averaged over dispatches)
+  profiles/<tag>_hbm_traffic.json         HBM bytes / launch for the kernels bench.py prices: (2*FETCH_SIZE + WRITE_SIZE) * 1024
+                                          (gfx950: FETCH_SIZE reports half of a wide coalesced stream; guide's correction)
+"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name: str) -> str:
+    m = re.search(r"coskad::(\w+(?:<[^>]*>)?)", name)
+    return m.group(1).replace(" ", "") if m else name.split("(")[0]
+
+
+def one(pattern: str) -> str:
+    hits = glob.glob(pattern, recursive=True)
+    if not hits:
+        sys.exit(f"missing {pattern}")
+    return hits[0]
+
+
+def main(tag: str) -> None:
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    shutil.copy(one(f"{src}/stats/**/*kernel_stats.csv"), f"{dst}/{tag}_bench_kernel_stats.csv")
+
+    # dynamic LDS is not in the trace, so launches of one symbol are told apart by their position inside a step:
+    # the k-th launch of a symbol in every step is the same layer ("slot" k; steps = number of k_adam_tick launches)
+    def slotted(rows, name_col):
+        rows = sorted(rows, key=lambda r: int(r["Start_Timestamp"]))
+        steps = max(1, sum(1 for r in rows if short(r[name_col]) == "k_adam_tick"))
+        count = defaultdict(int)
+        for r in rows:
+            count[short(r[name_col])] += 1
+        seen = defaultdict(int)
+        for r in rows:
+            k = short(r[name_col])
+            per = count[k] // steps if count[k] % steps == 0 else 0
+            slot = seen[k] % per if per else -1
+            seen[k] += 1
+            yield k, slot, r
+
+    inst = defaultdict(list)
+    with open(one(f"{src}/stats/**/*kernel_trace.csv")) as f:
+        for k, slot, r in slotted(list(csv.DictReader(f)), "Kernel_Name"):
+            key = (k, slot, int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))
+            inst[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    total = sum(sum(v) for v in inst.values())
+    rows = sorted(inst.items(), key=lambda kv: -sum(kv[1]))
+    with open(f"{dst}/{tag}_kernel_instances.csv", "w") as f:
+        f.write("kernel,launch_slot_in_step,workgroups,calls,avg_us,min_us,share_pct\n")
+        for (k, lds, wg), d in rows:
+            f.write(f"\"{k}\",{lds},{wg},{len(d)},{sum(d) / len(d):.1f},{min(d):.1f},{100 * sum(d) / total:.2f}\n")
+
+    pmc = defaultdict(lambda: defaultdict(list))
+    for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        with open(one(f"{src}/{sub}/**/*counter_collection.csv")) as f:
+            for k, slot, r in slotted([r for r in csv.DictReader(f) if r["Counter_Name"] == counter], "Kernel_Name"):
+                key = (k, slot, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+                pmc[key][counter].append(float(r["Counter_Value"]))
+    summary = {}
+    with open(f"{dst}/{tag}_hbm_traffic_pmc.csv", "w") as f:
+        f.write("kernel,launch_slot_in_step,workgroups,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_MB_per_launch\n")
+        for key, c in sorted(pmc.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0]))):
+            fe = sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"]))
+            wr = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"]))
+            hbm = (2 * fe + wr) * 1024
+            summary[key] = (fe, wr, hbm)
+            f.write(f"\"{key[0]}\",{key[1]},{key[2]},{len(c['FETCH_SIZE'])},{fe:.1f},{wr:.1f},{hbm / 1e6:.1f}\n")
+
+    def biggest(prefix: str):
+        c = [(k, v) for k, v in summary.items() if k[0].startswith(prefix)]
+        return max(c, key=lambda kv: kv[1][2]) if c else None
+
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, B=4096); "
+                   "counters are KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE reads "
+                   "1/2 of a wide coalesced stream; narrower accesses uncalibrated: upper bound)"}
+    for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2>"), ("layer_apply layer4", "k_layer_apply_m<12,17,4>")):
+        b = biggest(prefix)
+        if b:
+            (k, lds, wg), (fe, wr, hbm) = b
+            out[label] = {"kernel": k, "launch_slot_in_step": lds, "FETCH_SIZE_KB": round(fe, 1), "WRITE_SIZE_KB": round(wr, 1),
+                          "hbm_bytes_per_launch": int(hbm)}
+    with open(f"{dst}/{tag}_hbm_traffic.json", "w") as f:
+        json.dump(out, f, indent=1)
+    print(open(f"{dst}/{tag}_kernel_instances.csv").read())
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
