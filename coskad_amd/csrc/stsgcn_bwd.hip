@@ -74,11 +74,25 @@ template <int T, int V>
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ g, float* lds, int rows, int pbeg, int npos) {
   constexpr int TV = T * V, LDC = RedGeo<T, V>::LDC;
   const int n4 = npos >> 2;               // pbeg and npos are multiples of 4, TV % 4 == 0
-  for (int e = threadIdx.x; e < rows * n4; e += kBlock) {
-    const int row = e / n4, q4 = e - row * n4;
-    const float4 v = *reinterpret_cast<const float4*>(g + (size_t)row * TV + pbeg + 4 * q4);
-    float* d = lds + row * LDC + 4 * q4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  constexpr int UB = 3;   // HBM loads in flight per thread (64 rows x 17 float4 = 2.1 per thread)
+  const int n = rows * n4;
+  for (int e0 = threadIdx.x; e0 < n; e0 += UB * kBlock) {
+    float4 v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * kBlock;
+      const int row = e / n4, q4 = e - row * n4;
+      v[u] = e < n ? *reinterpret_cast<const float4*>(g + (size_t)row * TV + pbeg + 4 * q4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * kBlock;
+      if (e < n) {
+        const int row = e / n4, q4 = e - row * n4;
+        float* d = lds + row * LDC + 4 * q4;
+        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+      }
+    }
   }
 }
 
