@@ -98,7 +98,18 @@ __global__ __launch_bounds__(kBtlBlock) void k_btlnk_bwd(const float* __restrict
   for (int m = 0; m < 4; ++m) dw[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   float da = 0.f;
   const int nbeg = blockIdx.y * chunk, nend = min(B, nbeg + chunk);
+  // U rows of the tile (lane group q owns clips n0 + 4q + s), fetched one tile ahead of their use
+  auto load_u = [&](int n0, float4 (&u)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int nn = n0 + 4 * q + s;
+      u[s] = (kok && nn < nend) ? *reinterpret_cast<const float4*>(U + (size_t)nn * K + kc) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  float4 ucur[4], unext[4];
+  load_u(nbeg, ucur);
   for (int n0 = nbeg; n0 < nend; n0 += 16) {
+    load_u(n0 + 16, unext);
     // dX tile: A[i = clip][kk = j] = dz[n0+i][4g+kk]
     f32x4 dx[4];
 #pragma unroll
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(kBtlBlock) void k_btlnk_bwd(const float* __restrict
     for (int s = 0; s < 4; ++s) {
       const int nn = n0 + 4 * q + s;
       const bool ok = kok && nn < nend;
-      float4 u = ok ? *reinterpret_cast<const float4*>(U + (size_t)nn * K + kc) : float4{0.f, 0.f, 0.f, 0.f};
+      const float4 u = ucur[s];
       float4 x = u;
       if (pre) { x.x = prelu_f(u.x, a); x.y = prelu_f(u.y, a); x.z = prelu_f(u.z, a); x.w = prelu_f(u.w, a); }
       // dW[j][k] += dz[n][j] * x[n][k]:  A[i = j][kk = q] = dz[n0+4q+s][j = c]
@@ -137,6 +148,8 @@ __global__ __launch_bounds__(kBtlBlock) void k_btlnk_bwd(const float* __restrict
       }
       if (ok) *reinterpret_cast<float4*>(dU + (size_t)nn * K + kc) = g;
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ucur[s] = unext[s];
   }
   // dW partial: tile m, reg r <-> j = 4q + r, k = kc + m
   if (kok) {
