@@ -55,6 +55,14 @@ __host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * 
 
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
 
+// threadIdx.x behind an optimisation barrier: address arithmetic derived from it is recomputed where it is used
+// instead of being hoisted out of the persistent tile loop and held in VGPRs across every phase.
+__device__ __forceinline__ int tid_here() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 // wave-uniform value -> SGPR (lets hipcc use s_load for everything indexed by it)
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 

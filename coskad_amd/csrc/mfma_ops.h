@@ -38,12 +38,13 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict_
 // rows: valid rows of the image (row tiles of 16; rows beyond `rows` read as 0, never written)
 // TwL / AwL: LDS copies of T[V][T][T] and A[T][V][V].
 template <int T, int V, bool ADJ>
-__device__ __forceinline__ void temporal_mfma(float* img, int rows, const float* TwL) {
+__device__ __forceinline__ void temporal_mfma(float* img, int rows, const float* TwL, int tid = -1) {
   constexpr int LD = Geo<T, V>::LD;
   constexpr int KS = (T + 3) / 4;
   constexpr int RP = COSKAD_RP;   // row tiles per item: they share the B operand and give independent MFMA chains
   static_assert(T <= 16, "temporal_mfma: one 16-wide column tile");
-  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  if (tid < 0) tid = threadIdx.x;   // callers short of registers pass tid_here()
+  const int lane = tid & 63, wave = uniform(tid >> 6);
   const int i = lane & 15, k = lane >> 4;
   const int RT = (rows + 15) >> 4;
   const int RG = (RT + RP - 1) / RP;
@@ -86,14 +87,15 @@ __device__ __forceinline__ void temporal_mfma(float* img, int rows, const float*
 }
 
 template <int T, int V, bool ADJ>
-__device__ __forceinline__ void spatial_mfma(float* img, int rows, const float* AwL) {
+__device__ __forceinline__ void spatial_mfma(float* img, int rows, const float* AwL, int tid = -1) {
   constexpr int LD = Geo<T, V>::LD;
   constexpr int KS = (V + 3) / 4;
   constexpr int RP = COSKAD_RP;   // row tiles per item (share B, independent chains)
   // column tiles on MFMA; up to 2 leftover columns (V = 17, 18) are cheaper on the VALU
   constexpr int VX = (V > 16 && V - 16 <= 2) ? V - 16 : ((V > 32 && V - 32 <= 2) ? V - 32 : 0);
   constexpr int NT = (V - VX + 15) / 16;
-  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  if (tid < 0) tid = threadIdx.x;   // callers short of registers pass tid_here()
+  const int lane = tid & 63, wave = uniform(tid >> 6);
   const int i = lane & 15, k = lane >> 4;
   const int RT = (rows + 15) >> 4;
   const int RG = (RT + RP - 1) / RP;
@@ -178,15 +180,15 @@ __device__ __forceinline__ void spatial_mfma(float* img, int rows, const float* 
 }
 
 template <int T, int V, bool ADJ>
-__device__ __forceinline__ void gcn_mfma(float* img, int rows, const float* AwL, const float* TwL) {
+__device__ __forceinline__ void gcn_mfma(float* img, int rows, const float* AwL, const float* TwL, int tid = -1) {
   if constexpr (!ADJ) {
-    temporal_mfma<T, V, false>(img, rows, TwL);
+    temporal_mfma<T, V, false>(img, rows, TwL, tid);
     __syncthreads();
-    spatial_mfma<T, V, false>(img, rows, AwL);
+    spatial_mfma<T, V, false>(img, rows, AwL, tid);
   } else {
-    spatial_mfma<T, V, true>(img, rows, AwL);
+    spatial_mfma<T, V, true>(img, rows, AwL, tid);
     __syncthreads();
-    temporal_mfma<T, V, true>(img, rows, TwL);
+    temporal_mfma<T, V, true>(img, rows, TwL, tid);
   }
 }
 

@@ -427,7 +427,14 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
     const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
     float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
-    int Co) {
+    int Co
+#ifdef COSKAD_ABLATE
+    , int abl
+#endif
+    ) {
+#ifndef COSKAD_ABLATE
+  constexpr int abl = 0;
+#endif
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   constexpr int PS = (TV + 31) / 32;
 #ifndef COSKAD_XBF
@@ -467,14 +474,22 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
   copy_to_lds(ktl, kt, CiP);
   copy_to_lds(krl, kr, CiP);
   const int wave = uniform(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int j = lane & 15, kk = lane >> 4;
   const bool mine = wave < PS;                 // this wave's strip
-  const int p = 32 * wave + 2 * j;
-  const bool pok = mine && p < TV;
-  const int pc = p < TV ? p : TV - 2;
   const int KZS = KZ / 4, K1S = K1 / 4;
   float da = 0.f;
+  int tid = 0, lane = 0, j = 0, kk = 0, p = 0, pc = 0;
+  bool pok = false;
+  // lane geometry behind an optimisation barrier, refreshed per clip: the address arithmetic of every phase is
+  // then recomputed where it is used instead of being hoisted out of the clip loop and parked in VGPRs
+  auto refresh = [&]() {
+    tid = tid_here();
+    lane = tid & 63;
+    j = lane & 15; kk = lane >> 4;
+    p = 32 * wave + 2 * j;
+    pok = mine && p < TV;
+    pc = p < TV ? p : TV - 2;
+  };
+  refresh();
   // acc += W[0:Ci] . img over this wave's strip; 4 k-steps of LDS operands in flight before their MFMAs
   auto lds_conv = [&](const float* Wk, f32x4 (&acc)[OTI][2]) {
     for (int s0 = 0; s0 < KZS; s0 += 4) {
@@ -509,15 +524,16 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
       accA[t][0] = accA[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       accB[t][0] = accB[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    refresh();
     __syncthreads();
-    stage_rows<T, V>(gin, img, Ci * TV, pre, a_in);
+    if (!(abl & 1)) stage_rows<T, V>(gin, img, Ci * TV, pre, a_in, tid);
     __syncthreads();
     // phase 0: accB = Kr . X  (LDS, before the mixing overwrites X)
-    if (mine) {
+    if (mine && !(abl & 2)) {
       lds_conv(WlB + K1 * CiP, accB);
     }
     __syncthreads();
-    gcn_mfma<T, V, false>(img, Ci, AwL, TwL);
+    if (!(abl & 4)) gcn_mfma<T, V, false>(img, Ci, AwL, TwL, tid);
     __syncthreads();
     // phase A: accA = Kt.Z (LDS) + Bt.dU ; accB += Br.dU -- ONE pass over dU
     if (mine) {
@@ -530,8 +546,8 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
       };
 #pragma unroll
       for (int u = 0; u < XB; ++u) cur[u] = gload(u);
-      lds_conv(WlA, accA);
-      for (int g0 = 0; g0 < K1S; g0 += XB) {
+      if (!(abl & 16)) lds_conv(WlA, accA);
+      for (int g0 = 0; g0 < ((abl & 8) ? 0 : K1S); g0 += XB) {
 #pragma unroll
         for (int u = 0; u < XB; ++u) nxt[u] = gload(g0 + XB + u);
 #pragma unroll
@@ -569,14 +585,26 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
       }
     }
     __syncthreads();
-    if (dZout) {
-      unstage_rows<T, V>(dZout + (size_t)clip * Ci * TV, img, Ci * TV);
+    if (dZout && !(abl & 32)) {
+      unstage_rows<T, V>(dZout + (size_t)clip * Ci * TV, img, Ci * TV, tid);
       __syncthreads();   // the adjoint mixing below overwrites dZ in place: every wave must have copied it out
     }
     if (dIn) {
-      gcn_mfma<T, V, true>(img, Ci, AwL, TwL);
+      // the PReLU masks of the epilogue (pre-activations of the layer input) are fetched before the adjoint mixing,
+      // so their latency is covered by it
+      float2 um[OTI][4];
+      if (pre && pok) {
+#pragma unroll
+        for (int t = 0; t < OTI; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 16 * t + 4 * kk + r;
+            um[t][r] = *reinterpret_cast<const float2*>(gin + (size_t)(o < Ci ? o : Ci - 1) * TV + p);
+          }
+      }
+      if (!(abl & 64)) gcn_mfma<T, V, true>(img, Ci, AwL, TwL, tid);
       __syncthreads();
-      if (pok) {
+      if (pok && !(abl & 128)) {
         float* dg = dIn + (size_t)clip * Ci * TV;
 #pragma unroll
         for (int t = 0; t < OTI; ++t)
@@ -587,7 +615,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
               float g0 = accB[t][0][r] + krl[o] + img[o * LD + p];
               float g1 = accB[t][1][r] + krl[o] + img[o * LD + p + 1];
               if (pre) {
-                const float2 u = *reinterpret_cast<const float2*>(gin + (size_t)o * TV + p);
+                const float2 u = um[t][r];
                 if (u.x < 0.f) da = fmaf(g0, u.x, da);
                 if (u.y < 0.f) da = fmaf(g1, u.y, da);
                 g0 = u.x > 0.f ? g0 : a_in * g0;
@@ -1000,12 +1028,19 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
                        w.dz, dap, B, Ci, Co, NB);                                                       \
   } while (0)
+#ifdef COSKAD_ABLATE
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("COSKAD_ABL"); abl = e ? atoi(e) : 0; }
+#define ABL_ARG , abl
+#else
+#define ABL_ARG
+#endif
 #define LAUNCH_DF(OTI)                                                                                  \
   do {                                                                                                  \
     auto k = k_bwd_data_f<T, V, OTI>;                                                                   \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
-                       w.dz, dap, B, Ci, Co);                                                           \
+                       w.dz, dap, B, Ci, Co ABL_ARG);                                                   \
   } while (0)
     static int fused_ok = -1;
     if (fused_ok < 0) { const char* e = getenv("COSKAD_BWD_UNFUSED"); fused_ok = (e && e[0] == '1') ? 0 : 1; }
@@ -1043,7 +1078,10 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
     auto k = k_bwd_gcn_params<T, V>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB);
+    {
+      ProbeScope probe(KID_GCN_PARAMS, Ci, Co, st);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB);
+    }
     if ((rc = check_launch("bwd_gcn_params"))) return rc;
     hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, w.partials, grid, E, 0,
                        T * V * V, dA, accumulate);

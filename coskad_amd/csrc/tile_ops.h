@@ -23,13 +23,14 @@ namespace coskad {
 // optionally applying PReLU on the way (the producer layer stores pre-activations).
 template <int T, int V>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* lds, int nfloats,
-                                           bool do_prelu, float slope) {
+                                           bool do_prelu, float slope, int tid = -1) {
+  if (tid < 0) tid = threadIdx.x;
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   if constexpr (TV % 4 == 0) {
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const int n4 = nfloats >> 2;
     constexpr int UB = 4;   // HBM loads in flight per thread before the first LDS write
-    for (int i0 = threadIdx.x; i0 < n4; i0 += UB * kBlock) {
+    for (int i0 = tid; i0 < n4; i0 += UB * kBlock) {
       float4 v[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -107,13 +108,14 @@ struct TilePrefetch {
 
 // Write the LDS row image back to a contiguous HBM tile.
 template <int T, int V>
-__device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* lds, int nfloats) {
+__device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* lds, int nfloats, int tid = -1) {
+  if (tid < 0) tid = threadIdx.x;
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   if constexpr (TV % 4 == 0) {
     float4* g4 = reinterpret_cast<float4*>(g);
     const int n4 = nfloats >> 2;
 #pragma unroll 2
-    for (int i = threadIdx.x; i < n4; i += kBlock) {
+    for (int i = tid; i < n4; i += kBlock) {
       const int e = i << 2;
       const int row = e / TV;
       const int col = e - row * TV;
