@@ -16,10 +16,10 @@
 
 namespace coskad {
 
-constexpr int kMaxGrid = 512;  // persistent blocks of the reduction kernels (= partials to sum)
+constexpr int kMaxGrid = 768;  // persistent blocks of the reduction kernels (= partials to sum)
 
 template <int T, int V, int NTC>
-__global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict__ in,
+__global__ __launch_bounds__(kBlock, (NTC <= 2 ? 6 : 4)) void k_fwd_moments(const float* __restrict__ in,
                                                        const float* __restrict__ Aw,
                                                        const float* __restrict__ Tw,
                                                        const float* __restrict__ in_slope,
@@ -27,8 +27,8 @@ __global__ __launch_bounds__(kBlock) void k_fwd_moments(const float* __restrict_
                                                        int NB, int need_x) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* scratch = lds + NB * Ci * LD;  // kScratchFloats
-  float* AwL = scratch + kScratchFloats;
+  float* scratch = lds;                 // kScratchFloats, aliased onto the row image (only used after the tile loop)
+  float* AwL = lds + max(NB * Ci * LD, kScratchFloats);
   float* TwL = AwL + T * V * V;
   copy_to_lds(AwL, Aw, T * V * V);
   copy_to_lds(TwL, Tw, V * T * T);
@@ -234,7 +234,8 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   const int E = 2 * (Ci * Ci + Ci);
   int NB = Ci >= 32 ? 1 : 32 / Ci;   // 32 rows per tile (2 MFMA row tiles)
   if (NB > B) NB = B;
-  const size_t lds = ((size_t)NB * Ci * LD + kScratchFloats + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
+  const size_t img = (size_t)NB * Ci * LD > (size_t)kScratchFloats ? (size_t)NB * Ci * LD : (size_t)kScratchFloats;
+  const size_t lds = (img + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
   if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "train_stats: LDS %zu too large", lds);
   const int ntiles = ceil_div(B, NB);
   const int grid = ntiles < kMaxGrid ? ntiles : kMaxGrid;
