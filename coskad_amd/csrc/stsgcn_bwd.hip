@@ -23,7 +23,7 @@
 
 namespace coskad {
 
-constexpr int kMaxGridBwd = 512;
+constexpr int kMaxGridBwd = 768;   // persistent blocks: up to three 512-thread blocks per CU
 
 // ---------------------------------------------------------------------------------------
 // 1. reductions.  LDS: X image (nb*Ci rows) then dU image (nb*Co rows) then 1024 scratch.
@@ -97,7 +97,7 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ g, float* 
 }
 
 template <int T, int V, int NTO, int NTC>
-__global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__ in,
+__global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce(const float* __restrict__ in,
                                                       const float* __restrict__ dU,
                                                       const float* __restrict__ Aw,
                                                       const float* __restrict__ Tw,
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(kBlock) void k_bwd_reduce(const float* __restrict__
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldx = lds;                         // X / Z image: NB*Ci rows x LD
   float* ldu = lds + NB * Ci * LD;          // dU slab: NB*Co rows x LDC
-  float* scratch = ldu + NB * Co * LDC;     // kScratchFloats
-  float* AwL = scratch + kScratchFloats;
+  float* scratch = lds;                     // kScratchFloats, aliased onto the images (only used after the tile loop)
+  float* AwL = lds + max(NB * Ci * LD + NB * Co * LDC, kScratchFloats);
   float* TwL = AwL + T * V * V;
   copy_to_lds(AwL, Aw, T * V * V);
   copy_to_lds(TwL, Tw, V * T * T);
@@ -966,15 +966,21 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     int NB = Ci >= 32 ? 1 : 32 / Ci;
     if (NB > B) NB = B;
     auto red_lds = [&](int nb_) {
-      return ((size_t)nb_ * Ci * LD + (size_t)nb_ * Co * RedGeo<T, V>::LDC + kScratchFloats + (size_t)T * V * V +
-              (size_t)V * T * T) * sizeof(float);
+      size_t img = (size_t)nb_ * Ci * LD + (size_t)nb_ * Co * RedGeo<T, V>::LDC;
+      if (img < (size_t)kScratchFloats) img = kScratchFloats;
+      return (img + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
     };
-    while (NB > 1 && red_lds(NB) > 76 * 1024) --NB;   // keep two blocks per CU
+    const int nto = ceil_div(Co, 16), ntc = ceil_div(Ci, 16);
+    // blocks per CU: three when the accumulators are small enough for 6 waves/SIMD and the images fit a third of
+    // the LDS (fewer clips per tile if need be), else two
+    const bool three = nto * ntc <= 2;
+    const size_t lds_cap = three ? (size_t)52 * 1024 : (size_t)76 * 1024;   // (LDS is allocated in coarse granules)
+    while (NB > 1 && red_lds(NB) > lds_cap) --NB;
     const size_t lds = red_lds(NB);
     if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
     const int ntiles = ceil_div(B, NB);
-    const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
-    const int nto = ceil_div(Co, 16), ntc = ceil_div(Ci, 16);
+    int grid = 256 * ((three && lds <= lds_cap) ? 3 : (lds <= (size_t)80 * 1024 ? 2 : 1));
+    if (grid > ntiles) grid = ntiles;
     const int need_q = Wr != nullptr;
 #define LAUNCH_R(NTO, NTC)                                                                              \
   do {                                                                                                  \
@@ -1075,7 +1081,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     const size_t lds = ((size_t)2 * NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
     if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
     const int ntiles = ceil_div(B, NB);
-    const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
+    const int grid = ntiles < 512 ? ntiles : 512;
     auto k = k_bwd_gcn_params<T, V>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     {
@@ -1103,7 +1109,7 @@ static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* A
   const int NB = rows < 32 ? rows : 32;
   const size_t lds = ((size_t)2 * NB * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
   const int ntiles = ceil_div(rows, NB);
-  const int grid = ntiles < kMaxGridBwd ? ntiles : kMaxGridBwd;
+  const int grid = ntiles < 512 ? ntiles : 512;
   float* partials = reinterpret_cast<float*>(ws);
   auto k = k_bwd_gcn_params<T, V>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -238,7 +238,9 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   const size_t lds = (img + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
   if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "train_stats: LDS %zu too large", lds);
   const int ntiles = ceil_div(B, NB);
-  const int grid = ntiles < kMaxGrid ? ntiles : kMaxGrid;
+  // persistent blocks: as many 512-thread blocks per CU as LDS (coarse granules: keep a margin) and VGPRs allow
+  const int per_cu = lds <= (size_t)52 * 1024 && Ci <= 32 ? 3 : (lds <= (size_t)80 * 1024 ? 2 : 1);
+  const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
   float* partials = reinterpret_cast<float*>(ws);
   double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + round_up((int)(kMaxGrid * (size_t)E * sizeof(float)), 256));
   const int need_x = Wr != nullptr;
