@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 T, V, C_IN = 12, 17, 2
 CHANNELS, HID, LATENT = [32, 16, 32], 64, 16
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
@@ -168,6 +169,13 @@ def main():
                     "traffic_source": "profiles/r01_hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE, B=4096)",
                     "algorithmic_bytes_per_launch": byts,
                     "avg_launch_us": round(probe_ms.value * 1e3, 2), "launches": probe_n.value}
+            # the same launches against the fp32 MFMA roof: convs Bt.dU, Br.dU (C_in x C_out each),
+            # Kt.Z, Kr.X (C_in x C_in each) + the mixing and its adjoint; intensity 31 FLOP/B > ridge 19.6
+            ci, co = CHANNELS[-1], HID
+            flops = B * (2 * T * V * (2 * ci * co + 2 * ci * ci) + 2 * ci * 2 * T * V * (T + V))
+            tf = flops / (probe_ms.value * 1e-3) / 1e12
+            roof["mfma_f32"] = {"achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": flops}
         if fwd_n.value:
             byts = B * tvb * (CHANNELS[-1] + HID)        # layer 4 forward: read 32 channels, write 64
             ach = byts / (fwd_ms.value * 1e-3) / 1e9
