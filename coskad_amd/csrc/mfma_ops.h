@@ -196,182 +196,11 @@ __device__ __forceinline__ void gcn_mfma(float* img, int rows, const float* AwL,
 
 // ---- 1x1 convolutions of one clip as an MFMA GEMM ---------------------------------------
 //   Out[o][p] = bias[o] + sum_k Wl[k][o] * In_k[p]
-// K-image of the clip: k in [0, KZ) = rows of the LDS image `zimg` (KZ = Ci rounded up to 4,
-// rows >= Ci have zero weights), k in [KZ, KZ+KX) = rows of the global tensor `xg`
-// (stride TV, optional PReLU on load; KX = 0: no second source).
-// Work items = (position tile of 16, group of OTI output tiles); the 4 waves take items
-// round-robin.  Store: out[o*TV + p] (+ optional PReLU), o < Co, p < TV.
+// K-image of the clip: k in [0, KZ) = rows of the LDS image (KZ = Ci rounded up to 4, rows >= Ci have zero
+// weights), then rows of up to two global tensors (stride TV, optional PReLU on load): see conv_mfma_s below.
 namespace coskad {
 
-template <int T, int V, int OTI, class Epilogue>
-__device__ __forceinline__ void conv_mfma(const float* zimg, int KZ, int nz, const float* __restrict__ xg,
-                                          int KX, int nx, bool pre, float a_in, const float* Wl, int CoP,
-                                          int item0, int item_step, Epilogue&& epi) {
-  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
-  constexpr int PT = (TV + 15) / 16;
-  constexpr int XB = 8;   // global k-steps prefetched per item (covers C_in <= 32; more: second batch)
-  const int lane = threadIdx.x & 63;
-  const int j = lane & 15, kk = lane >> 4;
-  const int OG = (CoP / 16 + OTI - 1) / OTI;
-  const int nitems = PT * OG;
-  const int KXS = KX / 4, KZS = KZ / 4;
-
-  auto load_x = [&](int it, int s0, float (&xb)[XB]) {
-    const int pt = it / OG;
-    const int p = 16 * pt + j;
-    const int pc = p < TV ? p : TV - 1;
-#pragma unroll
-    for (int u = 0; u < XB; ++u) {
-      const int c = 4 * (s0 + u) + kk;
-      const int cc = c < nx ? c : nx - 1;
-      xb[u] = (s0 + u < KXS && it < nitems) ? xg[(size_t)cc * TV + pc] : 0.f;
-    }
-  };
-
-  float xcur[XB], xnext[XB];
-  if (KXS > 0) load_x(item0, 0, xcur);
-  for (int it = item0; it < nitems; it += item_step) {
-    const int pt = it / OG, og = it - pt * OG;
-    const int p = 16 * pt + j;
-    const int pc = p < TV ? p : TV - 1;
-    f32x4 acc[OTI];
-#pragma unroll
-    for (int t = 0; t < OTI; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wcol = Wl + 16 * og * OTI + j;
-    if (KXS > 0) load_x(it + item_step, 0, xnext);   // next item's X operands fly during this item
-    // LDS source: batches of 4 k-steps (12+ LDS reads in flight, then 4*OTI MFMAs)
-    for (int s0 = 0; s0 < KZS; s0 += 4) {
-      float b[4], a[4][OTI];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = 4 * (s0 + u) + kk;
-        const int cc = c < nz ? c : nz - 1;
-        const bool ok = s0 + u < KZS;
-        b[u] = ok ? zimg[cc * LD + pc] : 0.f;
-        const float* w = wcol + (ok ? c : 0) * CoP;
-#pragma unroll
-        for (int t = 0; t < OTI; ++t) a[u][t] = w[16 * t];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < OTI; ++t) acc[t] = mfma4(a[u][t], b[u], acc[t]);
-    }
-    // global source (prefetched)
-    for (int s0 = 0; s0 < KXS; s0 += XB) {
-      if (s0 > 0) load_x(it, s0, xcur);
-#pragma unroll
-      for (int u0 = 0; u0 < XB; u0 += 4) {
-        float a[4][OTI];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int st = s0 + u0 + u;
-          const float* w = wcol + (KZ + 4 * (st < KXS ? st : 0) + kk) * CoP;
-#pragma unroll
-          for (int t = 0; t < OTI; ++t) a[u][t] = w[16 * t];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float x = pre ? prelu_f(xcur[u0 + u], a_in) : xcur[u0 + u];   // 0 stays 0 beyond KXS
-#pragma unroll
-          for (int t = 0; t < OTI; ++t) acc[t] = mfma4(a[u][t], x, acc[t]);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < XB; ++u) xcur[u] = xnext[u];
-    // D[row = 4*kk + r][col = j]
-#pragma unroll
-    for (int t = 0; t < OTI; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) epi(16 * (og * OTI + t) + 4 * kk + r, p, acc[t][r]);
-  }
-}
-
-// Same GEMM with the weight (A) fragments held in registers: a wave works on ONE fixed output group
-// `og` for the whole kernel, so its fragments are loaded once per block.  KH = max k-steps per source
-// (8 covers C_in <= 32); callers fall back to conv_mfma for larger K.
-template <int OTI, int KH>
-struct ConvFrags {
-  float z[KH][OTI];   // weights of the LDS (Z) source, k-step s
-  float x[KH][OTI];   // weights of the global (X) source
-};
-
-template <int OTI, int KH>
-__device__ __forceinline__ void load_conv_frags(ConvFrags<OTI, KH>& f, const float* Wl, int CoP, int og, int KZ,
-                                                int KX) {
-  const int lane = threadIdx.x & 63;
-  const int i = lane & 15, kk = lane >> 4;
-#pragma unroll
-  for (int s = 0; s < KH; ++s)
-#pragma unroll
-    for (int t = 0; t < OTI; ++t) {
-      const int o = 16 * (og * OTI + t) + i;
-      f.z[s][t] = (4 * s < KZ && o < CoP) ? Wl[(4 * s + kk) * CoP + o] : 0.f;
-      f.x[s][t] = (4 * s < KX && o < CoP) ? Wl[(KZ + 4 * s + kk) * CoP + o] : 0.f;
-    }
-}
-
-template <int T, int V, int OTI, int KH, class Epilogue>
-__device__ __forceinline__ void conv_mfma_r(const float* zimg, int KZ, int nz, const float* __restrict__ xg,
-                                            int KX, int nx, bool pre, float a_in, const ConvFrags<OTI, KH>& f,
-                                            int og, int pt0, int pt_step, Epilogue&& epi) {
-  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
-  constexpr int PT = (TV + 15) / 16;
-  const int lane = threadIdx.x & 63;
-  const int j = lane & 15, kk = lane >> 4;
-  const int KZS = KZ / 4, KXS = KX / 4;
-  float xcur[KH], xnext[KH];
-  auto load_x = [&](int pt, float (&xb)[KH]) {
-    const int p = 16 * pt + j;
-    const int pc = p < TV ? p : TV - 1;
-#pragma unroll
-    for (int u = 0; u < KH; ++u) {
-      const int c = 4 * u + kk;
-      const int cc = c < nx ? c : nx - 1;
-      xb[u] = (u < KXS && pt < PT) ? xg[(size_t)cc * TV + pc] : 0.f;
-    }
-  };
-  if (KXS > 0) load_x(pt0, xcur);
-  for (int pt = pt0; pt < PT; pt += pt_step) {
-    const int p = 16 * pt + j;
-    const int pc = p < TV ? p : TV - 1;
-    if (KXS > 0) load_x(pt + pt_step, xnext);
-    float b[KH];
-#pragma unroll
-    for (int u = 0; u < KH; ++u) {
-      const int c = 4 * u + kk;
-      const int cc = c < nz ? c : nz - 1;
-      b[u] = u < KZS ? zimg[cc * LD + pc] : 0.f;
-    }
-    f32x4 acc[OTI];
-#pragma unroll
-    for (int t = 0; t < OTI; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < KH; ++u) {
-      if (u < KZS) {
-#pragma unroll
-        for (int t = 0; t < OTI; ++t) acc[t] = mfma4(f.z[u][t], b[u], acc[t]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < KH; ++u) {
-      if (u < KXS) {
-        const float x = pre ? prelu_f(xcur[u], a_in) : xcur[u];
-#pragma unroll
-        for (int t = 0; t < OTI; ++t) acc[t] = mfma4(f.x[u][t], x, acc[t]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < KH; ++u) xcur[u] = xnext[u];
-#pragma unroll
-    for (int t = 0; t < OTI; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) epi(16 * (og * OTI + t) + 4 * kk + r, p, acc[t][r]);
-  }
-}
-
-// LDS weight table of the folded layer: Wl[k][o], k over the padded K-image (see conv_mfma).
+// LDS weight table of the folded layer: Wl[k][o], k over the padded K-image.
 // src: [(2*Ci)][CoP] (rows 0..Ci-1: Z part, Ci..2Ci-1: X part)
 __device__ __forceinline__ void load_wfold_padded(float* Wl, const float* __restrict__ src, int Ci, int KZ,
                                                   int CoP, int nsrc) {

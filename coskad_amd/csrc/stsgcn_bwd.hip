@@ -680,7 +680,14 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
                                                           const float* __restrict__ Tw,
                                                           const float* __restrict__ in_slope,
                                                           float* __restrict__ partials, int B, int Ci,
-                                                          int NB) {
+                                                          int NB
+#ifdef COSKAD_ABLATE
+                                                          , int abl
+#endif
+                                                          ) {
+#ifndef COSKAD_ABLATE
+  constexpr int abl = 0;
+#endif
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   constexpr int NW = kBlock / 64;
   // dA is V x V per frame: MFMA tiles of 16 for the bulk; up to 2 leftover joints (V = 17, 18) on the VALU
@@ -726,78 +733,93 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
     const int rows = nb * Ci;
     const float* gin = in + (size_t)clip0 * Ci * TV;
     __syncthreads();
-    stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
-    stage_rows<T, V>(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
+    if (!(abl & 64)) stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
+    if (!(abl & 1)) stage_rows<T, V>(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
     __syncthreads();
-    temporal_mfma<T, V, false>(img1, rows, TwL);  // Y = temporal(X)
+    if (!(abl & 2)) temporal_mfma<T, V, false>(img1, rows, TwL);  // Y = temporal(X)
     __syncthreads();
     // dA[t] += Y[:, t, :]^T dZ[:, t, :]   (K = rows)
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
       const int t = tbeg + tt;
-      if (t < tend) {
-        for (int r0 = 0; r0 < rows; r0 += 4) {
-          const bool rok = r0 + k < rows;
-          const float* y = img1 + (rok ? r0 + k : 0) * LD + t * V;
-          const float* d = img2 + (rok ? r0 + k : 0) * LD + t * V;
-          float a[NTV], b[NTV];
+      if (t < tend && !(abl & 4)) {
+        // K = rows in batches of KB k-steps: all LDS operands of a batch are in flight before its MFMAs
+        constexpr int KB = 4;
+        for (int r0 = 0; r0 < rows; r0 += 4 * KB) {
+          float a[KB][NTV], b[KB][NTV], yx[KB][VXA], dx[KB][VXA];
 #pragma unroll
-          for (int q = 0; q < NTV; ++q) {
-            const int col = 16 * q + i;
-            const bool ok = rok && col < VM;
-            a[q] = ok ? y[col] : 0.f;
-            b[q] = ok ? d[col] : 0.f;
-          }
+          for (int u = 0; u < KB; ++u) {
+            const int r = r0 + 4 * u + k;
+            const bool rok = r < rows;
+            const float* y = img1 + (rok ? r : 0) * LD + t * V;
+            const float* d = img2 + (rok ? r : 0) * LD + t * V;
 #pragma unroll
-          for (int ta = 0; ta < NTV; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < NTV; ++tb)
-              accA[tt][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], accA[tt][ta][tb], 0, 0, 0);
-          if constexpr (VX > 0) {
-            float yx[VXA], dx[VXA];
-#pragma unroll
-            for (int x = 0; x < VX; ++x) {
-              yx[x] = rok ? y[VM + x] : 0.f;   // same address for the 16 lanes of a k group: broadcast
-              dx[x] = rok ? d[VM + x] : 0.f;
+            for (int q = 0; q < NTV; ++q) {
+              const int col = 16 * q + i;
+              const bool ok = rok && col < VM;
+              a[u][q] = ok ? y[col] : 0.f;
+              b[u][q] = ok ? d[col] : 0.f;
             }
 #pragma unroll
-            for (int x = 0; x < VX; ++x) {
+            for (int x = 0; x < VXA; ++x) {
+              yx[u][x] = (VX > 0 && rok) ? y[VM + x] : 0.f;   // same address for the 16 lanes of a k group: broadcast
+              dx[u][x] = (VX > 0 && rok) ? d[VM + x] : 0.f;
+            }
+          }
 #pragma unroll
-              for (int q = 0; q < NTV; ++q) {
-                pcol[tt][x][q] = fmaf(a[q], dx[x], pcol[tt][x][q]);   // dA[t][v = 16q+i][VM+x]
-                prow[tt][x][q] = fmaf(yx[x], b[q], prow[tt][x][q]);   // dA[t][VM+x][w = 16q+i]
+          for (int u = 0; u < KB; ++u) {
+#pragma unroll
+            for (int ta = 0; ta < NTV; ++ta)
+#pragma unroll
+              for (int tb = 0; tb < NTV; ++tb)
+                accA[tt][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ta], b[u][tb], accA[tt][ta][tb], 0, 0, 0);
+            if constexpr (VX > 0) {
+#pragma unroll
+              for (int x = 0; x < VX; ++x) {
+#pragma unroll
+                for (int q = 0; q < NTV; ++q) {
+                  pcol[tt][x][q] = fmaf(a[u][q], dx[u][x], pcol[tt][x][q]);   // dA[t][v = 16q+i][VM+x]
+                  prow[tt][x][q] = fmaf(yx[u][x], b[u][q], prow[tt][x][q]);   // dA[t][VM+x][w = 16q+i]
+                }
+#pragma unroll
+                for (int y2 = 0; y2 < VX; ++y2) pcor[tt][x][y2] = fmaf(yx[u][x], dx[u][y2], pcor[tt][x][y2]);
               }
-#pragma unroll
-              for (int y2 = 0; y2 < VX; ++y2) pcor[tt][x][y2] = fmaf(yx[x], dx[y2], pcor[tt][x][y2]);
             }
           }
         }
       }
     }
     __syncthreads();
-    spatial_mfma<T, V, true>(img2, rows, AwL);  // dY = spatial^T(dZ)
-    stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);  // X again (img1 is free: dA is done)
+    if (!(abl & 8)) spatial_mfma<T, V, true>(img2, rows, AwL);  // dY = spatial^T(dZ)
+    if (!(abl & 16)) stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);  // X again (img1 is free: dA is done)
     __syncthreads();
     // dT[v][t][q] += sum_rows X[t*V+v] dY[q*V+v]
 #pragma unroll
     for (int vv = 0; vv < VPW; ++vv) {
       const int v = vbeg + vv;
-      if (v < vend) {
-        for (int r0 = 0; r0 < rows; r0 += 4) {
-          const bool rok = r0 + k < rows;
-          const int row = rok ? r0 + k : 0;
-          float a[NTT], b[NTT];
+      if (v < vend && !(abl & 32)) {
+        constexpr int KB = 4;
+        for (int r0 = 0; r0 < rows; r0 += 4 * KB) {
+          float a[KB][NTT], b[KB][NTT];
 #pragma unroll
-          for (int ta = 0; ta < NTT; ++ta) {
-            const int t = 16 * ta + i;
-            a[ta] = (rok && t < T) ? img1[row * LD + t * V + v] : 0.f;
-            b[ta] = (rok && t < T) ? img2[row * LD + t * V + v] : 0.f;
+          for (int u = 0; u < KB; ++u) {
+            const int r = r0 + 4 * u + k;
+            const bool rok = r < rows;
+            const int row = rok ? r : 0;
+#pragma unroll
+            for (int ta = 0; ta < NTT; ++ta) {
+              const int t = 16 * ta + i;
+              a[u][ta] = (rok && t < T) ? img1[row * LD + t * V + v] : 0.f;
+              b[u][ta] = (rok && t < T) ? img2[row * LD + t * V + v] : 0.f;
+            }
           }
 #pragma unroll
-          for (int ta = 0; ta < NTT; ++ta)
+          for (int u = 0; u < KB; ++u)
 #pragma unroll
-            for (int tb = 0; tb < NTT; ++tb)
-              accT[vv][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], accT[vv][ta][tb], 0, 0, 0);
+            for (int ta = 0; ta < NTT; ++ta)
+#pragma unroll
+              for (int tb = 0; tb < NTT; ++tb)
+                accT[vv][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ta], b[u][tb], accT[vv][ta][tb], 0, 0, 0);
         }
       }
     }
@@ -1086,7 +1108,13 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     {
       ProbeScope probe(KID_GCN_PARAMS, Ci, Co, st);
+#ifdef COSKAD_ABLATE
+      static int ablg = -1;
+      if (ablg < 0) { const char* e = getenv("COSKAD_ABLG"); ablg = e ? atoi(e) : 0; }
+      hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB, ablg);
+#else
       hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB);
+#endif
     }
     if ((rc = check_launch("bwd_gcn_params"))) return rc;
     hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, w.partials, grid, E, 0,
@@ -1113,7 +1141,11 @@ static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* A
   float* partials = reinterpret_cast<float*>(ws);
   auto k = k_bwd_gcn_params<T, V>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef COSKAD_ABLATE
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB, 0);
+#else
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB);
+#endif
   hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, partials, grid, E, 0, T * V * V, dA, accumulate);
   hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(1024), 0, st, partials, grid, E, T * V * V, V * T * T, dT, accumulate);
   return check_launch("gcn_bwd_params");

@@ -64,48 +64,6 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* l
   }
 }
 
-// Software pipeline for persistent tile kernels: fetch() issues the NEXT tile's HBM loads into registers
-// (they fly while the current tile is computed); commit() writes them to the LDS row image.
-template <int T, int V, int PF>
-struct TilePrefetch {
-  float4 r[PF];
-  static_assert(Geo<T, V>::TV % 4 == 0, "tile prefetch uses float4");
-  __device__ __forceinline__ void fetch(const float* __restrict__ g, int nfloats) {
-    const float4* g4 = reinterpret_cast<const float4*>(g);
-    const int n4 = nfloats >> 2;
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int i = threadIdx.x + u * kBlock;
-      r[u] = i < n4 ? g4[i] : float4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  // `g` / `nfloats` must be those of the matching fetch()
-  __device__ __forceinline__ void commit(const float* __restrict__ g, float* lds, int nfloats, bool do_prelu,
-                                         float slope) const {
-    constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
-    const int n4 = nfloats >> 2;
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int i = threadIdx.x + u * kBlock;
-      if (i < n4) {
-        float4 v = r[u];
-        const int e = i << 2, row = e / TV, col = e - row * TV;
-        if (do_prelu) {
-          v.x = prelu_f(v.x, slope); v.y = prelu_f(v.y, slope);
-          v.z = prelu_f(v.z, slope); v.w = prelu_f(v.w, slope);
-        }
-        float* d = lds + row * LD + col;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
-    }
-    for (int e = PF * kBlock * 4 + threadIdx.x; e < nfloats; e += kBlock) {   // beyond the register window
-      const int row = e / TV, col = e - row * TV;
-      const float v = g[e];
-      lds[row * LD + col] = do_prelu ? prelu_f(v, slope) : v;
-    }
-  }
-};
-
 // Write the LDS row image back to a contiguous HBM tile.
 template <int T, int V>
 __device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* lds, int nfloats, int tid = -1) {
