@@ -96,9 +96,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    dev = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group(args.backend)  # "nccl" = RCCL on ROCm
+        if args.backend == "nccl":   # "nccl" = RCCL on ROCm; bind the communicator to this rank's GPU up front
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
 
     B = args.batch
     st = R.init_stse_state(C_IN, CHANNELS, HID, LATENT, T, V, seed=0)   # same weights on every rank
@@ -111,7 +115,7 @@ def main():
 
     def sync():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[dev]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
