@@ -201,13 +201,11 @@ __global__ __launch_bounds__(1024) void k_bwd_fold(
     float* __restrict__ dgs, float* __restrict__ dbs, float* __restrict__ dWr, float* __restrict__ dbr,
     float* __restrict__ dgr, float* __restrict__ dbr2, float* __restrict__ coef, int Ci, int Co,
     int accumulate) {
-  // LDS: doubles k2[2][Co], g1[2][Co], h[2][Co] (h = g1 sdU/n - k2 (W.mu)); floats W[2][Co*Ci], mu[2][Ci]
+  // LDS: doubles k2[2][Co], g1[2][Co], h[2][Co] (h = g1 sdU/n - k2 (W.mu)), red[E]; floats W[2][Co*Ci], mu[2][Ci]
   extern __shared__ double shd[];
   const bool ident = Wr == nullptr;
   const int CiP = round_up(Ci, 16);
-  const double* P = red;
-  const double* Q = red + Co * Ci;
-  const double* sdU = red + 2 * Co * Ci;
+  const int E = 2 * Co * Ci + Co;
   const float* WCs = stat + 2 * Ci;
   const float* WCr = WCs + Co * Ci;
   const float* istd_s = WCr + Co * Ci + Co;
@@ -215,13 +213,18 @@ __global__ __launch_bounds__(1024) void k_bwd_fold(
   double* k2 = shd;            // [2][Co]
   double* g1 = shd + 2 * Co;   // [2][Co]
   double* hh = shd + 4 * Co;   // [2][Co]
-  float* Wl = reinterpret_cast<float*>(shd + 6 * Co);  // [2][Co*Ci]
+  double* redl = shd + 6 * Co; // [E]: the fp64 batch reductions, staged once (the loops below walk them row-wise)
+  const double* P = redl;
+  const double* Q = redl + Co * Ci;
+  const double* sdU = redl + 2 * Co * Ci;
+  float* Wl = reinterpret_cast<float*>(redl + E);      // [2][Co*Ci]
   float* mul = Wl + 2 * Co * Ci;                       // [2][Ci]: muZ then muX
   float* wDZ = coef;
   float* kt = wDZ + (Co + Ci) * CiP;
   float* wDX = kt + CiP;
   float* kr = wDX + (Co + Ci) * CiP;
 
+  for (int i = threadIdx.x; i < E; i += blockDim.x) redl[i] = red[i];
   for (int i = threadIdx.x; i < Co * Ci; i += blockDim.x) {
     Wl[i] = Wt[i];
     Wl[Co * Ci + i] = ident ? 0.f : Wr[i];
@@ -1032,7 +1035,9 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if ((rc = check_launch("bwd_reduce_partials"))) return rc;
   }
   // 2. fold
-  hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(1024), 6 * Co * sizeof(double) + (2 * Co * Ci + 2 * Ci) * sizeof(float), st, w.red, (double)B * TV, stat,
+  const size_t fold_lds = (size_t)(6 * Co + 2 * Co * Ci + Co) * sizeof(double) + (size_t)(2 * Co * Ci + 2 * Ci) * sizeof(float);
+  if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_bwd_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
+  hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(1024), fold_lds, st, w.red, (double)B * TV, stat,
                      Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate);
   if ((rc = check_launch("bwd_fold"))) return rc;
   // 3. data path
