@@ -183,6 +183,77 @@ __global__ __launch_bounds__(kBlock) void k_mse_head(const float* __restrict__ z
   block_partials(vals, partials);
 }
 
+// Mahalanobis head (eval_utils.py:28-38; staticCenter.py:178-181).  slots: [0] sum dist, [1..L] sum z, [17] #clips,
+// [18] sum |z|.  dist = sqrt(d^T VI d), d = z - c;  d dist / dz = (VI + VI^T) d / (2 dist).
+__global__ __launch_bounds__(kBlock) void k_mahalanobis_head(const float* __restrict__ z,
+                                                            const float* __restrict__ cvec,
+                                                            const float* __restrict__ VI,
+                                                            float* __restrict__ dz, float* __restrict__ score,
+                                                            float* __restrict__ partials, int B, int L,
+                                                            float gscale) {
+  __shared__ float vi[LMAX * LMAX];
+  for (int e = threadIdx.x; e < LMAX * LMAX; e += kBlock) {
+    const int r = e / LMAX, q = e - r * LMAX;
+    vi[e] = (r < L && q < L) ? VI[r * L + q] : 0.f;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  float vals[kHeadSlots];
+#pragma unroll
+  for (int k = 0; k < kHeadSlots; ++k) vals[k] = 0.f;
+  if (n < B) {
+    const Vec u = load_vec(z + (size_t)n * L, L), c = load_vec(cvec, L);
+    Vec d, w, wt;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) { d.v[j] = j < L ? u.v[j] - c.v[j] : 0.f; w.v[j] = 0.f; wt.v[j] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < LMAX; ++r)
+#pragma unroll
+      for (int q = 0; q < LMAX; ++q) {
+        const float a = vi[r * LMAX + q];          // wave-uniform address: LDS broadcast
+        w.v[r] = fmaf(a, d.v[q], w.v[r]);          // (VI d)[r]
+        wt.v[q] = fmaf(a, d.v[r], wt.v[q]);        // (VI^T d)[q]
+      }
+    const float dist = sqrtf(dot(d, w));
+    vals[0] = dist;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) vals[1 + j] = u.v[j];
+    vals[LMAX + 1] = 1.f;
+    vals[LMAX + 2] = sqrtf(dot(u, u));
+    if (score) score[n] = dist;
+    if (dz) {
+      Vec g;
+      const float inv = gscale / (2.f * dist);     // dist == 0: inf * 0 = NaN, as torch.sqrt's backward gives
+#pragma unroll
+      for (int j = 0; j < LMAX; ++j) g.v[j] = (w.v[j] + wt.v[j]) * inv;
+      store_vec(dz + (size_t)n * L, g, L);
+    }
+  }
+  block_partials(vals, partials);
+}
+
+// gram (+)= sum_n z_n z_n^T  [L x L]; one block, thread (i, j), clips staged through LDS in fixed order.
+// Sigma (z-mu)(z-mu)^T for any mu follows from it and the [1..L], [17] slots (batch_cov_mat_step, staticCenter.py:40-46).
+__global__ __launch_bounds__(LMAX * LMAX) void k_gram(const float* __restrict__ z, float* __restrict__ gram, int B,
+                                                     int L, int accumulate) {
+  constexpr int CH = 256;
+  __shared__ float zs[CH * LMAX];
+  const int i = threadIdx.x / LMAX, j = threadIdx.x % LMAX;
+  float s = 0.f;
+  for (int n0 = 0; n0 < B; n0 += CH) {
+    const int nc = min(CH, B - n0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nc * L; e += LMAX * LMAX) {
+      const int r = e / L, q = e - r * L;
+      zs[r * LMAX + q] = z[(size_t)(n0 + r) * L + q];
+    }
+    __syncthreads();
+    if (i < L && j < L)
+      for (int r = 0; r < nc; ++r) s = fmaf(zs[r * LMAX + i], zs[r * LMAX + j], s);
+  }
+  if (i < L && j < L) gram[i * L + j] = accumulate ? gram[i * L + j] + s : s;
+}
+
 // Poincare head.  slots: [0] sum dist, [1..L] sum gamma*zh, [17] sum (gamma-1), [18] sum |zh|
 __global__ __launch_bounds__(kBlock) void k_poincare_head(const float* __restrict__ z,
                                                          const float* __restrict__ cvec,
@@ -368,6 +439,23 @@ int coskad_mse_head_f32(const float* z, const float* c, float* dz, float* score,
   if (stats || acc)
     hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(64), 0, stream, ws, P, 1.f / ((float)B * (float)L), stats, acc);
   return check_launch("mse_head");
+}
+
+/* Mahalanobis one-class head: loss = mean_n sqrt((z_n-c)^T VI (z_n-c)) (utils/eval_utils.py:28-38 as called at
+ * euclidean_encoder_staticCenter.py:181), gradient, per-window score (eval_utils.py:41-47), centre sums as in the
+ * MSE head, and optionally gram (+)= sum_n z_n z_n^T (the second moments behind compute_inv_cov_mat, :133-142). */
+int coskad_mahalanobis_head_f32(const float* z, const float* c, const float* VI, float* dz, float* score,
+                                float* stats, float* acc, float* gram, int gram_accumulate, float upstream,
+                                float* ws, int B, int L, hipStream_t stream) {
+  if (!z || !c || !VI || !ws) return fail(COSKAD_ERR_ARG, "mahalanobis_head: null pointer");
+  if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "mahalanobis_head: B=%d latent=%d (max %d)", B, L, LMAX);
+  const int P = ceil_div(B, kBlock);
+  hipLaunchKernelGGL(k_mahalanobis_head, dim3(P), dim3(kBlock), 0, stream, z, c, VI, dz, score, ws, B, L,
+                     upstream / (float)B);
+  if (stats || acc)
+    hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(64), 0, stream, ws, P, 1.f / (float)B, stats, acc);
+  if (gram) hipLaunchKernelGGL(k_gram, dim3(1), dim3(LMAX * LMAX), 0, stream, z, gram, B, L, gram_accumulate);
+  return check_launch("mahalanobis_head");
 }
 
 /* Poincare one-class head (hyperbolic_encoder.py:147,157; utils/hyper_math.py formulas):

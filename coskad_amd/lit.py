@@ -44,12 +44,13 @@ class LitEncoder(nn.Module):
         self.hparams = Namespace(args=args)                  # save_hyperparameters()
         self.hyperbolic = bool(getattr(args, "hyperbolic", False) if hyperbolic is None else hyperbolic)
         self.static_center = bool(getattr(args, "static_center", False))
+        self.distance = str(getattr(args, "distance", "euclidean")).lower()   # staticCenter.py:66,84: 'mahalanobis' option
         channels = list(getattr(args, "channels", [32, 16, 32]))
         self.eps = float(getattr(args, "center_tolerance", 1e-3))
         self.model = STSE(c_in=args.num_coords, h_dim=args.h_dim, latent_dim=args.latent_dim,
                           n_frames=args.dataset_seg_len, dropout=args.dropout, n_joints=_joints(args),
                           channels=channels, projector=getattr(args, "projector", "linear"),
-                          encoder_type=getattr(args, "encoder_type", "STS_GCN"))
+                          encoder_type=getattr(args, "encoder_type", "STS_GCN"), distance=self.distance)
         self.learning_rate = args.opt_lr
         self.batch_size = getattr(args, "dataset_batch_size", 2048)
         self.logged: Dict[str, float] = {}
@@ -73,16 +74,23 @@ class LitEncoder(nn.Module):
             return
         dev = next(self.model.parameters()).device
         acc = torch.zeros(ops.HEAD_SLOTS, device=dev)
+        L = self.model.latent_dim
+        maha = self.distance == 'mahalanobis' and not self.hyperbolic
+        gram = torch.zeros(L, L, device=dev) if maha else None
+        eye = torch.eye(L, device=dev) if maha else None
         self.model.eval()
         with torch.no_grad():
             for batch in train_loader():
                 z = self.model(batch[0].to(dev))
                 if self.hyperbolic:
                     ops.poincare_head(z, None, need_grad=False, acc=acc)
+                elif maha:                                  # centre sums + second moments in one pass
+                    ops.mahalanobis_head(z, self.model.c, eye, need_grad=False, acc=acc, gram=gram)
                 else:
                     ops.mse_head(z, self.model.c, need_grad=False, acc=acc)
         parallel.allreduce_sum_(acc)
-        L = self.model.latent_dim
+        if maha:
+            parallel.allreduce_sum_(gram)
         self.n_samples = float(acc[17]) if not self.hyperbolic else None
         if self.hyperbolic:
             c = ops.midpoint_finalize(acc, L)
@@ -93,9 +101,13 @@ class LitEncoder(nn.Module):
         else:
             # dynamicCenter.py:96-100: the initial centre is stored but model.c stays 0 during the first epoch
             self._temp = ops.center_finalize(acc, 0.0, L)
+        if maha:                                            # staticCenter.py:124-127,133-142
+            from .trainer import inv_cov_from_moments
+            mu = self.model.c if self.static_center else self._temp
+            self.model.inv_cov_matrix.copy_(inv_cov_from_moments(gram, acc, mu, L))
         self.model.train()
         self._engine = STSETrainStep(self.model, lr=self.learning_rate, alpha=float(getattr(self.args, "alpha", 0.0)),
-                                     head="poincare" if self.hyperbolic else "euclidean")
+                                     head="poincare" if self.hyperbolic else ("mahalanobis" if maha else "euclidean"))
         self._epoch = 0
 
     # ---- one optimisation step -----------------------------------------------------------
@@ -111,6 +123,8 @@ class LitEncoder(nn.Module):
 
     def on_train_epoch_end(self) -> None:
         eng = self._engine
+        if eng.head == 'mahalanobis':                      # staticCenter.py:146-147 (before the centre update)
+            eng.refresh_inv_cov(self.model.c)
         if self.hyperbolic:
             if not self.static_center:                     # hyperbolic_encoder.py:175-183
                 c = eng.refresh_center()
@@ -158,6 +172,9 @@ class LitEncoder(nn.Module):
         """per-window anomaly score on the device (eval_utils.py:63-67)."""
         if self.hyperbolic:
             _, _, _, score = ops.poincare_head(hidden.contiguous(), self.model.c, need_grad=False, need_score=True)
+        elif self.distance == 'mahalanobis':               # eval_utils.py:41-47
+            _, _, score = ops.mahalanobis_head(hidden.contiguous(), self.model.c, self.model.inv_cov_matrix,
+                                               need_grad=False, need_score=True)
         else:
             _, _, score = ops.mse_head(hidden.contiguous(), self.model.c, need_grad=False, need_score=True)
         return score

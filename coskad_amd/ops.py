@@ -213,6 +213,21 @@ def mse_head(z, c, need_grad=True, need_score=False, acc=None, upstream=1.0, ws=
     return stats, dz, score
 
 
+def mahalanobis_head(z, c, VI, need_grad=True, need_score=False, acc=None, gram=None, gram_accumulate=True,
+                     upstream=1.0, ws=None):
+    """-> (stats[19], dz or None, score or None).  stats[0] = mahalanobis(z, c, VI) (mean); gram (+)= sum z z^T."""
+    B, L = z.shape
+    _chk(z, "z"); _chk(c, "c", (L,)); _chk(VI, "VI", (L, L)); _chk(acc, "acc", (HEAD_SLOTS,), optional=True)
+    _chk(gram, "gram", (L, L), optional=True)
+    ws = head_ws(B, z.device) if ws is None else ws
+    dz = torch.empty_like(z) if need_grad else None
+    score = torch.empty(B, device=z.device, dtype=torch.float32) if need_score else None
+    stats = torch.empty(HEAD_SLOTS, device=z.device, dtype=torch.float32)
+    call("coskad_mahalanobis_head_f32", ptr(z), ptr(c), ptr(VI), ptr(dz), ptr(score), ptr(stats), ptr(acc), ptr(gram),
+         i32(int(gram_accumulate)), ctypes.c_float(upstream), ptr(ws), i32(B), i32(L), _stream())
+    return stats, dz, score
+
+
 def poincare_head(z, c, need_grad=True, need_zh=False, need_score=False, acc=None, upstream=1.0, ws=None):
     """-> (stats[19], dz, zh, score).  stats[0] = dist(c, project(expmap0(z))).mean()."""
     B, L = z.shape

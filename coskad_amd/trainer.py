@@ -50,6 +50,14 @@ class FlatParams:
             off += k
 
 
+def inv_cov_from_moments(gram: Tensor, acc: Tensor, mu: Tensor, L: int) -> Tensor:
+    """inverse of sum (z-mu)(z-mu)^T / (n-1), written with gram = sum z z^T, s = acc[1..L] = sum z, n = acc[17]."""
+    s, n = acc[1:1 + L].double(), acc[17].double()
+    m = mu.double()
+    S = gram.double() - torch.outer(m, s) - torch.outer(s, m) + n * torch.outer(m, m)
+    return torch.inverse((S / (n - 1)).float())
+
+
 class STSETrainStep:
     """One-class training of an STSE (linear projector) without autograd.
 
@@ -73,6 +81,8 @@ class STSETrainStep:
         self.layers = [layer_tensors(l) for l in model.encoder.model]
         self.ws = engine.Workspace()
         self.center_acc = torch.zeros(ops.HEAD_SLOTS, device=dev, dtype=torch.float32)
+        L = model.latent_dim
+        self.gram_acc = torch.zeros(L, L, device=dev, dtype=torch.float32) if head == 'mahalanobis' else None
         self.reg_scale = 0.5 / self.fp.n_reg_tensors          # calc_reg_loss value = reg_scale * sum p^2
         self.reg_coef = self.alpha * 2.0 * self.reg_scale      # its gradient coefficient, times alpha
         # gradient views per layer, in the kernels' vocabulary
@@ -105,6 +115,8 @@ class STSETrainStep:
             stats, dz, _ = ops.mse_head(z, m.c, acc=self.center_acc)
         elif self.head == 'poincare':
             stats, dz, _, _ = ops.poincare_head(z, m.c, acc=self.center_acc)
+        elif self.head == 'mahalanobis':
+            stats, dz, _ = ops.mahalanobis_head(z, m.c, m.inv_cov_matrix, acc=self.center_acc, gram=self.gram_acc)
         else:
             raise ValueError(f"unknown head {self.head}")
         K = W.shape[1]
@@ -137,6 +149,17 @@ class STSETrainStep:
         self._x_static.copy_(x)
         self._graph.replay()
         return self._stats_static
+
+    def refresh_inv_cov(self, mu: Tensor, reset: bool = True) -> Tensor:
+        """inv_cov_matrix <- inverse(sum_n (z_n - mu)(z_n - mu)^T / (n - 1)) over the latents seen since the last
+        reset (staticCenter.py:40-46,133-142), from the accumulated second moments (all-reduced over ranks)."""
+        parallel.allreduce_sum_(self.gram_acc, self.pg)
+        acc = self.center_acc.clone()
+        parallel.allreduce_sum_(acc, self.pg)
+        self.model.inv_cov_matrix.copy_(inv_cov_from_moments(self.gram_acc, acc, mu, self.model.latent_dim))
+        if reset:
+            self.gram_acc.zero_()
+        return self.model.inv_cov_matrix
 
     def reg_loss(self) -> Tensor:
         """utils/model_utils.py::calc_reg_loss value of the current parameters (1-element tensor)."""

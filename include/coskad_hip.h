@@ -128,6 +128,13 @@ size_t coskad_head_ws_floats(int B);    /* scratch floats the head kernels need 
 int coskad_mse_head_f32(const float* z, const float* c, float* dz, float* score, float* stats, float* acc,
                         float upstream, float* ws, int B, int L, hipStream_t stream);
 
+/* Mahalanobis head: loss = mean_n sqrt((z_n-c)^T VI (z_n-c)) (utils/eval_utils.py:28-38, called at
+ * euclidean_encoder_staticCenter.py:178-181), gradient, score (eval_utils.py:41-47), the MSE head's centre sums, and
+ * gram[L*L] (+)= sum_n z_n z_n^T, from which batch_cov_mat_step / compute_inv_cov_mat (:40-46,133-142) follow. */
+int coskad_mahalanobis_head_f32(const float* z, const float* c, const float* VI, float* dz, float* score,
+                                float* stats, float* acc, float* gram, int gram_accumulate, float upstream,
+                                float* ws, int B, int L, hipStream_t stream);
+
 /* zh = project(expmap0(z)); loss = mean dist(c, zh) (hyperbolic_encoder.py:147,157 with the formulas
  * of utils/hyper_math.py:13-29,100-105,173-179,207-210,302-306), gradient w.r.t. z, score = dist,
  * stats: [0] loss, [1..L] sum gamma*zh, [17] sum (gamma-1), [18] sum |zh|;  c NULL: embed + sums only. */

@@ -21,14 +21,15 @@ def make_args(**kw):
     return Namespace(**a)
 
 
-@pytest.mark.parametrize("mode", ["euclid_dynamic", "euclid_static", "hyperbolic"])
+@pytest.mark.parametrize("mode", ["euclid_dynamic", "euclid_static", "hyperbolic", "mahalanobis_static"])
 def test_train_score_auc_parity(mode, tmp_path):
     from coskad_amd.lit import LitEncoder, Trainer, load_checkpoint
     from coskad_amd.utils.synthetic import batches, make_dataset
     torch.manual_seed(0)
     train, _ = make_dataset(n_scenes=2, n_clips=3, n_persons=2, clip_len=100, num_transform=2, anomaly=False, seed=1)
     test, gts = make_dataset(n_scenes=1, n_clips=3, n_persons=2, clip_len=100, num_transform=2, anomaly=True, seed=2)
-    args = make_args(hyperbolic=(mode == "hyperbolic"), static_center=(mode == "euclid_static"))
+    args = make_args(hyperbolic=(mode == "hyperbolic"), static_center=mode in ("euclid_static", "mahalanobis_static"),
+                     distance="mahalanobis" if mode == "mahalanobis_static" else "euclidean")
     lit = LitEncoder(args).cuda()
     lit.gts = gts
     tr = Trainer(max_epochs=3, ckpt_dir=str(tmp_path))
@@ -42,6 +43,8 @@ def test_train_score_auc_parity(mode, tmp_path):
         z = R.stse_encode(x, st, training=False)
         if mode == "hyperbolic":
             s_ref = R.dist(st["c"][None], R.project(R.expmap0(z)))
+        elif mode == "mahalanobis_static":
+            s_ref = R.mahalanobis(z, st["c"][None], st["inv_cov_matrix"])           # eval_utils.py:41-47
         else:
             s_ref = R.euclid_window_score(z, st["c"])
     auc_ref, per_t_ref, _ = RS.score_dataset(s_ref.double().numpy(), trans.numpy(), meta.numpy(), frames.numpy(), gts, 2)
@@ -63,6 +66,11 @@ def test_train_score_auc_parity(mode, tmp_path):
         err_hip = float(((s_hip.double() - s64) / s64).abs().max())
         assert err_hip <= 2 * err_oracle + 1e-4, (err_hip, err_oracle)
         tol = dict(rtol=1e-2, atol=1e-2)
+    elif mode == "mahalanobis_static":
+        # sqrt(d^T VI d) with VI = inverse covariance (condition number ~1e3 here) amplifies the 1e-4 latent tolerance
+        tol = dict(rtol=5e-3, atol=1e-3)
+        s_same = R.mahalanobis(z_hip.cpu(), st["c"][None], st["inv_cov_matrix"])       # head alone, same latents
+        np.testing.assert_allclose(s_hip.numpy(), s_same.numpy(), rtol=2e-4, atol=1e-4)
     else:
         tol = dict(rtol=2e-4, atol=1e-4)
     np.testing.assert_allclose(s_hip.numpy(), s_ref.numpy(), **tol)

@@ -113,3 +113,37 @@ def test_stsvae_forward_backward():
     loss = ((xr - x) ** 2).mean() + kl_ps_uniform(q, p).mean() + (1 / kappa).mean()    # spherical_vae.py:81-107
     loss.backward()
     assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in m.parameters())
+
+
+def test_mahalanobis_head_vs_oracle():
+    """loss, gradient, per-window score, centre sums, second moments and the inverse covariance (a13)."""
+    from coskad_amd import ops
+    from coskad_amd.trainer import inv_cov_from_moments
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(5)
+    B, L = 1000, 16
+    z = torch.randn(B, L, generator=g) * torch.linspace(0.2, 2.0, L)
+    c = torch.randn(L, generator=g) * 0.1
+    A = torch.randn(L, L, generator=g)
+    VI = A @ A.T / L + 0.5 * torch.eye(L) + 0.05 * torch.randn(L, L, generator=g)      # not exactly symmetric
+    zr = z.clone().requires_grad_(True)
+    d_ref = R.mahalanobis(zr, c[None], VI)
+    d_ref.mean().backward()
+    acc = torch.zeros(ops.HEAD_SLOTS, device="cuda")
+    gram = torch.zeros(L, L, device="cuda")
+    stats, dz, score = ops.mahalanobis_head(z.cuda(), c.cuda(), VI.cuda(), need_score=True, acc=acc, gram=gram)
+    np.testing.assert_allclose(score.cpu().numpy(), d_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(stats[0]), float(d_ref.detach().mean()), rtol=1e-5)
+    np.testing.assert_allclose(dz.cpu().numpy(), zr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(acc[1:1 + L].cpu().numpy(), z.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    assert float(acc[17]) == B
+    np.testing.assert_allclose(gram.cpu().numpy(), (z.T.double() @ z.double()).numpy(), rtol=1e-4, atol=1e-2)
+    # compute_inv_cov_mat (staticCenter.py:133-142) = inverse(sum (z-mu)(z-mu)^T / (n-1))
+    mu = z.mean(0)
+    S = ((z - mu)[:, :, None] @ (z - mu)[:, None, :]).sum(0)
+    ref_inv = torch.inverse(S / (B - 1))
+    got = inv_cov_from_moments(gram, acc, mu.cuda(), L).cpu()
+    np.testing.assert_allclose(got.numpy(), ref_inv.numpy(), rtol=2e-3, atol=1e-4)
+    # a second batch accumulates
+    ops.mahalanobis_head(z.cuda(), c.cuda(), VI.cuda(), need_grad=False, acc=acc, gram=gram)
+    np.testing.assert_allclose(gram.cpu().numpy(), 2 * (z.T.double() @ z.double()).numpy(), rtol=1e-4, atol=2e-2)
