@@ -319,3 +319,15 @@ def adam_dev(p, g, m, v, mask, hyper, beta1, beta2, eps, gscale=1.0, reg_coef=0.
     call("coskad_adam_dev_f32", ptr(p), ptr(g), ptr(m), ptr(v), ptr(mask), ctypes.c_size_t(p.numel()), ptr(hyper),
          ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(gscale),
          ctypes.c_float(reg_coef), _stream())
+
+
+def gather_transform(xy, mats, index, T, V):
+    """Batch [B, 2, T, V] from the device-resident window table xy [N, 2, T*V]: item i = transform i // N of window
+    i % N (utils/dataset.py:65-77; PoseTransform of utils/dataset_utils.py:272-310)."""
+    N = xy.shape[0]
+    _chk(xy, "xy", (N, 2, T * V)); _chk(mats, "mats", (mats.shape[0], 3, 3)); _chk(index, "index", dtype=torch.int64)
+    B = index.numel()
+    out = torch.empty(B, 2, T, V, device=xy.device, dtype=torch.float32)
+    call("coskad_gather_transform_f32", ptr(xy), ptr(index), ptr(mats), ptr(out), i32(B), i32(N), i32(mats.shape[0]),
+         i32(T * V), _stream())
+    return out

@@ -21,13 +21,18 @@ def main():
     model = LitEncoder(args).cuda()
     path = os.path.join(args.exp_dir, args.dataset_choice, args.dir_name, args.load_ckpt)
     print('Loading model from {}'.format(path))
-    if args.data_dir != 'synthetic':
-        raise NotImplementedError("only `data_dir: synthetic` is wired (SURVEY 8f rank 2)")
-    test, gts = make_dataset(n_scenes=2, n_clips=3, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
-                             anomaly=True, seed=args.seed + 1)
-    model.gts = gts
     trainer = Trainer()
-    out = trainer.predict(model, lambda: batches(test, args.dataset_batch_size), ckpt_path=path)
+    if args.data_dir == 'synthetic':
+        test, gts = make_dataset(n_scenes=2, n_clips=3, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
+                                 anomaly=True, seed=args.seed + 1)
+        model.gts = gts
+        out = trainer.predict(model, lambda: batches(test, args.dataset_batch_size), ckpt_path=path)
+    else:
+        # eval_COSKAD.py:107-116: test split of the Morais-format tree, scaler pickled by the training run
+        from coskad_amd.utils.dataset import get_dataset_and_loader
+        dataset_args.exp_dir = os.path.dirname(path)
+        _, loader = get_dataset_and_loader(dataset_args, split=args.split)
+        out = trainer.predict(model, lambda: loader, ckpt_path=path)
     auc = model.validation_epoch_end(out)
     print('final AUC score: {}'.format(auc))
 

@@ -117,6 +117,14 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
                          float* dW, float* db, float* dslope, void* ws, size_t ws_bytes, int accumulate,
                          int B, int K, int L, hipStream_t stream);
 
+/* ---- batch formation from the HBM-resident window table (callers' side of the path) ----- */
+
+/* out[b, c, :] = M[t][c][0] x[s] + M[t][c][1] y[s] + M[t][c][2] with s = index[b] % N, t = index[b] / N, c < 2:
+ * the item rule of utils/dataset.py:65-77 with the affine PoseTransform of utils/dataset_utils.py:272-310.
+ * xy: [N, 2, TV], index: [B] int64, mats: [ntrans, 3, 3], out: [B, 2, TV]. */
+int coskad_gather_transform_f32(const float* xy, const long long* index, const float* mats, float* out, int B, int N,
+                                int ntrans, int TV, hipStream_t stream);
+
 /* ---- one-class heads, centre statistics, regulariser, optimiser ------------------------ */
 
 int coskad_head_slots(void);            /* floats in a stats / acc block (19) */

@@ -36,17 +36,29 @@ def main():
     if args.use_decoder or args.use_vae:
         raise NotImplementedError("autoencoder / VAE wrappers are outside this round's scope (SURVEY 8f)")
     model = LitEncoder(args).cuda()                  # hyperbolic / static_center switches: train_COSKAD.py:36-55
-    if args.data_dir != 'synthetic':
-        raise NotImplementedError("only `data_dir: synthetic` is wired; the reference's CSV pipeline is SURVEY 8f rank 2")
-    train, _ = make_dataset(n_scenes=4, n_clips=4, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
-                            anomaly=False, seed=args.seed)
-    val, gts = make_dataset(n_scenes=2, n_clips=3, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
-                            anomaly=True, seed=args.seed + 1)
-    model.gts = gts
     bs = args.dataset_batch_size
     trainer = Trainer(max_epochs=args.ae_epochs, ckpt_dir=args.ckpt_dir, save_top_k=2)
-    trainer.fit(model, lambda: batches(train, bs, shuffle=True, seed=args.seed, rank=rank, world=world),
-                (lambda: batches(val, bs, rank=rank, world=world)) if args.validation else None)
+    if args.data_dir == 'synthetic':
+        train, _ = make_dataset(n_scenes=4, n_clips=4, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
+                                anomaly=False, seed=args.seed)
+        val, gts = make_dataset(n_scenes=2, n_clips=3, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
+                                anomaly=True, seed=args.seed + 1)
+        model.gts = gts
+        trainer.fit(model, lambda: batches(train, bs, shuffle=True, seed=args.seed, rank=rank, world=world),
+                    (lambda: batches(val, bs, rank=rank, world=world)) if args.validation else None)
+    else:
+        # Morais-format trajectories (`dataset_path_to_robust`, train_COSKAD.py:80-85): window table resident in HBM,
+        # batches formed on the device; frame masks are read from args.gt_path by LitEncoder.post_processing
+        from coskad_amd.utils.dataset import get_dataset_and_loader
+        args.exp_dir_scaler = args.ckpt_dir
+        dataset_args.exp_dir = args.ckpt_dir
+        if args.validation:
+            _, train_loader, _, val_loader = get_dataset_and_loader(dataset_args, split=args.split, validation=True,
+                                                                    rank=rank, world=world)
+        else:
+            _, train_loader = get_dataset_and_loader(dataset_args, split=args.split, rank=rank, world=world)
+            val_loader = None
+        trainer.fit(model, lambda: train_loader, (lambda: val_loader) if val_loader is not None else None)
     if rank == 0:
         for rec in trainer.history:
             print(rec)
