@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from ... import engine, ops
+from ..common.alternative_components import EncoderLearnablePlainGCN, EncoderStaticPlainGCN
 from ..common.components import MLP, Decoder, Encoder
 from ..graph_layers.stsgcn import _PReLUFn
 
@@ -35,7 +36,7 @@ class _BottleneckFn(torch.autograd.Function):
         K = W.shape[1]
         dW = torch.empty_like(W)
         db = torch.empty(L, device=W.device, dtype=W.dtype) if ctx.has_bias else None
-        dslope = torch.empty_like(slope)
+        dslope = torch.empty_like(slope) if slope is not None else None   # no activation in front: plain-GCN encoders
         buf = ctx.ws.get(ops.btlnk_bwd_ws_bytes(B, K, L), U.device)
         dU = ops.btlnk_bwd(U, W, dz.contiguous(), slope, dW, db, dslope, buf)
         return dU, dslope, dW, db, None
@@ -52,7 +53,7 @@ def _legacy(kw: dict, new: str, old: str, default=None):
 class STSE(nn.Module):
     """STS-GCN encoder + bottleneck to a latent pulled towards a centre `c` (reference ae.py:12-165)."""
 
-    encoder_classes = {'sts_gcn': Encoder}
+    encoder_classes = {'sts_gcn': Encoder, 'learnable_gcn': EncoderLearnablePlainGCN, 'static_gcn': EncoderStaticPlainGCN}
 
     def __init__(self, input_dim: int = None, layer_channels: List[int] = None, hidden_dimension: int = None,
                  latent_dim: int = None, n_frames: int = None, n_joints: int = None, encoder_type: str = 'sts_gcn',
@@ -85,9 +86,9 @@ class STSE(nn.Module):
             self.encoder = self.encoder_classes[self.encoder_type](
                 input_dim=self.input_dim, layer_channels=self.layer_channels, hidden_dimension=self.hidden_dimension,
                 n_frames=self.n_frames, n_joints=self.n_joints, dropout=self.dropout, bias=self.bias, device=self.device)
-        elif self.encoder_type in ('st_gcn', 'learnable_gcn', 'static_gcn'):
-            raise NotImplementedError(f"coskad_amd: encoder type {self.encoder_type} is outside the STS-GCN hot path "
-                                      "(SURVEY 8f rank 4)")
+        elif self.encoder_type == 'st_gcn':
+            raise NotImplementedError("coskad_amd: encoder type st_gcn is not mirrored (its constructor raises a "
+                                      "TypeError in the reference snapshot, SURVEY 8c)")
         else:
             raise ValueError(f'Encoder type {self.encoder_type} not supported.')
 
@@ -104,7 +105,10 @@ class STSE(nn.Module):
     def encode(self, X: Tensor, return_shape: bool = False):
         assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
         B = X.shape[0]
-        U, slope = self.encoder.forward_preact(X)   # [B, hid, T, V] pre-activation of the last layer
+        if hasattr(self.encoder, 'forward_preact'):
+            U, slope = self.encoder.forward_preact(X)   # [B, hid, T, V] pre-activation of the last layer
+        else:
+            U, slope = self.encoder(X), None            # plain-GCN encoders: already activated (ReLU)
         X_shape = (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)
         if isinstance(self.btlnk, nn.Linear) and self.latent_dim <= 16:
             Z = _BottleneckFn.apply(U, slope, self.btlnk.weight, self.btlnk.bias, self._ws)

@@ -136,3 +136,13 @@ def test_stsvae_surface():
     assert m.fc_var.out_features == 1 and isinstance(m.btlnk, torch.nn.Identity)     # vae.py:150,161
     with pytest.raises(ValueError):
         STSVAE(2, [8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='nope')
+
+
+def test_static_gcn_adjacency_matches_reference_buffer():
+    """EncoderStaticPlainGCN's fixed adjacency (alternative_components.py:213-229,243-259), built array-wise."""
+    import os
+    from coskad_amd.models.common.alternative_components import EncoderStaticPlainGCN
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stse_altgcn.npz"))
+    enc = EncoderStaticPlainGCN(2, [8, 4], 8, 12, 17, 0.0)
+    np.testing.assert_array_equal(enc.Adj.numpy(), g["static_gcn.sd.encoder.Adj"])
+    np.testing.assert_allclose(enc.Adj.sum(1).numpy(), 1.0, rtol=1e-6)
