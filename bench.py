@@ -146,6 +146,18 @@ def main():
             eng.step(x)
         sync()
         lib.coskad_probe_end(ctypes.byref(fwd_ms), ctypes.byref(fwd_n))
+    # forward-only (eval-mode encoder + bottleneck; SURVEY 8d's forward roofline target), outside the timed region
+    model.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            model(x)
+        sync()
+        tf0 = time.perf_counter()
+        for _ in range(10):
+            model(x)
+        sync()
+        fwd_dt = (time.perf_counter() - tf0) / 10
+    model.train()
     if world > 1:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -200,6 +212,9 @@ def main():
             "algorithmic_bytes_per_clip": {"fwd": fwd_b, "bwd": bwd_b},
             "step_hbm_frac": round(world * B * args.steps / dt * (fwd_b + bwd_b) / world / (HBM_PEAK_GBS * 1e9), 4),
             "final_loss": round(loss, 6),
+            "forward_only": {"value": round(B / fwd_dt, 1), "unit": "clips/s per GPU", "ms": round(fwd_dt * 1e3, 4),
+                             "hbm_frac": round(B / fwd_dt * fwd_b / (HBM_PEAK_GBS * 1e9), 4),
+                             "what": "eval-mode STSE forward (4 layer kernels + bottleneck), BN folded from running stats"},
             "roofline": roof,
             "roofline_fwd_layer4": roof_fwd,
         }

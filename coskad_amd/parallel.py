@@ -57,11 +57,20 @@ def broadcast_(t: Tensor, src: int = 0, group=None) -> Tensor:
 
 
 def gather_rows(t: Tensor, group=None) -> Tensor:
-    """all_gather of per-rank row blocks [N_r, ...] (equal N_r) -> [W*N_r, ...] in rank order
-    (validation: latents + metadata to score on every rank)."""
+    """all_gather of per-rank row blocks [N_r, ...] -> [sum N_r, ...] in rank order (validation: latents + metadata
+    to score on every rank).  Ranks may hold different row counts (an r::W split of the last batch): blocks are
+    padded to the largest count for the collective and trimmed afterwards."""
     w = world_size(group)
     if w == 1:
         return t
-    out = [torch.empty_like(t) for _ in range(w)]
-    dist.all_gather(out, t.contiguous(), group=group)
-    return torch.cat(out, dim=0)
+    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+    counts = [torch.empty_like(n) for _ in range(w)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    pad = t.contiguous()
+    if t.shape[0] < m:
+        pad = torch.cat([pad, pad.new_zeros((m - t.shape[0],) + tuple(t.shape[1:]))], 0)
+    out = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)

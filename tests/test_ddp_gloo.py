@@ -46,6 +46,8 @@ def _worker(rank, world, port, q):
     parallel.allreduce_mean_(flat)
     parallel.allreduce_sum_(stats)
     gathered = parallel.gather_rows(idx.float()[:, None])
+    ragged = parallel.gather_rows(torch.arange(11)[rank::world].float()[:, None])   # 6 rows on rank 0, 5 on rank 1
+    assert sorted(ragged[:, 0].tolist()) == list(range(11)), ragged
     q.put((rank, flat.numpy(), stats.numpy(), gathered.numpy()))
     dist.destroy_process_group()
 
