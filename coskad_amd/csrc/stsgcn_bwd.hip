@@ -972,18 +972,55 @@ static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
   return w;
 }
 
+// Stage 4 of the layer backward: dA, dT from the layer input (pre-activation + producer slope) and the stored dZ.
+// partials: >= min(512, tiles) * (T*V*V + V*T*T) floats.
+template <int T, int V>
+static int launch_layer_gcn_params(const float* in, const float* in_slope, const float* dz, const float* Aw,
+                                   const float* Tw, float* dA, float* dT, float* partials, int accumulate, int B,
+                                   int Ci, int Co_tag, hipStream_t st) {
+  constexpr int LD = Geo<T, V>::LD;
+  const int E = T * V * V + V * T * T;
+  int NB = Ci >= 32 ? 1 : 32 / Ci;
+  if (NB > B) NB = B;
+  const size_t lds = ((size_t)2 * NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
+  if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
+  const int ntiles = ceil_div(B, NB);
+  const int grid = ntiles < 512 ? ntiles : 512;
+  auto k = k_bwd_gcn_params<T, V>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    ProbeScope probe(KID_GCN_PARAMS, Ci, Co_tag, st);
+#ifdef COSKAD_ABLATE
+    static int ablg = -1;
+    if (ablg < 0) { const char* e = getenv("COSKAD_ABLG"); ablg = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, B, Ci, NB, ablg);
+#else
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, B, Ci, NB);
+#endif
+  }
+  int rc;
+  if ((rc = check_launch("bwd_gcn_params"))) return rc;
+  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, partials, grid, E, 0,
+                     T * V * V, dA, accumulate);
+  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(1024), 0, st, partials, grid, E,
+                     T * V * V, V * T * T, dT, accumulate);
+  return check_launch("bwd_gcn_reduce");
+}
+
 template <int T, int V>
 static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, const float* Tw,
                             const float* in_slope, const float* stat, const float* Wt, const float* gs,
                             const float* Wr, const float* gr, float* dIn, float* dA, float* dT, float* dWt,
                             float* dbt, float* dgs, float* dbs, float* dWr, float* dbr, float* dgr,
                             float* dbr2, float* dslope_in, void* ws, size_t ws_bytes, int accumulate,
-                            int B, int Ci, int Co, hipStream_t st) {
+                            int B, int Ci, int Co, hipStream_t st, float* dz_ext = nullptr) {
+  // dz_ext != NULL: dZ goes to the caller's buffer and stage 4 (dA, dT) is left to coskad_layer_gcn_params_f32
   constexpr int LD = Geo<T, V>::LD, TV = Geo<T, V>::TV;
   if (Ci > 64 || Co > 64) return fail(COSKAD_ERR_SHAPE, "layer_bwd: channels (%d,%d) > 64 not supported", Ci, Co);
   if (ws_bytes < layer_bwd_ws_bytes(B, Ci, Co, T, V))
     return fail(COSKAD_ERR_WORKSPACE, "layer_bwd: workspace %zu < %zu bytes", ws_bytes, layer_bwd_ws_bytes(B, Ci, Co, T, V));
   BwdWs w = carve(ws, B, Ci, Co, T, V);
+  if (dz_ext) w.dz = dz_ext;
   int rc;
   // 1. reductions
   {
@@ -1101,33 +1138,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     }
   }
   // 4. gcn parameter gradients
-  {
-    const int E = T * V * V + V * T * T;
-    int NB = Ci >= 32 ? 1 : 32 / Ci;
-    if (NB > B) NB = B;
-    const size_t lds = ((size_t)2 * NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
-    if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
-    const int ntiles = ceil_div(B, NB);
-    const int grid = ntiles < 512 ? ntiles : 512;
-    auto k = k_bwd_gcn_params<T, V>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    {
-      ProbeScope probe(KID_GCN_PARAMS, Ci, Co, st);
-#ifdef COSKAD_ABLATE
-      static int ablg = -1;
-      if (ablg < 0) { const char* e = getenv("COSKAD_ABLG"); ablg = e ? atoi(e) : 0; }
-      hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB, ablg);
-#else
-      hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, w.dz, Aw, Tw, in_slope, w.partials, B, Ci, NB);
-#endif
-    }
-    if ((rc = check_launch("bwd_gcn_params"))) return rc;
-    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, w.partials, grid, E, 0,
-                       T * V * V, dA, accumulate);
-    hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(1024), 0, st, w.partials, grid, E,
-                       T * V * V, V * T * T, dT, accumulate);
-    if ((rc = check_launch("bwd_gcn_reduce"))) return rc;
-  }
+  if (!dz_ext) return launch_layer_gcn_params<T, V>(in, in_slope, w.dz, Aw, Tw, dA, dT, w.partials, accumulate, B, Ci, Co, st);
   return COSKAD_OK;
 }
 
@@ -1196,6 +1207,42 @@ int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const
   return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
                                   dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
                                   ws_bytes, accumulate, B, Ci, Co, stream)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+/* Stages 1-3 of coskad_layer_bwd_f32 with dZ [B,Ci,T,V] written to the caller's buffer; stage 4 is
+ * coskad_layer_gcn_params_f32, which a caller may enqueue on a second stream while the chain continues. */
+int coskad_layer_bwd_data_f32(const float* in, const float* dU, const float* A, const float* Tm,
+                              const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
+                              const float* Wr, const float* gamma_r, float* dIn, float* dZ, float* dWt, float* dbt,
+                              float* dgamma_t, float* dbeta_t, float* dWr, float* dbr, float* dgamma_r,
+                              float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes, int accumulate, int B,
+                              int Ci, int Co, int T, int V, hipStream_t stream) {
+  if (!in || !dU || !A || !Tm || !stat || !Wt || !gamma_t || !dZ || !dWt || !dgamma_t || !dbeta_t || !ws)
+    return fail(COSKAD_ERR_ARG, "layer_bwd_data: null pointer");
+  if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd_data: residual grads missing");
+  if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_bwd_data: identity residual needs Ci == Co");
+  if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd_data: B=%d Ci=%d Co=%d", B, Ci, Co);
+#define CALL(T_, V_)                                                                                              \
+  return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, nullptr, nullptr, dWt, \
+                                  dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws, ws_bytes,   \
+                                  accumulate, B, Ci, Co, stream, dZ)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+size_t coskad_layer_gcn_params_ws_bytes(int T, int V) { return coskad_gcn_bwd_params_ws_bytes(T, V); }
+
+/* dA, dT of one layer from its input `in` (pre-activation of the producer, PReLU(in_slope) applied on load; NULL for
+ * the raw network input) and the dZ stored by coskad_layer_bwd_data_f32. */
+int coskad_layer_gcn_params_f32(const float* in, const float* in_slope, const float* dZ, const float* A,
+                                const float* Tm, float* dA, float* dT, void* ws, size_t ws_bytes, int accumulate,
+                                int B, int Ci, int T, int V, hipStream_t stream) {
+  if (!in || !dZ || !A || !Tm || !dA || !dT || !ws) return fail(COSKAD_ERR_ARG, "layer_gcn_params: null pointer");
+  if (B <= 0 || Ci <= 0 || Ci > 64) return fail(COSKAD_ERR_ARG, "layer_gcn_params: B=%d Ci=%d", B, Ci);
+  if (ws_bytes < coskad_layer_gcn_params_ws_bytes(T, V)) return fail(COSKAD_ERR_WORKSPACE, "layer_gcn_params: workspace too small");
+#define CALL(T_, V_) return launch_layer_gcn_params<T_, V_>(in, in_slope, dZ, A, Tm, dA, dT, reinterpret_cast<float*>(ws), accumulate, B, Ci, 0, stream)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

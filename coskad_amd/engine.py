@@ -128,13 +128,39 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
     return h, ctx
 
 
+class SideStream:
+    """Second HIP stream for the mixing-parameter gradients (dA, dT): they depend only on a layer's input and dZ, so
+    they run beside the next layer's reductions and fill the GPU during its single-block fold kernels.  Owns the
+    buffers that must outlive the main stream's reuse: two dZ images (alternating layers) and the partial sums."""
+
+    def __init__(self) -> None:
+        self.stream: Optional[torch.cuda.Stream] = None
+        self.dz = [None, None]
+        self.ws = None
+        self.done = [None, None]      # events: side work that last read dz[k] has finished
+
+    def ensure(self, nfloats: int, ws_bytes: int, device) -> None:
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=device)
+        for k in range(2):
+            if self.dz[k] is None or self.dz[k].numel() < nfloats:
+                self.dz[k] = torch.empty(nfloats, device=device, dtype=torch.float32)
+        if self.ws is None or self.ws.numel() < ws_bytes:
+            self.ws = torch.empty(ws_bytes, device=device, dtype=torch.uint8)
+
+
 def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Workspace,
-                   grads: List[Dict[str, Tensor]], need_dx: bool, accumulate: bool = False) -> Optional[Tensor]:
+                   grads: List[Dict[str, Tensor]], need_dx: bool, accumulate: bool = False,
+                   side: Optional[SideStream] = None) -> Optional[Tensor]:
     """Backward through the chain.  `grads[i]` maps A,T,Wt,bt,gt,bet,Wr,br,gr,ber,slope -> tensors to
     fill for layer i.  The slope gradient of layer i is produced while back-propagating through
     layer i+1 (its consumer); the caller owns the last layer's slope gradient.
+    With `side`, dA / dT are computed on its stream (joined into the current stream before returning).
     Returns d(inputs[0]) if need_dx."""
     n = len(layers)
+    main = torch.cuda.current_stream() if side is not None else None
+    if side is not None:
+        side.done = [None, None]     # the previous call joined the side stream: nothing of it is still in flight
     for i in range(n - 1, -1, -1):
         L = layers[i]
         x_in = ctx.inputs[i]
@@ -146,9 +172,23 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
             g["slope_in"] = grads[i - 1]["slope"]
         want_dx = need_dx or i > 0
         buf = ws.get(ops.layer_bwd_ws_bytes(B, Ci, L.Co, T, V), x_in.device)
-        dIn = ops.layer_bwd(x_in, dU, L.A, L.T, in_slope, ctx.stats[i], L.w2(L.Wt), L.gt, L.w2(L.Wr), L.gr,
-                            _as2d(g), buf, need_dx=want_dx, accumulate=accumulate)
+        args = (x_in, dU, L.A, L.T, in_slope, ctx.stats[i], L.w2(L.Wt), L.gt, L.w2(L.Wr), L.gr, _as2d(g), buf)
+        if side is None:
+            dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate)
+        else:
+            k = i & 1
+            side.ensure(max(x.numel() for x in ctx.inputs), ops.layer_gcn_params_ws_bytes(T, V), x_in.device)
+            if side.done[k] is not None:
+                main.wait_event(side.done[k])          # the side kernels that read this dZ image are finished
+            dz = side.dz[k][:x_in.numel()].view(B, Ci, T, V)
+            dIn = ops.layer_bwd_data(*args, dZ=dz, need_dx=want_dx, accumulate=accumulate)
+            side.stream.wait_stream(main)
+            with torch.cuda.stream(side.stream):
+                ops.layer_gcn_params(x_in, in_slope, dz, L.A, L.T, g["A"], g["T"], side.ws, accumulate=accumulate)
+                side.done[k] = side.stream.record_event()
         dU = dIn
+    if side is not None:
+        main.wait_stream(side.stream)
     return dU if need_dx else None
 
 

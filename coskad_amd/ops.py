@@ -158,6 +158,50 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
     return dIn if need_dx else None
 
 
+def layer_bwd_data(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, dZ, need_dx=True, dIn=None,
+                   accumulate=False):
+    """Stages 1-3 of layer_bwd (everything but dA, dT); dZ [B,Ci,T,V] receives the mixing-output gradient that
+    layer_gcn_params consumes (possibly on another stream).  Returns dIn (or None)."""
+    B, Ci, T, V = x_in.shape
+    Co = Wt.shape[0]
+    _chk(x_in, "x_in"); _chk(dU, "dU", (B, Co, T, V)); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
+    _chk(Wt, "Wt", (Co, Ci)); _chk(gt, "gamma_t", (Co,)); _chk(stat, "stat", (stat_floats(Ci, Co),))
+    _chk(Wr, "Wr", (Co, Ci), optional=True); _chk(gr, "gamma_r", (Co,), optional=True)
+    _chk(in_slope, "in_slope", (1,), optional=True); _chk(dZ, "dZ", (B, Ci, T, V))
+    for k, shp in (("Wt", (Co, Ci)), ("gt", (Co,)), ("bet", (Co,))):
+        _chk(grads[k], "grad " + k, shp)
+    for k, shp in (("bt", (Co,)), ("Wr", (Co, Ci)), ("br", (Co,)), ("gr", (Co,)), ("ber", (Co,)), ("slope_in", (1,))):
+        _chk(grads.get(k), "grad " + k, shp, optional=True)
+    need = layer_bwd_ws_bytes(B, Ci, Co, T, V)
+    if ws is None or _bytes(ws) < need:
+        raise ValueError(f"workspace too small: need {need} bytes")
+    if need_dx and dIn is None:
+        dIn = torch.empty_like(x_in)
+    call("coskad_layer_bwd_data_f32", ptr(x_in), ptr(dU), ptr(A), ptr(Tm), ptr(in_slope), ptr(stat), ptr(Wt), ptr(gt),
+         ptr(Wr), ptr(gr), ptr(dIn if need_dx else None), ptr(dZ), ptr(grads["Wt"]), ptr(grads.get("bt")),
+         ptr(grads["gt"]), ptr(grads["bet"]), ptr(grads.get("Wr")), ptr(grads.get("br")), ptr(grads.get("gr")),
+         ptr(grads.get("ber")), ptr(grads.get("slope_in")), ptr(ws), ctypes.c_size_t(_bytes(ws)),
+         i32(1 if accumulate else 0), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    return dIn if need_dx else None
+
+
+def layer_gcn_params_ws_bytes(T, V) -> int:
+    fn = _lib.lib().coskad_layer_gcn_params_ws_bytes
+    fn.restype = ctypes.c_size_t
+    return fn(i32(T), i32(V))
+
+
+def layer_gcn_params(x_in, in_slope, dZ, A, Tm, dA, dT, ws, accumulate=False):
+    """dA, dT of one layer from its stored input and dZ (enqueued on the CURRENT torch stream)."""
+    B, Ci, T, V = x_in.shape
+    _chk(x_in, "x_in"); _chk(dZ, "dZ", (B, Ci, T, V)); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
+    _chk(dA, "dA", (T, V, V)); _chk(dT, "dT", (V, T, T)); _chk(in_slope, "in_slope", (1,), optional=True)
+    if ws is None or _bytes(ws) < layer_gcn_params_ws_bytes(T, V):
+        raise ValueError("workspace too small")
+    call("coskad_layer_gcn_params_f32", ptr(x_in), ptr(in_slope), ptr(dZ), ptr(A), ptr(Tm), ptr(dA), ptr(dT), ptr(ws),
+         ctypes.c_size_t(_bytes(ws)), i32(1 if accumulate else 0), i32(B), i32(Ci), i32(T), i32(V), _stream())
+
+
 def btlnk_fwd(U: Tensor, W: Tensor, bias: Optional[Tensor], slope: Optional[Tensor]) -> Tensor:
     """z = Linear(flatten(PReLU(U)))  (reference ae.py:97-101)."""
     B = U.shape[0]

@@ -10,6 +10,8 @@ sync_batchnorm).
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
@@ -65,7 +67,8 @@ class STSETrainStep:
     """
 
     def __init__(self, model, lr: float = 1e-4, alpha: float = 1e-6, head: str = 'euclidean',
-                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, use_graph: bool = False) -> None:
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, use_graph: bool = False,
+                 side_stream: bool = False) -> None:
         from .models.sts.ae import STSE
         if not isinstance(model, STSE) or not isinstance(model.btlnk, torch.nn.Linear):
             raise TypeError("STSETrainStep drives an STSE with projector='linear'")
@@ -94,6 +97,9 @@ class STSETrainStep:
                  "br": pre + "residual.0.bias", "gr": pre + "residual.1.weight", "ber": pre + "residual.1.bias",
                  "slope": pre + "prelu.weight"}
             self.grads.append({k: self.fp.gviews[n] for k, n in g.items() if n in self.fp.gviews})
+        # optional: dA / dT on a second stream beside the next layer's reductions.  Measured SLOWER on MI355X (2.43 vs
+        # 2.28 ms/step: the two LDS-heavy persistent kernels halve each other's occupancy), so it is off by default.
+        self.side = engine.SideStream() if (side_stream or os.environ.get("COSKAD_SIDE_STREAM", "0") == "1") else None
         self.use_graph = use_graph
         self._graph = None
         self._x_static: Optional[Tensor] = None
@@ -123,7 +129,7 @@ class STSETrainStep:
         buf = self.ws.get(ops.btlnk_bwd_ws_bytes(B, K, W.shape[0]), x.device)
         dU = ops.btlnk_bwd(U, W, dz, slope, self.fp.gviews["btlnk.weight"],
                            self.fp.gviews.get("btlnk.bias"), self.grads[-1]["slope"], buf)
-        engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False)
+        engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False, side=self.side)
         if self.world > 1:
             dist.all_reduce(self.fp.grad, group=self.pg)   # RCCL, one flat 0.96 MB buffer (SUM; /W in Adam)
         ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,

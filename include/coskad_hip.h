@@ -99,6 +99,20 @@ int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const
                          float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                          int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream);
 
+/* The same backward split in two calls, so that stage 4 (dA, dT; independent of the rest of the chain) can be enqueued
+ * on a second stream: coskad_layer_bwd_data_f32 = batch reductions + fold + data path, with the mixing-output gradient
+ * dZ [B,Ci,T,V] written to the caller's buffer; coskad_layer_gcn_params_f32 = dA, dT from `in` and that dZ. */
+int coskad_layer_bwd_data_f32(const float* in, const float* dU, const float* A, const float* Tm,
+                              const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
+                              const float* Wr, const float* gamma_r, float* dIn, float* dZ, float* dWt, float* dbt,
+                              float* dgamma_t, float* dbeta_t, float* dWr, float* dbr, float* dgamma_r,
+                              float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes, int accumulate, int B,
+                              int Ci, int Co, int T, int V, hipStream_t stream);
+size_t coskad_layer_gcn_params_ws_bytes(int T, int V);
+int coskad_layer_gcn_params_f32(const float* in, const float* in_slope, const float* dZ, const float* A,
+                                const float* Tm, float* dA, float* dT, void* ws, size_t ws_bytes, int accumulate,
+                                int B, int Ci, int T, int V, hipStream_t stream);
+
 /* Parameter gradients of ConvTemporalGraphical alone (stsgcn.py:154-155), given its input x and
  * the gradient dZ of its output; rows = N*C. */
 size_t coskad_gcn_bwd_params_ws_bytes(int T, int V);

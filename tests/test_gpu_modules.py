@@ -172,3 +172,23 @@ def test_plain_gcn_encoders_vs_reference(enc):
     for k, p in m.named_parameters():
         ref = g[f"{enc}.grad.{k}"]
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=1e-6 + 1e-4 * np.abs(ref).max(), err_msg=k)
+
+
+def test_split_backward_on_side_stream_is_bit_identical(golden):
+    """coskad_layer_bwd_data_f32 + coskad_layer_gcn_params_f32 on a second stream == the single-call backward."""
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import STSETrainStep
+    from oracle import ref_cpu as R
+    x = R.synthetic_clips(64, seed=9).cuda()
+    flats = []
+    for side in (False, True):
+        st = R.init_stse_state(2, (32, 16, 32), 64, 16, 12, 17, seed=0)
+        st["c"] = torch.full((16,), 0.1)
+        m = STSE(2, [32, 16, 32], 64, 16, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+        m.load_state_dict(st, strict=True)
+        eng = STSETrainStep(m.cuda().train(), lr=1e-3, alpha=1e-6, side_stream=side)
+        for _ in range(3):
+            eng.step(x)
+        torch.cuda.synchronize()
+        flats.append(eng.fp.flat.clone())
+    assert torch.equal(flats[0], flats[1])

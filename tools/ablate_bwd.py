@@ -27,15 +27,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         ms, n = ctypes.c_float(0), ctypes.c_int(0)
         lib.coskad_probe_end(ctypes.byref(ms), ctypes.byref(n))
         res.append(f"{ms.value*1e3:7.1f}")
-    print(f"abl={int(os.environ.get('COSKAD_ABL','0')):3d}/{int(os.environ.get('COSKAD_ABLG','0')):3d}  L4 {res[0]} us   L2 {res[1]} us", flush=True)
+    print(f"abl={int(os.environ.get('COSKAD_ABL','0')):3d}/{int(os.environ.get('COSKAD_ABLG','0')):3d}/{int(os.environ.get('COSKAD_DBG','0')):3d}  L4 {res[0]} us   L2 {res[1]} us", flush=True)
 else:
     names = {0: "full", 1: "-stage", 2: "-phase0(Kr.X)", 4: "-gcn fwd", 8: "-dU loop", 16: "-Kt.Z", 32: "-unstage dZ", 64: "-gcn adj",
              128: "-epilogue", 255: "nothing but barriers", 8 + 16 + 2: "-all conv", 4 + 64: "-both gcn", 1 + 32 + 128: "-all global io except dU"}
+    if len(sys.argv) > 1 and sys.argv[1] == "apply":   # k_layer_apply_m phases (runtime env COSKAD_DBG, no special build)
+        names = {0: "full", 4: "-stage", 1: "-gcn", 2: "-conv", 8: "-store", 16: "-conv X part (global)", 32: "-conv Z part (LDS)",
+                 7: "skeleton", 1 + 4: "-stage -gcn"}
+        os.environ["ABL_KID"] = "1"
     if len(sys.argv) > 1 and sys.argv[1] == "gcn":   # k_bwd_gcn_params phases
         names = {0: "full", 64: "-stage X", 1: "-stage dZ", 2: "-temporal", 4: "-dA", 8: "-spatial adj", 16: "-restage X", 32: "-dT",
                  127: "barriers only", 4 + 32: "-dA -dT", 2 + 8: "-both mixing", 1 + 16 + 64: "-all staging"}
         os.environ["ABL_KID"] = "5"
     for m, nm in names.items():
-        env = dict(os.environ, **({"COSKAD_ABLG": str(m)} if os.environ.get("ABL_KID") == "5" else {"COSKAD_ABL": str(m)}))
+        key = {"5": "COSKAD_ABLG", "1": "COSKAD_DBG"}.get(os.environ.get("ABL_KID", "2"), "COSKAD_ABL")
+        env = dict(os.environ, **{key: str(m)})
         out = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         print(f"{nm:28s} {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]}", flush=True)
