@@ -928,6 +928,52 @@ __global__ __launch_bounds__(256) void k_sum_to(const float* __restrict__ v, int
   if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)sh[0] : (float)sh[0];
 }
 
+// dA, dT (and optionally the producer's slope gradient) from the block partials in ONE launch:
+// blocks [0, ceil(E/64)) reduce 64 elements x 16 partial-slices of [dA | dT]; one extra block sums `dap` (<= 1024).
+__global__ __launch_bounds__(1024) void k_reduce_gcn(const float* __restrict__ partials, int P, int nA, int nT,
+                                                      float* __restrict__ dA, float* __restrict__ dT,
+                                                      const float* __restrict__ dap, int ndap,
+                                                      float* __restrict__ dslope, int accumulate) {
+  __shared__ double sh[1024];
+  const int E = nA + nT;
+  const int nblk = (E + 63) / 64;
+  if ((int)blockIdx.x == nblk) {     // slope-gradient block (launched only when dap != NULL)
+    double s = 0.0;
+    for (int i = threadIdx.x; i < ndap; i += 1024) s += (double)dap[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dslope[0] = accumulate ? dslope[0] + (float)sh[0] : (float)sh[0];
+    return;
+  }
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < E) {
+    const float* base = partials + e;
+    int p = slice;
+    for (; p + 48 < P; p += 64) {
+      s0 += (double)base[(size_t)p * E];
+      s1 += (double)base[(size_t)(p + 16) * E];
+      s2 += (double)base[(size_t)(p + 32) * E];
+      s3 += (double)base[(size_t)(p + 48) * E];
+    }
+    for (; p < P; p += 16) s0 += (double)base[(size_t)p * E];
+  }
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (slice == 0 && e < E) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+    float* out = e < nA ? dA + e : dT + (e - nA);
+    out[0] = accumulate ? out[0] + (float)t : (float)t;
+  }
+}
+
 static int nb_for(int rows_per_clip, int B, int LD, int budget) {
   int nb = rows_per_clip >= 64 ? 1 : 64 / rows_per_clip;
   if (nb < 1) nb = 1;
@@ -977,7 +1023,8 @@ static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
 template <int T, int V>
 static int launch_layer_gcn_params(const float* in, const float* in_slope, const float* dz, const float* Aw,
                                    const float* Tw, float* dA, float* dT, float* partials, int accumulate, int B,
-                                   int Ci, int Co_tag, hipStream_t st) {
+                                   int Ci, int Co_tag, hipStream_t st, const float* dap = nullptr, int ndap = 0,
+                                   float* dslope = nullptr) {
   constexpr int LD = Geo<T, V>::LD;
   const int E = T * V * V + V * T * T;
   int NB = Ci >= 32 ? 1 : 32 / Ci;
@@ -1000,10 +1047,8 @@ static int launch_layer_gcn_params(const float* in, const float* in_slope, const
   }
   int rc;
   if ((rc = check_launch("bwd_gcn_params"))) return rc;
-  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, partials, grid, E, 0,
-                     T * V * V, dA, accumulate);
-  hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(1024), 0, st, partials, grid, E,
-                     T * V * V, V * T * T, dT, accumulate);
+  hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(E, 64) + (dap ? 1 : 0)), dim3(1024), 0, st, partials, grid, T * V * V,
+                     V * T * T, dA, dT, dap, ndap, dslope, accumulate);
   return check_launch("bwd_gcn_reduce");
 }
 
@@ -1079,6 +1124,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   if ((rc = check_launch("bwd_fold"))) return rc;
   // 3. data path
   int grid_d;
+  const float* dap_sum = nullptr;   // block partials of the producer's slope gradient (summed by stage 4's reduce)
   {
     int NB = Ci >= 32 ? 1 : 32 / Ci;
     if (NB > B) NB = B;
@@ -1132,13 +1178,16 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     }
 #undef LAUNCH_D
     if ((rc = check_launch("bwd_data"))) return rc;
-    if (dap) {
+    if (dap && dz_ext) {   // split call: stage 4 is not ours, finish the slope gradient here
       hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, st, dap, grid_d, dslope_in, accumulate);
       if ((rc = check_launch("bwd_dslope"))) return rc;
     }
+    dap_sum = dap;
   }
   // 4. gcn parameter gradients
-  if (!dz_ext) return launch_layer_gcn_params<T, V>(in, in_slope, w.dz, Aw, Tw, dA, dT, w.partials, accumulate, B, Ci, Co, st);
+  if (!dz_ext)
+    return launch_layer_gcn_params<T, V>(in, in_slope, w.dz, Aw, Tw, dA, dT, w.partials, accumulate, B, Ci, Co, st,
+                                         dap_sum, grid_d, dslope_in);
   return COSKAD_OK;
 }
 
