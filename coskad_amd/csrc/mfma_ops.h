@@ -224,7 +224,7 @@ __device__ __forceinline__ void load_wfold_padded(float* Wl, const float* __rest
 // PReLU)]; KZ, K1, K2 are multiples of 4 (weights of padded rows are zero); Wl[k][CoP] in LDS.
 namespace coskad {
 
-template <int T, int V, int OTI, class Epilogue>
+template <int T, int V, int OTI, int XB = COSKAD_XB, class Epilogue>
 __device__ __forceinline__ void conv_mfma_s(const float* zimg, int KZ, int nz, const float* __restrict__ g1,
                                             int K1, int n1, const float* __restrict__ g2, int K2, int n2,
                                             bool act2, float a2, const float* Wl, int CoP, int og, int s0,
@@ -232,7 +232,6 @@ __device__ __forceinline__ void conv_mfma_s(const float* zimg, int KZ, int nz, c
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   static_assert(TV % 2 == 0, "strip conv needs an even number of positions");
   constexpr int PS = (TV + 31) / 32;
-  constexpr int XB = COSKAD_XB;
   const int lane = threadIdx.x & 63;
   const int j = lane & 15, kk = lane >> 4;
   const int KZS = KZ / 4, KGS = (K1 + K2) / 4, K1S = K1 / 4;

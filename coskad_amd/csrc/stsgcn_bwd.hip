@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce
                                                       const float* __restrict__ Tw,
                                                       const float* __restrict__ in_slope,
                                                       float* __restrict__ partials, int B, int Ci,
-                                                      int Co, int NB, int need_q) {
+                                                      int Co, int NB, int need_q, const float* __restrict__ Zg) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   constexpr int NCH = RedGeo<T, V>::NCH, CH = RedGeo<T, V>::CH, LDC = RedGeo<T, V>::LDC;
   static_assert(TV % 4 == 0, "chunked staging uses float4");
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce
       }
     }
     __syncthreads();
-    gcn_mfma<T, V, false>(ldx, nb * Ci, AwL, TwL);
+    if (Zg) stage_rows<T, V>(Zg + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, false, 0.f);   // stored gcn(X)
+    else gcn_mfma<T, V, false>(ldx, nb * Ci, AwL, TwL);
     for (int ch = 0; ch < NCH; ++ch) {
       const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
       __syncthreads();
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
     const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
     float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
-    int Co, int NB) {
+    int Co, int NB, const float* __restrict__ Zg) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sred[kBlock / 64];
@@ -358,9 +359,13 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
     const float* gdu = dU + (size_t)clip0 * Co * TV;
 
     __syncthreads();
-    stage_rows<T, V>(gin, lds, rows * TV, pre, a_in);
-    __syncthreads();
-    gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
+    if (Zg) {
+      stage_rows<T, V>(Zg + (size_t)clip0 * Ci * TV, lds, rows * TV, false, 0.f);   // stored gcn(X): X itself is only read in phase B
+    } else {
+      stage_rows<T, V>(gin, lds, rows * TV, pre, a_in);
+      __syncthreads();
+      gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
+    }
     __syncthreads();
     // phase A (MFMA): dZ[:,p] = kt + Kt Z[:,p] + Bt dU[:,p], in place over Z.  One item = all channels of a
     // strip, so every Z column is fully read before it is overwritten.
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
     const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
     float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
-    int Co
+    int Co, const float* __restrict__ Zg
 #ifdef COSKAD_ABLATE
     , int abl
 #endif
@@ -536,7 +541,8 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
       lds_conv(WlB + K1 * CiP, accB);
     }
     __syncthreads();
-    if (!(abl & 4)) gcn_mfma<T, V, false>(img, Ci, AwL, TwL, tid);
+    if (Zg) stage_rows<T, V>(Zg + (size_t)clip * Ci * TV, img, Ci * TV, false, 0.f, tid);   // stored gcn(X) replaces X
+    else if (!(abl & 4)) gcn_mfma<T, V, false>(img, Ci, AwL, TwL, tid);
     __syncthreads();
     // phase A: accA = Kt.Z (LDS) + Bt.dU ; accB += Br.dU -- ONE pass over dU
     if (mine) {
@@ -1058,7 +1064,8 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
                             const float* Wr, const float* gr, float* dIn, float* dA, float* dT, float* dWt,
                             float* dbt, float* dgs, float* dbs, float* dWr, float* dbr, float* dgr,
                             float* dbr2, float* dslope_in, void* ws, size_t ws_bytes, int accumulate,
-                            int B, int Ci, int Co, hipStream_t st, float* dz_ext = nullptr) {
+                            int B, int Ci, int Co, hipStream_t st, float* dz_ext = nullptr,
+                            const float* Zg = nullptr) {
   // dz_ext != NULL: dZ goes to the caller's buffer and stage 4 (dA, dT) is left to coskad_layer_gcn_params_f32
   constexpr int LD = Geo<T, V>::LD, TV = Geo<T, V>::TV;
   if (Ci > 64 || Co > 64) return fail(COSKAD_ERR_SHAPE, "layer_bwd: channels (%d,%d) > 64 not supported", Ci, Co);
@@ -1094,7 +1101,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     auto k = k_bwd_reduce<T, V, NTO, NTC>;                                                              \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dU, Aw, Tw, in_slope, w.partials, B,    \
-                       Ci, Co, NB, need_q);                                                             \
+                       Ci, Co, NB, need_q, Zg);                                                         \
   } while (0)
 #define LAUNCH_R_O(NTO)                                          \
   do {                                                           \
@@ -1142,7 +1149,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     auto k = k_bwd_data<T, V, OTI>;                                                                     \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
-                       w.dz, dap, B, Ci, Co, NB);                                                       \
+                       w.dz, dap, B, Ci, Co, NB, Zg);                                                   \
   } while (0)
 #ifdef COSKAD_ABLATE
     static int abl = -1;
@@ -1156,7 +1163,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     auto k = k_bwd_data_f<T, V, OTI>;                                                                   \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
-                       w.dz, dap, B, Ci, Co ABL_ARG);                                                   \
+                       w.dz, dap, B, Ci, Co, Zg ABL_ARG);                                               \
   } while (0)
     static int fused_ok = -1;
     if (fused_ok < 0) { const char* e = getenv("COSKAD_BWD_UNFUSED"); fused_ok = (e && e[0] == '1') ? 0 : 1; }
@@ -1256,6 +1263,26 @@ int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const
   return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
                                   dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
                                   ws_bytes, accumulate, B, Ci, Co, stream)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+/* The same with Z = gcn(PReLU(in)) as stored by coskad_layer_train_stats_z_f32 (NULL: recompute it). */
+int coskad_layer_bwd_z_f32(const float* in, const float* dU, const float* A, const float* Tm,
+                         const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
+                         const float* Wr, const float* gamma_r, float* dIn, float* dA, float* dT, float* dWt,
+                         float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
+                         float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
+                         int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z) {
+  if (!in || !dU || !A || !Tm || !stat || !Wt || !gamma_t || !dA || !dT || !dWt || !dgamma_t || !dbeta_t || !ws)
+    return fail(COSKAD_ERR_ARG, "layer_bwd: null pointer");
+  if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd: residual grads missing");
+  if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_bwd: identity residual needs Ci == Co");
+  if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd: B=%d Ci=%d Co=%d", B, Ci, Co);
+#define CALL(T_, V_)                                                                                       \
+  return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
+                                  dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
+                                  ws_bytes, accumulate, B, Ci, Co, stream, nullptr, Z)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

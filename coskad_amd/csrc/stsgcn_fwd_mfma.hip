@@ -60,6 +60,136 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
   }
 }
 
+// Training-mode layer when Z = gcn(X) was stored by the statistics pass: U = Wz.Z + Wx.PReLU(Xpre) + b is then a pure
+// streaming GEMM -- both operands come from HBM as 8-byte strip loads, nothing is staged, no barrier after the weight
+// load.  A work item is (clip, 32-position strip, output-tile group); waves take items grid-stride, so the MFMA load is
+// balanced over the SIMDs regardless of 7 strips per clip.  LDS: folded weights + bias only.
+#ifndef COSKAD_XBZ
+#define COSKAD_XBZ 4   // k-steps of 8-byte operand loads in flight per wave (everything comes from HBM here)
+#endif
+template <int T, int V, int OTI>
+__global__ __launch_bounds__(256) void k_layer_apply_z(
+    const float* __restrict__ Z, const float* __restrict__ in, float* __restrict__ out,
+    const float* __restrict__ wfold, const float* __restrict__ bias, const float* __restrict__ in_slope,
+    const float* __restrict__ out_slope, int B, int Ci, int Co, int CoP) {
+  constexpr int TV = Geo<T, V>::TV;
+  constexpr int PS = (TV + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int KZ = round_up(Ci, 4);
+  float* Wl = lds;
+  float* bl = Wl + 2 * KZ * CoP;
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const bool post = out_slope != nullptr;
+  const float a_out = post ? out_slope[0] : 0.f;
+  for (int e = threadIdx.x; e < 2 * KZ * CoP; e += 256) {      // load_wfold_padded for a 256-thread block
+    const int k = e / CoP, o = e - k * CoP;
+    const int src = k / KZ, c = k - src * KZ;
+    Wl[e] = c < Ci ? wfold[(size_t)(src * Ci + c) * CoP + o] : 0.f;
+  }
+  for (int e = threadIdx.x; e < CoP; e += 256) bl[e] = bias[e];
+  __syncthreads();
+  const int NOG = (CoP / 16 + OTI - 1) / OTI;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int KS = KZ / 4;                       // k-steps per source
+  constexpr int XB = COSKAD_XBZ;
+  const long long nitems = (long long)B * PS * NOG;
+  for (long long item = (long long)blockIdx.x * 4 + wave; item < nitems; item += (long long)gridDim.x * 4) {
+    const int og = (int)(item % NOG);
+    const long long r = item / NOG;
+    const int sp = (int)(r % PS);
+    const int clip = (int)(r / PS);
+    const int lane = tid_here() & 63;          // lane geometry recomputed per item: nothing address-like stays live
+    const int j = lane & 15, kk = lane >> 4;
+    const int p = 32 * sp + 2 * j;
+    const bool pok = p < TV;
+    const int pc = pok ? p : TV - 2;
+    // lane pointers; k-step g of a source is `+ g * 4 * TV` (rows beyond C_in are clamped: their weights are zero)
+    const int rowk = kk < Ci ? kk : Ci - 1;
+    const float* zp = Z + ((size_t)clip * Ci + rowk) * TV + pc;
+    const float* xp = in + ((size_t)clip * Ci + rowk) * TV + pc;
+    const bool full = (Ci & 3) == 0;
+    auto gload = [&](int g) -> float2 {        // g in [0, 2*KS): Z rows then X rows
+      if (g >= 2 * KS) return float2{0.f, 0.f};
+      const bool isz = g < KS;
+      const int gs = isz ? g : g - KS;
+      const float* base = isz ? zp : xp;
+      int off = gs * 4 * TV;
+      if (!full && 4 * gs + kk >= Ci) off = (Ci - 1 - rowk) * TV;
+      float2 v = *reinterpret_cast<const float2*>(base + off);
+      if (!isz && pre) { v.x = prelu_f(v.x, a_in); v.y = prelu_f(v.y, a_in); }
+      return v;
+    };
+    f32x4 acc[OTI][2];
+#pragma unroll
+    for (int t = 0; t < OTI; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float* wcol = Wl + 16 * og * OTI + j;
+    float2 cur[XB], nxt[XB];
+#pragma unroll
+    for (int u = 0; u < XB; ++u) cur[u] = gload(u);
+    for (int g0 = 0; g0 < 2 * KS; g0 += XB) {
+#pragma unroll
+      for (int u = 0; u < XB; ++u) nxt[u] = gload(g0 + XB + u);
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        if (g0 + u < 2 * KS) {
+          const float* w = wcol + (4 * (g0 + u) + kk) * CoP;     // weight rows: [Z part KZ][X part KZ]
+#pragma unroll
+          for (int t = 0; t < OTI; ++t) {
+            const float a = w[16 * t];
+            acc[t][0] = mfma4(a, cur[u].x, acc[t][0]);
+            acc[t][1] = mfma4(a, cur[u].y, acc[t][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < XB; ++u) cur[u] = nxt[u];
+    }
+    if (pok) {
+      float* ogp = out + (size_t)clip * Co * TV + p;
+#pragma unroll
+      for (int t = 0; t < OTI; ++t)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int o = 16 * (og * OTI + t) + 4 * kk + r4;
+          if (o < Co) {
+            float v0 = acc[t][0][r4] + bl[o], v1 = acc[t][1][r4] + bl[o];
+            if (post) { v0 = prelu_f(v0, a_out); v1 = prelu_f(v1, a_out); }
+            *reinterpret_cast<float2*>(ogp + (size_t)o * TV) = float2{v0, v1};
+          }
+        }
+    }
+  }
+}
+
+template <int T, int V>
+int launch_layer_apply_z(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
+                         const float* in_slope, const float* out_slope, int B, int Ci, int Co, hipStream_t st) {
+  const int CoP = round_up(Co, 16), KZ = round_up(Ci, 4);
+  const size_t lds = ((size_t)2 * KZ * CoP + CoP) * sizeof(float);
+  if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_apply_z: LDS %zu too large", lds);
+  constexpr int PS = (Geo<T, V>::TV + 31) / 32;
+  const long long witems = ((long long)B * PS + 3) / 4;
+  static int gz = -1;
+  if (gz < 0) { const char* e = getenv("COSKAD_GZ"); gz = e ? atoi(e) : 8; }
+  const int grid = (int)(witems < 256 * gz ? witems : 256 * gz);
+#define LAUNCH_Z(OTI)                                                                                 \
+  do {                                                                                                \
+    auto k = k_layer_apply_z<T, V, OTI>;                                                              \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, Z, in, out, wfold, bias, in_slope, out_slope, B, Ci, Co, CoP); \
+  } while (0)
+  ProbeScope probe(KID_LAYER_APPLY, Ci, Co, st);
+  static int otz = -1;
+  if (otz < 0) { const char* e = getenv("COSKAD_OTZ"); otz = e ? atoi(e) : 4; }
+  if (CoP == 16 || otz == 1) LAUNCH_Z(1);
+  else if (CoP == 32 || otz == 2) LAUNCH_Z(2);
+  else if (CoP == 48) LAUNCH_Z(3);
+  else LAUNCH_Z(4);
+#undef LAUNCH_Z
+  return check_launch("layer_apply_z");
+}
+
 size_t layer_apply_m_lds(int T, int V, int Ci, int CoP, int NB) {
   const int TV = T * V, LD = TV % 2 == 0 ? TV + 1 : TV;
   return ((size_t)NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T + 2 * (size_t)round_up(Ci, 4) * CoP + CoP) * sizeof(float);
@@ -103,3 +233,14 @@ template int launch_layer_apply_m<12, 14>(const float*, float*, const float*, co
 template int launch_layer_apply_m<12, 18>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
 
 }  // namespace coskad
+
+using namespace coskad;
+extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const float* wfold,
+                                        const float* bias, const float* in_slope, const float* out_slope, int B,
+                                        int Ci, int Co, int T, int V, hipStream_t stream) {
+  if (!Z || !in || !out || !wfold || !bias) return fail(COSKAD_ERR_ARG, "layer_apply_z: null pointer");
+  if (B <= 0 || Ci <= 0 || Co <= 0 || Co > 64 || Ci > 64) return fail(COSKAD_ERR_ARG, "layer_apply_z: B=%d Ci=%d Co=%d", B, Ci, Co);
+#define CALL(T_, V_) return launch_layer_apply_z<T_, V_>(Z, in, out, wfold, bias, in_slope, out_slope, B, Ci, Co, stream)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}

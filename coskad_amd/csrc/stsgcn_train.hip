@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kBlock, (NTC <= 2 ? 6 : 4)) void k_fwd_moments(cons
                                                        const float* __restrict__ Tw,
                                                        const float* __restrict__ in_slope,
                                                        float* __restrict__ partials, int B, int Ci,
-                                                       int NB, int need_x) {
+                                                       int NB, int need_x, float* __restrict__ Zout) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* scratch = lds;                 // kScratchFloats, aliased onto the row image (only used after the tile loop)
@@ -54,6 +54,8 @@ __global__ __launch_bounds__(kBlock, (NTC <= 2 ? 6 : 4)) void k_fwd_moments(cons
     }
     gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
     __syncthreads();
+    // Z = gcn(X) is kept for the rest of the step (apply and both backward kernels read it instead of recomputing)
+    if (Zout) unstage_rows<T, V>(Zout + (size_t)clip0 * Ci * TV, lds, rows * TV);
     for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC>(lds + n * Ci * LD, Ci, mz, sz);
   }
   // partial layout: [MX Ci*Ci][sumX Ci][MZ Ci*Ci][sumZ Ci]
@@ -226,7 +228,7 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
                               const float* br, const float* gr, const float* brr, float* rm_r,
                               float* rv_r, long long* nbt_r, float momentum, float* wfold, float* bias,
                               float* stat, void* ws, size_t ws_bytes, int B, int Ci, int Co,
-                              hipStream_t st) {
+                              hipStream_t st, float* Zout = nullptr) {
   constexpr int LD = Geo<T, V>::LD, TV = Geo<T, V>::TV;
   if (Ci > 64) return fail(COSKAD_ERR_SHAPE, "train_stats: C_in=%d > 64 not supported", Ci);
   if (ws_bytes < train_stats_ws_bytes(Ci))
@@ -249,7 +251,7 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   do {                                                                                          \
     auto k = k_fwd_moments<T, V, NTC>;                                                          \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, Aw, Tw, in_slope, partials, B, Ci, NB, need_x); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, Aw, Tw, in_slope, partials, B, Ci, NB, need_x, Zout); \
   } while (0)
   {
   ProbeScope probe(KID_FWD_MOMENTS, Ci, Co, st);
@@ -298,6 +300,28 @@ int coskad_layer_train_stats_f32(const float* in, const float* A, const float* T
   return launch_train_stats<T_, V_>(in, A, Tm, in_slope, Wt, bt, gamma_t, beta_t, rmean_t, rvar_t, nbt_t, \
                                     Wr, br, gamma_r, beta_r, rmean_r, rvar_r, nbt_r, momentum, wfold, \
                                     bias, stat, ws, ws_bytes, B, Ci, Co, stream)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+/* The same, additionally storing Z = gcn(PReLU(in)) [B,Ci,T,V] for coskad_layer_apply_z_f32 and the *_z backward. */
+int coskad_layer_train_stats_z_f32(const float* in, const float* A, const float* Tm, const float* in_slope,
+                                 const float* Wt, const float* bt, const float* gamma_t,
+                                 const float* beta_t, float* rmean_t, float* rvar_t, long long* nbt_t,
+                                 const float* Wr, const float* br, const float* gamma_r,
+                                 const float* beta_r, float* rmean_r, float* rvar_r, long long* nbt_r,
+                                 float momentum, float* wfold, float* bias, float* stat, void* ws,
+                                 size_t ws_bytes, int B, int Ci, int Co, int T, int V,
+                                 hipStream_t stream, float* Z) {
+  if (!in || !A || !Tm || !Wt || !gamma_t || !beta_t || !wfold || !bias || !stat || !ws)
+    return fail(COSKAD_ERR_ARG, "layer_train_stats: null pointer");
+  if (Wr && (!gamma_r || !beta_r)) return fail(COSKAD_ERR_ARG, "layer_train_stats: residual BN missing");
+  if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_train_stats: identity residual needs Ci == Co");
+  if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_train_stats: B=%d Ci=%d Co=%d", B, Ci, Co);
+#define CALL(T_, V_)                                                                                   \
+  return launch_train_stats<T_, V_>(in, A, Tm, in_slope, Wt, bt, gamma_t, beta_t, rmean_t, rvar_t, nbt_t, \
+                                    Wr, br, gamma_r, beta_r, rmean_r, rvar_r, nbt_r, momentum, wfold, \
+                                    bias, stat, ws, ws_bytes, B, Ci, Co, stream, Z)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

@@ -12,6 +12,7 @@ Everything here is plumbing around C-ABI calls (coskad_amd.ops); there is no CPU
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -99,6 +100,7 @@ class ChainCtx:
     """What chain_backward needs from chain_forward (train mode)."""
     inputs: List[Tensor] = field(default_factory=list)   # input of layer i (x, U_0, U_1, ...)
     stats: List[Tensor] = field(default_factory=list)    # stat block of layer i
+    zs: List[Optional[Tensor]] = field(default_factory=list)   # stored gcn(input) of layer i (None: recompute)
     in_slope: Optional[Tensor] = None                    # activation applied to inputs[0] (None: raw)
 
 
@@ -111,21 +113,33 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
     for L in layers:
         if h.shape[1] != L.Ci:
             raise ValueError(f"layer expects {L.Ci} input channels, got {h.shape[1]}")
+        Z = None
         if training:
             buf = ws.get(ops.train_stats_ws_bytes(L.Ci), x.device)
+            if STORE_Z:
+                Z = torch.empty_like(h)     # gcn(PReLU(h)): written by the statistics pass, read by everything after
             wfold, bias, stat = ops.layer_train_stats(
                 h, L.A, L.T, slope, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
-                L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum)
+                L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum, Z=Z)
         else:
             wfold, bias = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t,
                                       L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
             stat = None
-        u = ops.layer_apply(h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)
+        if Z is not None and L.Co <= 32:    # streaming GEMM over Z and h; for 64 output channels the fused kernel wins
+            u = ops.layer_apply_z(Z, h, wfold, bias, L.Co, in_slope=slope)
+        else:
+            u = ops.layer_apply(h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)
         if ctx is not None:
             ctx.inputs.append(h)
             ctx.stats.append(stat)
+            ctx.zs.append(Z)
         h, slope = u, L.slope
     return h, ctx
+
+
+# training forward keeps Z = gcn(X) of every layer (82 channels x 816 B per clip) instead of recomputing the mixing in the
+# apply and backward kernels; COSKAD_STORE_Z=0 selects the recompute path
+STORE_Z = os.environ.get("COSKAD_STORE_Z", "1") != "0"
 
 
 class SideStream:
@@ -174,7 +188,7 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
         buf = ws.get(ops.layer_bwd_ws_bytes(B, Ci, L.Co, T, V), x_in.device)
         args = (x_in, dU, L.A, L.T, in_slope, ctx.stats[i], L.w2(L.Wt), L.gt, L.w2(L.Wr), L.gr, _as2d(g), buf)
         if side is None:
-            dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate)
+            dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate, Z=ctx.zs[i] if ctx.zs else None)
         else:
             k = i & 1
             side.ensure(max(x.numel() for x in ctx.inputs), ops.layer_gcn_params_ws_bytes(T, V), x_in.device)

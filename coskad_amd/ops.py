@@ -95,8 +95,9 @@ def train_stats_ws_bytes(Ci: int) -> int:
 
 
 def layer_train_stats(x, A, Tm, in_slope, Wt, bt, gt, bet, rm_t, rv_t, nbt_t,
-                      Wr, br, gr, ber, rm_r, rv_r, nbt_r, ws, momentum: float = 0.1):
-    """Train-mode BN statistics of one layer -> (wfold, bias, stat); updates running stats in place."""
+                      Wr, br, gr, ber, rm_r, rv_r, nbt_r, ws, momentum: float = 0.1, Z: Optional[Tensor] = None):
+    """Train-mode BN statistics of one layer -> (wfold, bias, stat); updates running stats in place.
+    Z (optional, same shape as x): receives gcn(PReLU(x)) for layer_apply_z and the stored-Z backward."""
     B, Ci, T, V = x.shape
     Co = Wt.shape[0]
     _chk(x, "x"); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
@@ -114,11 +115,28 @@ def layer_train_stats(x, A, Tm, in_slope, Wt, bt, gt, bet, rm_t, rv_t, nbt_t,
     wfold = torch.empty(2 * Ci, cop(Co), device=x.device, dtype=torch.float32)
     bias = torch.empty(cop(Co), device=x.device, dtype=torch.float32)
     stat = torch.empty(stat_floats(Ci, Co), device=x.device, dtype=torch.float32)
-    call("coskad_layer_train_stats_f32", ptr(x), ptr(A), ptr(Tm), ptr(in_slope), ptr(Wt), ptr(bt), ptr(gt),
-         ptr(bet), ptr(rm_t), ptr(rv_t), ptr(nbt_t), ptr(Wr), ptr(br), ptr(gr), ptr(ber), ptr(rm_r),
-         ptr(rv_r), ptr(nbt_r), ctypes.c_float(momentum), ptr(wfold), ptr(bias), ptr(stat), ptr(ws),
-         ctypes.c_size_t(ws.numel() * ws.element_size()), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    _chk(Z, "Z", tuple(x.shape), optional=True)
+    args = (ptr(x), ptr(A), ptr(Tm), ptr(in_slope), ptr(Wt), ptr(bt), ptr(gt),
+            ptr(bet), ptr(rm_t), ptr(rv_t), ptr(nbt_t), ptr(Wr), ptr(br), ptr(gr), ptr(ber), ptr(rm_r),
+            ptr(rv_r), ptr(nbt_r), ctypes.c_float(momentum), ptr(wfold), ptr(bias), ptr(stat), ptr(ws),
+            ctypes.c_size_t(ws.numel() * ws.element_size()), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    if Z is None:
+        call("coskad_layer_train_stats_f32", *args)
+    else:
+        call("coskad_layer_train_stats_z_f32", *args, ptr(Z))
     return wfold, bias, stat
+
+
+def layer_apply_z(Z, x, wfold, bias, Co, in_slope=None, out_slope=None, out=None):
+    """U = Wz.Z + Wx.PReLU(x) + b from the stored Z = gcn(PReLU(x)) (training forward; streaming, no recompute)."""
+    B, Ci, T, V = x.shape
+    _chk(x, "x"); _chk(Z, "Z", (B, Ci, T, V)); _chk(wfold, "wfold", (2 * Ci, cop(Co))); _chk(bias, "bias", (cop(Co),))
+    _chk(in_slope, "in_slope", (1,), optional=True); _chk(out_slope, "out_slope", (1,), optional=True)
+    if out is None:
+        out = torch.empty(B, Co, T, V, device=x.device, dtype=torch.float32)
+    call("coskad_layer_apply_z_f32", ptr(Z), ptr(x), ptr(out), ptr(wfold), ptr(bias), ptr(in_slope), ptr(out_slope),
+         i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    return out
 
 
 def _bytes(t: Tensor) -> int:
@@ -132,7 +150,7 @@ def layer_bwd_ws_bytes(B, Ci, Co, T, V) -> int:
 
 
 def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, need_dx=True,
-              dIn=None, accumulate=False):
+              dIn=None, accumulate=False, Z=None):
     """Backward of one layer.  `grads` maps names -> preallocated gradient tensors:
     A, T, Wt, bt (opt), gt, bet, Wr, br (opt), gr, ber, slope_in (opt).  Returns dIn (or None)."""
     B, Ci, T, V = x_in.shape
@@ -150,11 +168,16 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
         raise ValueError(f"workspace too small: need {need} bytes")
     if need_dx and dIn is None:
         dIn = torch.empty_like(x_in)
-    call("coskad_layer_bwd_f32", ptr(x_in), ptr(dU), ptr(A), ptr(Tm), ptr(in_slope), ptr(stat), ptr(Wt), ptr(gt),
-         ptr(Wr), ptr(gr), ptr(dIn if need_dx else None), ptr(grads["A"]), ptr(grads["T"]), ptr(grads["Wt"]),
-         ptr(grads.get("bt")), ptr(grads["gt"]), ptr(grads["bet"]), ptr(grads.get("Wr")), ptr(grads.get("br")),
-         ptr(grads.get("gr")), ptr(grads.get("ber")), ptr(grads.get("slope_in")), ptr(ws),
-         ctypes.c_size_t(_bytes(ws)), i32(1 if accumulate else 0), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    _chk(Z, "Z", (B, Ci, T, V), optional=True)
+    args = (ptr(x_in), ptr(dU), ptr(A), ptr(Tm), ptr(in_slope), ptr(stat), ptr(Wt), ptr(gt),
+            ptr(Wr), ptr(gr), ptr(dIn if need_dx else None), ptr(grads["A"]), ptr(grads["T"]), ptr(grads["Wt"]),
+            ptr(grads.get("bt")), ptr(grads["gt"]), ptr(grads["bet"]), ptr(grads.get("Wr")), ptr(grads.get("br")),
+            ptr(grads.get("gr")), ptr(grads.get("ber")), ptr(grads.get("slope_in")), ptr(ws),
+            ctypes.c_size_t(_bytes(ws)), i32(1 if accumulate else 0), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    if Z is None:
+        call("coskad_layer_bwd_f32", *args)
+    else:       # stored gcn(PReLU(x_in)) from layer_train_stats(..., Z=...): no mixing recompute in the backward kernels
+        call("coskad_layer_bwd_z_f32", *args, ptr(Z))
     return dIn if need_dx else None
 
 

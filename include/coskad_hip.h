@@ -80,6 +80,20 @@ int coskad_layer_train_stats_f32(const float* in, const float* A, const float* T
                                  size_t ws_bytes, int B, int Ci, int Co, int T, int V,
                                  hipStream_t stream);
 
+/* Stored-Z variant of the training forward: the statistics pass also writes Z = gcn(PReLU(in)) [B,Ci,T,V]; the layer
+ * is then a streaming GEMM over Z and `in` (no staging, no mixing recompute), and the backward reads Z as well. */
+int coskad_layer_train_stats_z_f32(const float* in, const float* A, const float* Tm, const float* in_slope,
+                                   const float* Wt, const float* bt, const float* gamma_t,
+                                   const float* beta_t, float* rmean_t, float* rvar_t, long long* nbt_t,
+                                   const float* Wr, const float* br, const float* gamma_r,
+                                   const float* beta_r, float* rmean_r, float* rvar_r, long long* nbt_r,
+                                   float momentum, float* wfold, float* bias, float* stat, void* ws,
+                                   size_t ws_bytes, int B, int Ci, int Co, int T, int V,
+                                   hipStream_t stream, float* Z);
+int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
+                             const float* in_slope, const float* out_slope, int B, int Ci, int Co, int T, int V,
+                             hipStream_t stream);
+
 /* ---- backward of one ST_GCNN_layer (autograd of stsgcn.py:94-116 in training mode) ------ */
 
 size_t coskad_layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V);
@@ -98,6 +112,15 @@ int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const
                          float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
                          float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                          int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream);
+
+/* coskad_layer_bwd_f32 reading the stored Z = gcn(PReLU(in)) of coskad_layer_train_stats_z_f32 instead of recomputing
+ * the mixing in its reduction and data kernels (Z == NULL: identical to coskad_layer_bwd_f32). */
+int coskad_layer_bwd_z_f32(const float* in, const float* dU, const float* A, const float* Tm,
+                           const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
+                           const float* Wr, const float* gamma_r, float* dIn, float* dA, float* dT, float* dWt,
+                           float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
+                           float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
+                           int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z);
 
 /* The same backward split in two calls, so that stage 4 (dA, dT; independent of the rest of the chain) can be enqueued
  * on a second stream: coskad_layer_bwd_data_f32 = batch reductions + fold + data path, with the mixing-output gradient
