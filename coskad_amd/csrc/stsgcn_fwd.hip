@@ -208,7 +208,7 @@ static int pick_nb(int Ci, int B, int LD) {
 template <int T, int V>
 int launch_layer_apply_m(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold,
                          const float* bias, const float* in_slope, const float* out_slope, int B, int Ci,
-                         int Co, hipStream_t st);  // stsgcn_fwd_mfma.hip
+                         int Co, hipStream_t st, const float* Zg);  // stsgcn_fwd_mfma.hip
 
 static int use_mfma() {
   static int v = -1;
@@ -225,7 +225,7 @@ static int launch_layer_apply(const float* in, float* out, const float* Aw, cons
                               const float* out_slope, int B, int Ci, int Co, hipStream_t st) {
   constexpr int LD = Geo<T, V>::LD;
   if (use_mfma()) {
-    const int rc = launch_layer_apply_m<T, V>(in, out, Aw, Tw, wfold, bias, in_slope, out_slope, B, Ci, Co, st);
+    const int rc = launch_layer_apply_m<T, V>(in, out, Aw, Tw, wfold, bias, in_slope, out_slope, B, Ci, Co, st, nullptr);
     if (rc <= 0) return rc;   // 1 = does not fit in LDS: VALU kernel below
   }
   const int CoP = round_up(Co, 16);

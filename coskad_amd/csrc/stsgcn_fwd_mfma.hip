@@ -12,7 +12,7 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
     const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ wfold, const float* __restrict__ bias,
     const float* __restrict__ in_slope, const float* __restrict__ out_slope, int B, int Ci, int Co,
-    int CoP, int NB, int dbg) {
+    int CoP, int NB, int dbg, const float* __restrict__ Zg) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int KZ = round_up(Ci, 4);
@@ -38,9 +38,13 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
     const int rows = nb * Ci;
     const float* gin = in + (size_t)clip0 * Ci * TV;
     __syncthreads();  // tables ready / previous tile's conv reads done
-    if (!(dbg & 4)) stage_rows<T, V>(gin, img, rows * TV, pre, a_in);
-    __syncthreads();
-    if (!(dbg & 1)) gcn_mfma<T, V, false>(img, rows, AwL, TwL);
+    if (Zg) {              // stored Z = gcn(X) (training: written by the statistics pass): stage it, skip the mixing
+      stage_rows<T, V>(Zg + (size_t)clip0 * Ci * TV, img, rows * TV, false, 0.f);
+    } else {
+      if (!(dbg & 4)) stage_rows<T, V>(gin, img, rows * TV, pre, a_in);
+      __syncthreads();
+      if (!(dbg & 1)) gcn_mfma<T, V, false>(img, rows, AwL, TwL);
+    }
     __syncthreads();
     for (int n = 0; n < nb && !(dbg & 2); ++n) {
       float* og = out + (size_t)(clip0 + n) * Co * TV;
@@ -198,7 +202,7 @@ size_t layer_apply_m_lds(int T, int V, int Ci, int CoP, int NB) {
 template <int T, int V>
 int launch_layer_apply_m(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold,
                          const float* bias, const float* in_slope, const float* out_slope, int B, int Ci,
-                         int Co, hipStream_t st) {
+                         int Co, hipStream_t st, const float* Zg) {
   const int CoP = round_up(Co, 16);
   int NB = Ci >= 32 ? 1 : 32 / Ci;   // 32 rows per tile: 2 row tiles of 16
   if (NB > B) NB = B;
@@ -213,7 +217,7 @@ int launch_layer_apply_m(const float* in, float* out, const float* Aw, const flo
     auto k = k_layer_apply_m<T, V, OTI>;                                                            \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, out, Aw, Tw, wfold, bias, in_slope,   \
-                       out_slope, B, Ci, Co, CoP, NB, dbg);                                         \
+                       out_slope, B, Ci, Co, CoP, NB, dbg, Zg);                                     \
   } while (0)
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("COSKAD_DBG"); dbg = e ? atoi(e) : 0; }
@@ -227,20 +231,25 @@ int launch_layer_apply_m(const float* in, float* out, const float* Aw, const flo
 }
 
 // explicit instantiations used by stsgcn_fwd.hip's dispatcher
-template int launch_layer_apply_m<12, 17>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
-template int launch_layer_apply_m<12, 25>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
-template int launch_layer_apply_m<12, 14>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
-template int launch_layer_apply_m<12, 18>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t);
+template int launch_layer_apply_m<12, 17>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t, const float*);
+template int launch_layer_apply_m<12, 25>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t, const float*);
+template int launch_layer_apply_m<12, 14>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t, const float*);
+template int launch_layer_apply_m<12, 18>(const float*, float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, hipStream_t, const float*);
 
 }  // namespace coskad
 
 using namespace coskad;
-extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const float* wfold,
-                                        const float* bias, const float* in_slope, const float* out_slope, int B,
-                                        int Ci, int Co, int T, int V, hipStream_t stream) {
-  if (!Z || !in || !out || !wfold || !bias) return fail(COSKAD_ERR_ARG, "layer_apply_z: null pointer");
+extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const float* A, const float* Tm,
+                                        const float* wfold, const float* bias, const float* in_slope,
+                                        const float* out_slope, int B, int Ci, int Co, int T, int V,
+                                        hipStream_t stream) {
+  if (!Z || !in || !out || !A || !Tm || !wfold || !bias) return fail(COSKAD_ERR_ARG, "layer_apply_z: null pointer");
   if (B <= 0 || Ci <= 0 || Co <= 0 || Co > 64 || Ci > 64) return fail(COSKAD_ERR_ARG, "layer_apply_z: B=%d Ci=%d Co=%d", B, Ci, Co);
-#define CALL(T_, V_) return launch_layer_apply_z<T_, V_>(Z, in, out, wfold, bias, in_slope, out_slope, B, Ci, Co, stream)
+  // <= 32 output channels: streaming GEMM over Z and `in`; wider: the LDS-tiled kernel with Z staged instead of mixed
+  // (needs the mixing tables only as a layout; A/Tm are not read when Z is given)
+#define CALL(T_, V_)                                                                                              \
+  return Co <= 32 ? launch_layer_apply_z<T_, V_>(Z, in, out, wfold, bias, in_slope, out_slope, B, Ci, Co, stream) \
+                  : launch_layer_apply_m<T_, V_>(in, out, A, Tm, wfold, bias, in_slope, out_slope, B, Ci, Co, stream, Z)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

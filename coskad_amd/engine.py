@@ -125,8 +125,8 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
             wfold, bias = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t,
                                       L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
             stat = None
-        if Z is not None and L.Co <= 32:    # streaming GEMM over Z and h; for 64 output channels the fused kernel wins
-            u = ops.layer_apply_z(Z, h, wfold, bias, L.Co, in_slope=slope)
+        if Z is not None:
+            u = ops.layer_apply_z(Z, h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)
         else:
             u = ops.layer_apply(h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)
         if ctx is not None:

@@ -127,14 +127,15 @@ def layer_train_stats(x, A, Tm, in_slope, Wt, bt, gt, bet, rm_t, rv_t, nbt_t,
     return wfold, bias, stat
 
 
-def layer_apply_z(Z, x, wfold, bias, Co, in_slope=None, out_slope=None, out=None):
+def layer_apply_z(Z, x, A, Tm, wfold, bias, Co, in_slope=None, out_slope=None, out=None):
     """U = Wz.Z + Wx.PReLU(x) + b from the stored Z = gcn(PReLU(x)) (training forward; streaming, no recompute)."""
     B, Ci, T, V = x.shape
     _chk(x, "x"); _chk(Z, "Z", (B, Ci, T, V)); _chk(wfold, "wfold", (2 * Ci, cop(Co))); _chk(bias, "bias", (cop(Co),))
     _chk(in_slope, "in_slope", (1,), optional=True); _chk(out_slope, "out_slope", (1,), optional=True)
     if out is None:
         out = torch.empty(B, Co, T, V, device=x.device, dtype=torch.float32)
-    call("coskad_layer_apply_z_f32", ptr(Z), ptr(x), ptr(out), ptr(wfold), ptr(bias), ptr(in_slope), ptr(out_slope),
+    _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
+    call("coskad_layer_apply_z_f32", ptr(Z), ptr(x), ptr(out), ptr(A), ptr(Tm), ptr(wfold), ptr(bias), ptr(in_slope), ptr(out_slope),
          i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
     return out
 

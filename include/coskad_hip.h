@@ -90,9 +90,9 @@ int coskad_layer_train_stats_z_f32(const float* in, const float* A, const float*
                                    float momentum, float* wfold, float* bias, float* stat, void* ws,
                                    size_t ws_bytes, int B, int Ci, int Co, int T, int V,
                                    hipStream_t stream, float* Z);
-int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
-                             const float* in_slope, const float* out_slope, int B, int Ci, int Co, int T, int V,
-                             hipStream_t stream);
+int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const float* A, const float* Tm,
+                             const float* wfold, const float* bias, const float* in_slope, const float* out_slope,
+                             int B, int Ci, int Co, int T, int V, hipStream_t stream);
 
 /* ---- backward of one ST_GCNN_layer (autograd of stsgcn.py:94-116 in training mode) ------ */
 
