@@ -158,6 +158,85 @@ __global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce
   store_rowsums<NTO>(srow, scratch, dst + 2 * Co * Ci, Co);
 }
 
+// Stored-Z variant: X and Z = gcn(X) both sit in LDS (no mixing tables needed), so ONE pass over dU feeds both
+// P = sum dU Z^T and Q = sum dU X^T -- half the dU staging and barriers of the recompute kernel above.
+template <int NTA, int NTB>
+__device__ __forceinline__ void outer_accum_pq(const float* ldsA, int ldA, int va, const float* ldsX, const float* ldsZ,
+                                               int ldB, int offB, int vb, int npos, bool need_q,
+                                               f32x4 (&pacc)[NTA][NTB], f32x4 (&qacc)[NTA][NTB], float (&rs)[NTA]) {
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int i = lane & 15, k = lane >> 4;
+  for (int p0 = 4 * wave; p0 < npos; p0 += 4 * (kBlock / 64)) {
+    const bool pok = p0 + k < npos;
+    float a[NTA], bz[NTB], bx[NTB];
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) {
+      const int row = 16 * ta + i;
+      a[ta] = (pok && row < va) ? ldsA[row * ldA + p0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+      const int row = 16 * tb + i;
+      const bool ok = pok && row < vb;
+      bz[tb] = ok ? ldsZ[row * ldB + offB + p0 + k] : 0.f;
+      bx[tb] = (ok && need_q) ? ldsX[row * ldB + offB + p0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) {
+#pragma unroll
+      for (int tb = 0; tb < NTB; ++tb) {
+        pacc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], bz[tb], pacc[ta][tb], 0, 0, 0);
+        if (need_q) qacc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], bx[tb], qacc[ta][tb], 0, 0, 0);
+      }
+      rs[ta] += a[ta];
+    }
+  }
+}
+
+template <int T, int V, int NTO, int NTC>
+__global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce_z(
+    const float* __restrict__ in, const float* __restrict__ Zg, const float* __restrict__ dU,
+    const float* __restrict__ in_slope, float* __restrict__ partials, int B, int Ci, int Co, int NB, int need_q) {
+  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int NCH = RedGeo<T, V>::NCH, CH = RedGeo<T, V>::CH, LDC = RedGeo<T, V>::LDC;
+  static_assert(TV % 4 == 0, "chunked staging uses float4");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldz = lds;                         // Z image: NB*Ci rows x LD
+  float* ldx = ldz + NB * Ci * LD;          // X image (only when the residual branch has a conv)
+  float* ldu = ldx + (need_q ? NB * Ci * LD : 0);   // dU slab: NB*Co rows x LDC
+  float* scratch = lds;                     // aliased: used after the tile loop only
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  f32x4 pacc[NTO][NTC], qacc[NTO][NTC];
+  float srow[NTO];
+  zero_acc(pacc); zero_acc(qacc);
+#pragma unroll
+  for (int t = 0; t < NTO; ++t) srow[t] = 0.f;
+  const int ntiles = ceil_div(B, NB);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int clip0 = tile * NB;
+    const int nb = min(NB, B - clip0);
+    const float* gdu = dU + (size_t)clip0 * Co * TV;
+    __syncthreads();
+    stage_rows<T, V>(Zg + (size_t)clip0 * Ci * TV, ldz, nb * Ci * TV, false, 0.f);
+    if (need_q) stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, pre, a_in);
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
+      if (ch > 0) __syncthreads();          // the previous slab has been consumed
+      stage_chunk<T, V>(gdu, ldu, nb * Co, pbeg, npos);
+      __syncthreads();
+      for (int n = 0; n < nb; ++n)
+        outer_accum_pq<NTO, NTC>(ldu + n * Co * LDC, LDC, Co, ldx + n * Ci * LD, ldz + n * Ci * LD, LD, pbeg, Ci, npos,
+                                 need_q != 0, pacc, qacc, srow);
+    }
+  }
+  float* dst = partials + (size_t)blockIdx.x * (2 * Co * Ci + Co);
+  store_outer<NTO, NTC>(pacc, scratch, dst, Ci, Co, Ci);
+  store_outer<NTO, NTC>(qacc, scratch, dst + Co * Ci, Ci, Co, Ci);
+  store_rowsums<NTO>(srow, scratch, dst + 2 * Co * Ci, Co);
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_partials_d(const float* __restrict__ partials, int P, int E,
                                                              double* __restrict__ out) {
   __shared__ double sh[1024];
@@ -1085,6 +1164,48 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
       return (img + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
     };
     const int nto = ceil_div(Co, 16), ntc = ceil_div(Ci, 16);
+    const int need_q = Wr != nullptr;
+    if (Zg) {        // stored Z: one dU pass, no mixing tables in LDS
+      auto zlds = [&](int nb_) {
+        size_t img = (size_t)(need_q ? 2 : 1) * nb_ * Ci * LD + (size_t)nb_ * Co * RedGeo<T, V>::LDC;
+        if (img < (size_t)kScratchFloats) img = kScratchFloats;
+        return img * sizeof(float);
+      };
+      const bool three_z = nto * ntc <= 2;
+      const size_t cap = three_z ? (size_t)52 * 1024 : (size_t)76 * 1024;
+      int NBz = NB;
+      while (NBz > 1 && zlds(NBz) > cap) --NBz;
+      const size_t ldsz = zlds(NBz);
+      if (ldsz > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", ldsz);
+      const int ntl = ceil_div(B, NBz);
+      int gridz = 256 * ((three_z && ldsz <= cap) ? 3 : (ldsz <= (size_t)80 * 1024 ? 2 : 1));
+      if (gridz > ntl) gridz = ntl;
+#define LAUNCH_RZ(NTO, NTC)                                                                              \
+  do {                                                                                                  \
+    auto k = k_bwd_reduce_z<T, V, NTO, NTC>;                                                            \
+    if (ldsz > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz); \
+    hipLaunchKernelGGL(k, dim3(gridz), dim3(kBlock), ldsz, st, in, Zg, dU, in_slope, w.partials, B, Ci, Co, NBz, need_q); \
+  } while (0)
+#define LAUNCH_RZ_O(NTO)                                         \
+  do {                                                           \
+    if (ntc == 1) LAUNCH_RZ(NTO, 1);                             \
+    else if (ntc == 2) LAUNCH_RZ(NTO, 2);                        \
+    else if (ntc == 3) LAUNCH_RZ(NTO, 3);                        \
+    else LAUNCH_RZ(NTO, 4);                                      \
+  } while (0)
+      {
+        ProbeScope probe(KID_BWD_REDUCE, Ci, Co, st);
+        if (nto == 1) LAUNCH_RZ_O(1);
+        else if (nto == 2) LAUNCH_RZ_O(2);
+        else if (nto == 3) LAUNCH_RZ_O(3);
+        else LAUNCH_RZ_O(4);
+      }
+#undef LAUNCH_RZ_O
+#undef LAUNCH_RZ
+      if ((rc = check_launch("bwd_reduce_z"))) return rc;
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, gridz, E, w.red);
+      if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+    } else {
     // blocks per CU: three when the accumulators are small enough for 6 waves/SIMD and the images fit a third of
     // the LDS (fewer clips per tile if need be), else two
     const bool three = nto * ntc <= 2;
@@ -1095,7 +1216,6 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     const int ntiles = ceil_div(B, NB);
     int grid = 256 * ((three && lds <= lds_cap) ? 3 : (lds <= (size_t)80 * 1024 ? 2 : 1));
     if (grid > ntiles) grid = ntiles;
-    const int need_q = Wr != nullptr;
 #define LAUNCH_R(NTO, NTC)                                                                              \
   do {                                                                                                  \
     auto k = k_bwd_reduce<T, V, NTO, NTC>;                                                              \
@@ -1122,6 +1242,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if ((rc = check_launch("bwd_reduce"))) return rc;
     hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, grid, E, w.red);
     if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+    }
   }
   // 2. fold
   const size_t fold_lds = (size_t)(6 * Co + 2 * Co * Ci + Co) * sizeof(double) + (size_t)(2 * Co * Ci + 2 * Ci) * sizeof(float);
@@ -1294,7 +1415,7 @@ int coskad_layer_bwd_data_f32(const float* in, const float* dU, const float* A, 
                               const float* Wr, const float* gamma_r, float* dIn, float* dZ, float* dWt, float* dbt,
                               float* dgamma_t, float* dbeta_t, float* dWr, float* dbr, float* dgamma_r,
                               float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes, int accumulate, int B,
-                              int Ci, int Co, int T, int V, hipStream_t stream) {
+                              int Ci, int Co, int T, int V, hipStream_t stream, const float* Z) {
   if (!in || !dU || !A || !Tm || !stat || !Wt || !gamma_t || !dZ || !dWt || !dgamma_t || !dbeta_t || !ws)
     return fail(COSKAD_ERR_ARG, "layer_bwd_data: null pointer");
   if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd_data: residual grads missing");
@@ -1303,7 +1424,7 @@ int coskad_layer_bwd_data_f32(const float* in, const float* dU, const float* A, 
 #define CALL(T_, V_)                                                                                              \
   return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, nullptr, nullptr, dWt, \
                                   dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws, ws_bytes,   \
-                                  accumulate, B, Ci, Co, stream, dZ)
+                                  accumulate, B, Ci, Co, stream, dZ, Z)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

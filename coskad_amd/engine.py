@@ -195,7 +195,7 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
             if side.done[k] is not None:
                 main.wait_event(side.done[k])          # the side kernels that read this dZ image are finished
             dz = side.dz[k][:x_in.numel()].view(B, Ci, T, V)
-            dIn = ops.layer_bwd_data(*args, dZ=dz, need_dx=want_dx, accumulate=accumulate)
+            dIn = ops.layer_bwd_data(*args, dZ=dz, need_dx=want_dx, accumulate=accumulate, Z=ctx.zs[i] if ctx.zs else None)
             side.stream.wait_stream(main)
             with torch.cuda.stream(side.stream):
                 ops.layer_gcn_params(x_in, in_slope, dz, L.A, L.T, g["A"], g["T"], side.ws, accumulate=accumulate)

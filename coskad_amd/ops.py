@@ -183,7 +183,7 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
 
 
 def layer_bwd_data(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, dZ, need_dx=True, dIn=None,
-                   accumulate=False):
+                   accumulate=False, Z=None):
     """Stages 1-3 of layer_bwd (everything but dA, dT); dZ [B,Ci,T,V] receives the mixing-output gradient that
     layer_gcn_params consumes (possibly on another stream).  Returns dIn (or None)."""
     B, Ci, T, V = x_in.shape
@@ -191,7 +191,7 @@ def layer_bwd_data(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict,
     _chk(x_in, "x_in"); _chk(dU, "dU", (B, Co, T, V)); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
     _chk(Wt, "Wt", (Co, Ci)); _chk(gt, "gamma_t", (Co,)); _chk(stat, "stat", (stat_floats(Ci, Co),))
     _chk(Wr, "Wr", (Co, Ci), optional=True); _chk(gr, "gamma_r", (Co,), optional=True)
-    _chk(in_slope, "in_slope", (1,), optional=True); _chk(dZ, "dZ", (B, Ci, T, V))
+    _chk(in_slope, "in_slope", (1,), optional=True); _chk(dZ, "dZ", (B, Ci, T, V)); _chk(Z, "Z", (B, Ci, T, V), optional=True)
     for k, shp in (("Wt", (Co, Ci)), ("gt", (Co,)), ("bet", (Co,))):
         _chk(grads[k], "grad " + k, shp)
     for k, shp in (("bt", (Co,)), ("Wr", (Co, Ci)), ("br", (Co,)), ("gr", (Co,)), ("ber", (Co,)), ("slope_in", (1,))):
@@ -205,7 +205,7 @@ def layer_bwd_data(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict,
          ptr(Wr), ptr(gr), ptr(dIn if need_dx else None), ptr(dZ), ptr(grads["Wt"]), ptr(grads.get("bt")),
          ptr(grads["gt"]), ptr(grads["bet"]), ptr(grads.get("Wr")), ptr(grads.get("br")), ptr(grads.get("gr")),
          ptr(grads.get("ber")), ptr(grads.get("slope_in")), ptr(ws), ctypes.c_size_t(_bytes(ws)),
-         i32(1 if accumulate else 0), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+         i32(1 if accumulate else 0), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream(), ptr(Z))
     return dIn if need_dx else None
 
 

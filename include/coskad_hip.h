@@ -130,7 +130,7 @@ int coskad_layer_bwd_data_f32(const float* in, const float* dU, const float* A, 
                               const float* Wr, const float* gamma_r, float* dIn, float* dZ, float* dWt, float* dbt,
                               float* dgamma_t, float* dbeta_t, float* dWr, float* dbr, float* dgamma_r,
                               float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes, int accumulate, int B,
-                              int Ci, int Co, int T, int V, hipStream_t stream);
+                              int Ci, int Co, int T, int V, hipStream_t stream, const float* Z /* stored gcn(in) or NULL */);
 size_t coskad_layer_gcn_params_ws_bytes(int T, int V);
 int coskad_layer_gcn_params_f32(const float* in, const float* in_slope, const float* dZ, const float* A,
                                 const float* Tm, float* dA, float* dT, void* ws, size_t ws_bytes, int accumulate,
