@@ -100,6 +100,13 @@ class STSETrainStep:
         # optional: dA / dT on a second stream beside the next layer's reductions.  Measured SLOWER on MI355X (2.43 vs
         # 2.28 ms/step: the two LDS-heavy persistent kernels halve each other's occupancy), so it is off by default.
         self.side = engine.SideStream() if (side_stream or os.environ.get("COSKAD_SIDE_STREAM", "0") == "1") else None
+        # gradient buckets for the data-parallel all-reduce: [encoder | bottleneck]; the bottleneck parameters are the
+        # tail of the flat buffer (named_parameters order) and their gradients are final before the encoder backward
+        names = self.fp.names
+        first_tail = next((i for i, n in enumerate(names) if n.startswith("btlnk.")), None)
+        self.tail_off = None
+        if first_tail is not None and all(n.startswith("btlnk.") for n in names[first_tail:]):
+            self.tail_off = sum(self.fp.views[n].numel() for n in names[:first_tail])
         self.use_graph = use_graph
         self._graph = None
         self._x_static: Optional[Tensor] = None
@@ -129,9 +136,17 @@ class STSETrainStep:
         buf = self.ws.get(ops.btlnk_bwd_ws_bytes(B, K, W.shape[0]), x.device)
         dU = ops.btlnk_bwd(U, W, dz, slope, self.fp.gviews["btlnk.weight"],
                            self.fp.gviews.get("btlnk.bias"), self.grads[-1]["slope"], buf)
+        work = None
+        if self.world > 1 and self.tail_off is not None:
+            # bucket 1 (87 % of the bytes: the bottleneck weight) is complete now: its all-reduce runs on the collective
+            # stream while the encoder backward proceeds (SUM; the 1/W is folded into Adam)
+            work = dist.all_reduce(self.fp.grad[self.tail_off:], group=self.pg, async_op=True)
         engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False, side=self.side)
         if self.world > 1:
-            dist.all_reduce(self.fp.grad, group=self.pg)   # RCCL, one flat 0.96 MB buffer (SUM; /W in Adam)
+            head = self.fp.grad if work is None else self.fp.grad[:self.tail_off]
+            dist.all_reduce(head, group=self.pg)           # bucket 2: the encoder's gradients (0.12 MB)
+            if work is not None:
+                work.wait()
         ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,
                      self.beta2, self.eps, gscale=1.0 / self.world, reg_coef=self.reg_coef)
         return stats
