@@ -174,9 +174,7 @@ int launch_layer_apply_z(const float* Z, const float* in, float* out, const floa
   if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_apply_z: LDS %zu too large", lds);
   constexpr int PS = (Geo<T, V>::TV + 31) / 32;
   const long long witems = ((long long)B * PS + 3) / 4;
-  static int gz = -1;
-  if (gz < 0) { const char* e = getenv("COSKAD_GZ"); gz = e ? atoi(e) : 8; }
-  const int grid = (int)(witems < 256 * gz ? witems : 256 * gz);
+  const int grid = (int)(witems < 256 * 8 ? witems : 256 * 8);   // 8 four-wave blocks per CU (sweep: 4..16 within 5 %)
 #define LAUNCH_Z(OTI)                                                                                 \
   do {                                                                                                \
     auto k = k_layer_apply_z<T, V, OTI>;                                                              \
@@ -184,10 +182,8 @@ int launch_layer_apply_z(const float* Z, const float* in, float* out, const floa
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, Z, in, out, wfold, bias, in_slope, out_slope, B, Ci, Co, CoP); \
   } while (0)
   ProbeScope probe(KID_LAYER_APPLY, Ci, Co, st);
-  static int otz = -1;
-  if (otz < 0) { const char* e = getenv("COSKAD_OTZ"); otz = e ? atoi(e) : 4; }
-  if (CoP == 16 || otz == 1) LAUNCH_Z(1);
-  else if (CoP == 32 || otz == 2) LAUNCH_Z(2);
+  if (CoP == 16) LAUNCH_Z(1);
+  else if (CoP == 32) LAUNCH_Z(2);
   else if (CoP == 48) LAUNCH_Z(3);
   else LAUNCH_Z(4);
 #undef LAUNCH_Z
