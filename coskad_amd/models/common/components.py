@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ... import engine
-from ..graph_layers.stsgcn import ST_GCNN_layer, _PReLUFn, run_chain
+from ..graph_layers.stsgcn import ST_GCNN_layer, _PReLUFn, run_stack
 
 Tensor = torch.Tensor
 
@@ -25,11 +25,11 @@ class _Stack(nn.Module):
 
     def forward_preact(self, X: Tensor) -> Tuple[Tensor, Tensor]:
         """-> (U_last, slope_last): the fused path's hand-over to a consumer that applies PReLU on load."""
-        return run_chain(X, list(self.model), self._ws)
+        return run_stack(X, list(self.model), self._ws)
 
     def forward(self, X: Tensor) -> Tensor:
         u, slope = self.forward_preact(X)
-        return _PReLUFn.apply(u, slope)
+        return u if slope is None else _PReLUFn.apply(u, slope)
 
 
 class Encoder(_Stack):

@@ -17,6 +17,7 @@ import torch.nn as nn
 from ... import engine, ops
 
 Tensor = torch.Tensor
+WIDE_CHANNELS = 64   # widest layer the fused tile kernels take (csrc: `channels > 64 not supported`)
 
 
 class _GcnFn(torch.autograd.Function):
@@ -120,6 +121,8 @@ def run_chain(x: Tensor, layer_modules: List["ST_GCNN_layer"], ws: engine.Worksp
 
 
 class _PReLUFn(torch.autograd.Function):
+    """PReLU with one shared weight on the HIP kernels; slope None = identity (input already activated)."""
+
     @staticmethod
     def forward(ctx, u, slope):
         u = u.contiguous()
@@ -172,6 +175,43 @@ class ST_GCNN_layer(nn.Module):
             self.residual = nn.Identity()
         self.prelu = nn.PReLU()
 
+    @property
+    def is_wide(self) -> bool:
+        """More than 64 channels on either side: beyond the fused tile kernels (a clip's channels no longer fit LDS)."""
+        return max(self.in_channels, self.out_channels) > WIDE_CHANNELS
+
+    def forward_wide(self, X: Tensor) -> Tensor:
+        """Wide layers (the C = 2 -> 256 stack of BASELINE.json's north_star): the block is GEMM-dominated, so it runs
+        as the HIP mixing kernel (with its adjoint / parameter-gradient kernels) + the 1x1 convolutions on the GEMM /
+        convolution library + torch's BatchNorm / PReLU kernels -- the reference's own composition (stsgcn.py:106-110)
+        with its einsums replaced.  X is the post-activation input."""
+        Z = self.gcn(X)
+        out = self.tcn[1](self.tcn[0](Z))      # nn.Conv2d 1x1 (its weight-gradient GEMM beats a batched matmul + sum here)
+        res = X if isinstance(self.residual, nn.Identity) else self.residual(X)
+        return self.prelu(out + res)
+
     def forward(self, X: Tensor, t: Tensor = None) -> Tensor:
+        if self.is_wide:
+            return self.forward_wide(X)
         u, slope = run_chain(X, [self], self._ws)
         return _PReLUFn.apply(u, slope)
+
+
+def run_stack(x: Tensor, layer_modules: List["ST_GCNN_layer"], ws: engine.Workspace) -> Tuple[Tensor, Optional[Tensor]]:
+    """A stack that may mix fused (<= 64 channels) and wide layers.  -> (h, slope): apply PReLU(slope) to h to get the
+    stack's output (slope None: h is already activated)."""
+    h, slope = x, None
+    i, n = 0, len(layer_modules)
+    while i < n:
+        if layer_modules[i].is_wide:
+            if slope is not None:
+                h, slope = _PReLUFn.apply(h, slope), None
+            h = layer_modules[i].forward_wide(h)
+            i += 1
+        else:
+            j = i
+            while j < n and not layer_modules[j].is_wide:
+                j += 1
+            h, slope = run_chain(h, layer_modules[i:j], ws, in_slope=slope)
+            i = j
+    return h, slope

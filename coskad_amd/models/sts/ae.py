@@ -113,7 +113,7 @@ class STSE(nn.Module):
         if isinstance(self.btlnk, nn.Linear) and self.latent_dim <= 16:
             Z = _BottleneckFn.apply(U, slope, self.btlnk.weight, self.btlnk.bias, self._ws)
         else:
-            Z = self.btlnk(_PReLUFn.apply(U, slope).reshape(B, -1))
+            Z = self.btlnk((U if slope is None else _PReLUFn.apply(U, slope)).reshape(B, -1))
         if return_shape:
             return Z, X_shape
         return Z

@@ -192,3 +192,39 @@ def test_split_backward_on_side_stream_is_bit_identical(golden):
         torch.cuda.synchronize()
         flats.append(eng.fp.flat.clone())
     assert torch.equal(flats[0], flats[1])
+
+
+def test_wide_stack_c256_vs_oracle():
+    """The C = 2 -> 256 stack of the north_star wording (channels [64, 128, 256], h_dim 256): layer 1 on the fused
+    kernels, the wider layers on the HIP mixing kernel + library GEMMs; outputs and gradients against the oracle."""
+    from coskad_amd.models.sts.ae import STSE
+    from oracle import ref_cpu as R
+    st = R.init_stse_state(2, (64, 128, 256), 256, 16, 12, 17, seed=2)
+    st["c"] = torch.full((16,), 0.05)
+    x = R.synthetic_clips(6, seed=8)
+    m = STSE(2, [64, 128, 256], 256, 16, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    assert set(m.state_dict()) == set(st)
+    m.load_state_dict(st, strict=True)
+    m.cuda()
+    assert [l.is_wide for l in m.encoder.model] == [False, True, True, True]
+    m.eval()
+    with torch.no_grad():
+        z = m(x.cuda())
+        zr = R.stse_encode(x, {k: v.clone() for k, v in st.items()}, training=False)
+    np.testing.assert_allclose(z.cpu().numpy(), zr.numpy(), rtol=1e-4, atol=1e-4)
+    m.train()
+    z = m(x.cuda())
+    loss = torch.nn.functional.mse_loss(z, st["c"].cuda().expand_as(z))
+    loss.backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
+    sto = dict(st)
+    sto.update(params)
+    zt = R.stse_encode(x, sto, training=True)
+    lref = R.mse_to_center(zt, st["c"])
+    lref.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(lref.detach()), rtol=1e-4)
+    for k, p in m.named_parameters():
+        if k.endswith(("tcn.0.bias", "residual.0.bias")):
+            continue
+        ref = params[k].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-3, atol=1e-3 * np.abs(ref).max() + 1e-9, err_msg=k)
