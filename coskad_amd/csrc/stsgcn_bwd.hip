@@ -509,7 +509,8 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
 //     * dU is read ONCE: each 8-byte operand feeds both Bt.dU (-> dZ) and Br.dU (-> dX_res),
 //     * the dX_res accumulators stay in registers across the two mixing phases.
 // ---------------------------------------------------------------------------------------
-template <int T, int V, int OTI>
+// NBF clips per tile (NBF * C_in = 32 rows: 1 clip of 32 channels or 2 clips of 16); a wave owns its strip in every clip.
+template <int T, int V, int OTI, int NBF>
 __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
     const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
@@ -539,8 +540,8 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
   const float* kr = wDX + (Co + Ci) * CiP;
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
-  float* img = lds;
-  float* AwL = lds + Ci * LD;
+  float* imgt = lds;                         // NBF * C_in rows
+  float* AwL = lds + NBF * Ci * LD;
   float* TwL = AwL + T * V * V;
   float* WlA = TwL + V * T * T;              // [(KZ + K1)][CiP]: Kt rows (Z), then Bt rows (dU)
   float* WlB = WlA + (KZ + K1) * CiP;        // [(K1 + KZ)][CiP]: Br rows (dU), then Kr rows (X)
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
   };
   refresh();
   // acc += W[0:Ci] . img over this wave's strip; 4 k-steps of LDS operands in flight before their MFMAs
-  auto lds_conv = [&](const float* Wk, f32x4 (&acc)[OTI][2]) {
+  auto lds_conv = [&](const float* Wk, f32x4 (&acc)[OTI][2], const float* img) {
     for (int s0 = 0; s0 < KZS; s0 += 4) {
       float b0[4], b1[4], a[4][OTI];
 #pragma unroll
@@ -602,29 +603,41 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
     }
   };
 
-  for (int clip = blockIdx.x; clip < B; clip += gridDim.x) {
+  const int ntiles = ceil_div(B, NBF);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int clip = tile * NBF;                       // first clip of the tile
+    const int nb = min(NBF, B - clip);
+    const int rows = nb * Ci;
     const float* gin = in + (size_t)clip * Ci * TV;
-    const float* gdu = dU + (size_t)clip * Co * TV;
-    f32x4 accA[OTI][2], accB[OTI][2];
+    f32x4 accA[NBF][OTI][2], accB[NBF][OTI][2];
 #pragma unroll
-    for (int t = 0; t < OTI; ++t) {
-      accA[t][0] = accA[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      accB[t][0] = accB[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int n = 0; n < NBF; ++n)
+#pragma unroll
+      for (int t = 0; t < OTI; ++t) {
+        accA[n][t][0] = accA[n][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accB[n][t][0] = accB[n][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     refresh();
     __syncthreads();
-    if (!(abl & 1)) stage_rows<T, V>(gin, img, Ci * TV, pre, a_in, tid);
+    if (!(abl & 1)) stage_rows<T, V>(gin, imgt, rows * TV, pre, a_in, tid);
     __syncthreads();
     // phase 0: accB = Kr . X  (LDS, before the mixing overwrites X)
     if (mine && !(abl & 2)) {
-      lds_conv(WlB + K1 * CiP, accB);
+#pragma unroll
+      for (int n = 0; n < NBF; ++n)
+        if (n < nb) lds_conv(WlB + K1 * CiP, accB[n], imgt + n * Ci * LD);
     }
     __syncthreads();
-    if (Zg) stage_rows<T, V>(Zg + (size_t)clip * Ci * TV, img, Ci * TV, false, 0.f, tid);   // stored gcn(X) replaces X
-    else if (!(abl & 4)) gcn_mfma<T, V, false>(img, Ci, AwL, TwL, tid);
+    if (Zg) stage_rows<T, V>(Zg + (size_t)clip * Ci * TV, imgt, rows * TV, false, 0.f, tid);   // stored gcn(X) replaces X
+    else if (!(abl & 4)) gcn_mfma<T, V, false>(imgt, rows, AwL, TwL, tid);
     __syncthreads();
     // phase A: accA = Kt.Z (LDS) + Bt.dU ; accB += Br.dU -- ONE pass over dU
     if (mine) {
+#pragma unroll
+     for (int n = 0; n < NBF; ++n) {
+      if (n >= nb) break;
+      float* img = imgt + n * Ci * LD;
+      const float* gdu = dU + (size_t)(clip + n) * Co * TV;
       float2 cur[XB], nxt[XB];
       auto gload = [&](int g) -> float2 {
         if (g >= K1S) return float2{0.f, 0.f};
@@ -634,7 +647,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
       };
 #pragma unroll
       for (int u = 0; u < XB; ++u) cur[u] = gload(u);
-      if (!(abl & 16)) lds_conv(WlA, accA);
+      if (!(abl & 16)) lds_conv(WlA, accA[n], img);
       for (int g0 = 0; g0 < ((abl & 8) ? 0 : K1S); g0 += XB) {
 #pragma unroll
         for (int u = 0; u < XB; ++u) nxt[u] = gload(g0 + XB + u);
@@ -646,11 +659,11 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
 #pragma unroll
             for (int t = 0; t < OTI; ++t) {
               const float a1 = wa[16 * t], a2 = wb[16 * t];
-              accA[t][0] = mfma4(a1, cur[u].x, accA[t][0]);
-              accA[t][1] = mfma4(a1, cur[u].y, accA[t][1]);
+              accA[n][t][0] = mfma4(a1, cur[u].x, accA[n][t][0]);
+              accA[n][t][1] = mfma4(a1, cur[u].y, accA[n][t][1]);
               if (dIn) {
-                accB[t][0] = mfma4(a2, cur[u].x, accB[t][0]);
-                accB[t][1] = mfma4(a2, cur[u].y, accB[t][1]);
+                accB[n][t][0] = mfma4(a2, cur[u].x, accB[n][t][0]);
+                accB[n][t][1] = mfma4(a2, cur[u].y, accB[n][t][1]);
               }
             }
           }
@@ -666,44 +679,52 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
           for (int r = 0; r < 4; ++r) {
             const int o = 16 * t + 4 * kk + r;
             if (o < Ci) {
-              img[o * LD + p] = accA[t][0][r] + ktl[o];
-              img[o * LD + p + 1] = accA[t][1][r] + ktl[o];
+              img[o * LD + p] = accA[n][t][0][r] + ktl[o];
+              img[o * LD + p + 1] = accA[n][t][1][r] + ktl[o];
             }
           }
       }
+     }
     }
     __syncthreads();
     if (dZout && !(abl & 32)) {
-      unstage_rows<T, V>(dZout + (size_t)clip * Ci * TV, img, Ci * TV, tid);
+      unstage_rows<T, V>(dZout + (size_t)clip * Ci * TV, imgt, rows * TV, tid);
       __syncthreads();   // the adjoint mixing below overwrites dZ in place: every wave must have copied it out
     }
     if (dIn) {
       // the PReLU masks of the epilogue (pre-activations of the layer input) are fetched before the adjoint mixing,
       // so their latency is covered by it
-      float2 um[OTI][4];
+      float2 um[NBF][OTI][4];
       if (pre && pok) {
 #pragma unroll
-        for (int t = 0; t < OTI; ++t)
+        for (int n = 0; n < NBF; ++n)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int o = 16 * t + 4 * kk + r;
-            um[t][r] = *reinterpret_cast<const float2*>(gin + (size_t)(o < Ci ? o : Ci - 1) * TV + p);
-          }
+          for (int t = 0; t < OTI; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int o = 16 * t + 4 * kk + r;
+              const int nn = n < nb ? n : 0;
+              um[n][t][r] = *reinterpret_cast<const float2*>(gin + ((size_t)nn * Ci + (o < Ci ? o : Ci - 1)) * TV + p);
+            }
       }
-      if (!(abl & 64)) gcn_mfma<T, V, true>(img, Ci, AwL, TwL, tid);
+      if (!(abl & 64)) gcn_mfma<T, V, true>(imgt, rows, AwL, TwL, tid);
       __syncthreads();
       if (pok && !(abl & 128)) {
-        float* dg = dIn + (size_t)clip * Ci * TV;
+#pragma unroll
+       for (int n = 0; n < NBF; ++n) {
+        if (n >= nb) break;
+        const float* img = imgt + n * Ci * LD;
+        float* dg = dIn + (size_t)(clip + n) * Ci * TV;
 #pragma unroll
         for (int t = 0; t < OTI; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int o = 16 * t + 4 * kk + r;
             if (o < Ci) {
-              float g0 = accB[t][0][r] + krl[o] + img[o * LD + p];
-              float g1 = accB[t][1][r] + krl[o] + img[o * LD + p + 1];
+              float g0 = accB[n][t][0][r] + krl[o] + img[o * LD + p];
+              float g1 = accB[n][t][1][r] + krl[o] + img[o * LD + p + 1];
               if (pre) {
-                const float2 u = um[t][r];
+                const float2 u = um[n][t][r];
                 if (u.x < 0.f) da = fmaf(g0, u.x, da);
                 if (u.y < 0.f) da = fmaf(g1, u.y, da);
                 g0 = u.x > 0.f ? g0 : a_in * g0;
@@ -712,6 +733,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
               *reinterpret_cast<float2*>(dg + (size_t)o * TV + p) = float2{g0, g1};
             }
           }
+       }
       }
     }
   }
@@ -1255,7 +1277,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   const float* dap_sum = nullptr;   // block partials of the producer's slope gradient (summed by stage 4's reduce)
   {
     int NB = Ci >= 32 ? 1 : 32 / Ci;
-    if (NB > B) NB = B;
+    if (NB > B && !(Ci == 16 && dIn != nullptr)) NB = B;   // (the two-clip single-read kernel keeps its 32-row image)
     const int CiP = round_up(Ci, 16), KZ = round_up(Ci, 4), K1 = round_up(Co, 4);
     const size_t lds = ((size_t)NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T + 2 * (size_t)(KZ + K1) * CiP +
                         2 * CiP) * sizeof(float);
@@ -1279,9 +1301,9 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
 #else
 #define ABL_ARG
 #endif
-#define LAUNCH_DF(OTI)                                                                                  \
+#define LAUNCH_DF(OTI, NBF_)                                                                                  \
   do {                                                                                                  \
-    auto k = k_bwd_data_f<T, V, OTI>;                                                                   \
+    auto k = k_bwd_data_f<T, V, OTI, NBF_>;                                                             \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
                        w.dz, dap, B, Ci, Co, Zg ABL_ARG);                                               \
@@ -1289,12 +1311,16 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     static int fused_ok = -1;
     if (fused_ok < 0) { const char* e = getenv("COSKAD_BWD_UNFUSED"); fused_ok = (e && e[0] == '1') ? 0 : 1; }
     constexpr bool strips_fit = (Geo<T, V>::TV + 31) / 32 <= kBlock / 64;
-    if (fused_ok && strips_fit && NB == 1 && dIn != nullptr && CiP <= 64) {
+    // single-read variant: tiles of 32 rows = one clip of >= 32 channels, or two clips of exactly 16
+    const bool two_clip = Ci == 16;            // NB was kept at 2 above
+    if (fused_ok && strips_fit && (NB == 1 || two_clip) && dIn != nullptr && CiP <= 64) {
       ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
       if constexpr (strips_fit) {
-        if (CiP == 32) LAUNCH_DF(2);
-        else if (CiP == 48) LAUNCH_DF(3);
-        else LAUNCH_DF(4);
+        if (two_clip) LAUNCH_DF(1, 2);
+        else if (CiP == 16) LAUNCH_DF(1, 1);   // (one clip of < 16 channels: only when the batch is a single clip)
+        else if (CiP == 32) LAUNCH_DF(2, 1);
+        else if (CiP == 48) LAUNCH_DF(3, 1);
+        else LAUNCH_DF(4, 1);
       }
     } else
     {
