@@ -166,15 +166,44 @@ __global__ __launch_bounds__(kBtlBlock) void k_btlnk_bwd(const float* __restrict
   if (threadIdx.x == 0) dap[blockIdx.y * gridDim.x + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-// out[e] (+)= sum_p partials[p][e]; fp64 accumulate, fp32 store.
-__global__ __launch_bounds__(256) void k_reduce_partials_f32(const float* __restrict__ partials, int P,
-                                                              size_t E, float* __restrict__ out,
-                                                              int accumulate) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= E) return;
+// All reductions of the bottleneck backward in ONE launch (fp64 accumulate, fp32 store):
+//   blocks [0, nE)       : out[e] (+)= sum_p partials[p][e]            (dW, 256 elements per block)
+//   blocks [nE, nE + L)  : db[j]  (+)= sum_n dz[n][j]                  (one block per latent column; db may be NULL)
+//   block  nE + L        : dslope (+)= sum of the nda block partials   (dslope may be NULL)
+__global__ __launch_bounds__(256) void k_btlnk_reduce(const float* __restrict__ partials, int P, size_t E,
+                                                       float* __restrict__ out, const float* __restrict__ dz,
+                                                       int B, int L, float* __restrict__ db,
+                                                       const float* __restrict__ dap, int nda,
+                                                       float* __restrict__ dslope, int accumulate) {
+  __shared__ double sh[256];
+  const unsigned nE = (unsigned)((E + 255) / 256);
+  if (blockIdx.x < nE) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)partials[(size_t)p * E + e];
+    out[e] = accumulate ? out[e] + (float)s : (float)s;
+    return;
+  }
+  const int r = (int)(blockIdx.x - nE);        // 0..L-1: bias column, L: slope
   double s = 0.0;
-  for (int p = 0; p < P; ++p) s += (double)partials[(size_t)p * E + e];
-  out[e] = accumulate ? out[e] + (float)s : (float)s;
+  if (r < L) {
+    if (!db) return;
+    for (int n = threadIdx.x; n < B; n += 256) s += (double)dz[(size_t)n * L + r];
+  } else {
+    if (!dslope) return;
+    for (int i = threadIdx.x; i < nda; i += 256) s += (double)dap[i];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* o = r < L ? db + r : dslope;
+    o[0] = accumulate ? o[0] + (float)sh[0] : (float)sh[0];
+  }
 }
 
 // single-block: out[0] (+)= sum of n floats
@@ -252,9 +281,8 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
   int rc = check_launch("btlnk_bwd");
   if (rc) return rc;
   const size_t E = (size_t)L * K;
-  hipLaunchKernelGGL(k_reduce_partials_f32, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, dWp, S, E, dW, accumulate);
-  if (db) hipLaunchKernelGGL(k_colsum, dim3(L), dim3(256), 0, stream, dz, B, L, db, accumulate);
-  if (dslope && slope) hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, stream, dap, gx * S, dslope, accumulate);
+  hipLaunchKernelGGL(k_btlnk_reduce, dim3((unsigned)((E + 255) / 256) + L + 1), dim3(256), 0, stream, dWp, S, E, dW, dz, B,
+                     L, db, dap, gx * S, (dslope && slope) ? dslope : nullptr, accumulate);
   return check_launch("btlnk_bwd_reduce");
 }
 
