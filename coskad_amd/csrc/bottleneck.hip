@@ -206,37 +206,6 @@ __global__ __launch_bounds__(256) void k_btlnk_reduce(const float* __restrict__ 
   }
 }
 
-// single-block: out[0] (+)= sum of n floats
-__global__ __launch_bounds__(256) void k_sum_scalar(const float* __restrict__ v, int n,
-                                                     float* __restrict__ out, int accumulate) {
-  __shared__ double sh[256];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += (double)v[i];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)sh[0] : (float)sh[0];
-}
-
-// db[j] = sum_n dz[n][j]: one block per latent column, 256 threads stride over the clips
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dz, int B, int L,
-                                                 float* __restrict__ db, int accumulate) {
-  __shared__ double sh[256];
-  const int j = blockIdx.x;
-  double s = 0.0;
-  for (int n = threadIdx.x; n < B; n += 256) s += (double)dz[(size_t)n * L + j];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) db[j] = accumulate ? db[j] + (float)sh[0] : (float)sh[0];
-}
-
 static int btl_chunks(int B) {
   int s = ceil_div(B, 256);
   return s < 1 ? 1 : (s > 16 ? 16 : s);
