@@ -36,6 +36,12 @@ struct RedGeo {
   static constexpr int NCH = 3;
   static constexpr int CH = ((TV + NCH - 1) / NCH + 3) / 4 * 4;   // 68 for 12x17
   static constexpr int LDC = CH + 1;
+  // strides of the stored-Z kernel, whose only LDS access pattern is the MFMA outer-product operand
+  // "lane (i, k) -> row i, position p0 + k": a row stride == 2 (mod 4) spreads the 32 lanes of a half-wave over all
+  // 32 banks (i * S takes 16 distinct even residues, + k in {0, 1} / {2, 3}); the odd strides above leave ~45 % of the
+  // LDS cycles of that pattern in bank conflicts (rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
+  static constexpr int LDZ = TV + 2;         // 206 for 12x17 (TV % 4 == 0)
+  static constexpr int LDCZ = CH + 2;        // 70
 };
 
 // Out[a][b] += sum_{q < npos} A[a][offA + q] * B[b][offB + q]   (MFMA f32, waves split q)
@@ -70,9 +76,9 @@ __device__ __forceinline__ void outer_accum2(const float* ldsA, int ldA, int off
 }
 
 // stage rows x [pbeg, pbeg+npos) of a [rows][TV] global tile into a chunk image with stride LDC
-template <int T, int V>
+template <int T, int V, int LDCX = 0>
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ g, float* lds, int rows, int pbeg, int npos) {
-  constexpr int TV = T * V, LDC = RedGeo<T, V>::LDC;
+  constexpr int TV = T * V, LDC = LDCX ? LDCX : RedGeo<T, V>::LDC;
   const int n4 = npos >> 2;               // pbeg and npos are multiples of 4, TV % 4 == 0
   constexpr int UB = 3;   // HBM loads in flight per thread (64 rows x 17 float4 = 2.1 per thread)
   const int n = rows * n4;
@@ -198,8 +204,8 @@ template <int T, int V, int NTO, int NTC>
 __global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce_z(
     const float* __restrict__ in, const float* __restrict__ Zg, const float* __restrict__ dU,
     const float* __restrict__ in_slope, float* __restrict__ partials, int B, int Ci, int Co, int NB, int need_q) {
-  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
-  constexpr int NCH = RedGeo<T, V>::NCH, CH = RedGeo<T, V>::CH, LDC = RedGeo<T, V>::LDC;
+  constexpr int TV = Geo<T, V>::TV, LD = RedGeo<T, V>::LDZ;
+  constexpr int NCH = RedGeo<T, V>::NCH, CH = RedGeo<T, V>::CH, LDC = RedGeo<T, V>::LDCZ;
   static_assert(TV % 4 == 0, "chunked staging uses float4");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldz = lds;                         // Z image: NB*Ci rows x LD
@@ -219,12 +225,12 @@ __global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce
     const int nb = min(NB, B - clip0);
     const float* gdu = dU + (size_t)clip0 * Co * TV;
     __syncthreads();
-    stage_rows<T, V>(Zg + (size_t)clip0 * Ci * TV, ldz, nb * Ci * TV, false, 0.f);
-    if (need_q) stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, pre, a_in);
+    stage_rows<T, V, LD>(Zg + (size_t)clip0 * Ci * TV, ldz, nb * Ci * TV, false, 0.f);
+    if (need_q) stage_rows<T, V, LD>(in + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, pre, a_in);
     for (int ch = 0; ch < NCH; ++ch) {
       const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
       if (ch > 0) __syncthreads();          // the previous slab has been consumed
-      stage_chunk<T, V>(gdu, ldu, nb * Co, pbeg, npos);
+      stage_chunk<T, V, LDC>(gdu, ldu, nb * Co, pbeg, npos);
       __syncthreads();
       for (int n = 0; n < nb; ++n)
         outer_accum_pq<NTO, NTC>(ldu + n * Co * LDC, LDC, Co, ldx + n * Ci * LD, ldz + n * Ci * LD, LD, pbeg, Ci, npos,
@@ -1189,7 +1195,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     const int need_q = Wr != nullptr;
     if (Zg) {        // stored Z: one dU pass, no mixing tables in LDS
       auto zlds = [&](int nb_) {
-        size_t img = (size_t)(need_q ? 2 : 1) * nb_ * Ci * LD + (size_t)nb_ * Co * RedGeo<T, V>::LDC;
+        size_t img = (size_t)(need_q ? 2 : 1) * nb_ * Ci * RedGeo<T, V>::LDZ + (size_t)nb_ * Co * RedGeo<T, V>::LDCZ;
         if (img < (size_t)kScratchFloats) img = kScratchFloats;
         return img * sizeof(float);
       };

@@ -21,11 +21,12 @@ namespace coskad {
 
 // Stream `nfloats` contiguous floats (whole rows of TV) from HBM into the LDS row image,
 // optionally applying PReLU on the way (the producer layer stores pre-activations).
-template <int T, int V>
+// LDX: LDS row stride override (0 = the odd Geo stride; the batch-reduction kernels use TV + 2, see RedGeo)
+template <int T, int V, int LDX = 0>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* lds, int nfloats,
                                            bool do_prelu, float slope, int tid = -1) {
   if (tid < 0) tid = threadIdx.x;
-  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int TV = Geo<T, V>::TV, LD = LDX ? LDX : Geo<T, V>::LD;
   if constexpr (TV % 4 == 0) {
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const int n4 = nfloats >> 2;
