@@ -17,8 +17,9 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o r
 echo "fetch pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o run -- python3 $args > $out/write.log 2>&1
 echo "write pass done"
-# matrix-pipe and LDS counters (their own passes): MFMA busy cycles vs GPU-active cycles, LDS bank conflicts vs LDS-active
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -o run -- python3 $args > $out/mfma.log 2>&1
+# matrix-pipe and LDS counters (their own passes): rocprofv3's derived MfmaUtil (MFMA-busy cycles / (active cycles x SIMDs)),
+# LDS bank-conflict cycles vs LDS-active cycles
+rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $out/mfma -o run -- python3 $args > $out/mfma.log 2>&1
 echo "mfma pass done"
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/lds -o run -- python3 $args > $out/lds.log 2>&1
 echo "lds pass done"

@@ -92,17 +92,15 @@ def main(tag: str) -> None:
                 extra[(k, slot, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))][cname].append(float(r["Counter_Value"]))
     if extra:
         with open(f"{dst}/{tag}_mfma_lds_pmc.csv", "w") as f:
-            f.write("kernel,launch_slot_in_step,workgroups,mfma_busy_pct_of_simd_cycles,lds_bank_conflict_pct_of_lds_active\n")
+            f.write("kernel,launch_slot_in_step,workgroups,MfmaUtil_pct,lds_bank_conflict_pct_of_lds_active\n")
             def avg(c, n):
                 return sum(c.get(n, [0.0])) / max(1, len(c.get(n, [])))
-            order = sorted(extra.items(), key=lambda kv: -avg(kv[1], "SQ_VALU_MFMA_BUSY_CYCLES"))
+            order = sorted(extra.items(), key=lambda kv: -avg(kv[1], "MfmaUtil"))
             for key, c in order:
                 if not key[0].startswith("k_"):
                     continue
-                busy, act = avg(c, "SQ_VALU_MFMA_BUSY_CYCLES"), avg(c, "GRBM_GUI_ACTIVE")
                 conf, idx = avg(c, "SQ_LDS_BANK_CONFLICT"), avg(c, "SQ_LDS_IDX_ACTIVE")
-                # MfmaUtil of rocprofv3's derived-metric table: busy cycles summed over the SIMDs / (active cycles * #SIMDs)
-                util = 100.0 * busy / (act * 1024) if act else float("nan")      # 256 CUs x 4 SIMDs
+                util = avg(c, "MfmaUtil") if "MfmaUtil" in c else float("nan")   # rocprofv3's derived metric, per launch
                 lds = 100.0 * conf / idx if idx else float("nan")
                 f.write(f"\"{key[0]}\",{key[1]},{key[2]},{util:.1f},{lds:.1f}\n")
 
