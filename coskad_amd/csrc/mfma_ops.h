@@ -37,9 +37,11 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict_
 // ---- separable mixing on the LDS row image, in place -----------------------------------
 // rows: valid rows of the image (row tiles of 16; rows beyond `rows` read as 0, never written)
 // TwL / AwL: LDS copies of T[V][T][T] and A[T][V][V].
-template <int T, int V, bool ADJ>
+// LDX: row stride override of the LDS image (0 = Geo's odd stride, which the strip-conv kernels need; kernels without
+// a strip phase use TV + 2: conflict-free (row, k) operand reads, see RedGeo in stsgcn_bwd.hip)
+template <int T, int V, bool ADJ, int LDX = 0>
 __device__ __forceinline__ void temporal_mfma(float* img, int rows, const float* TwL, int tid = -1) {
-  constexpr int LD = Geo<T, V>::LD;
+  constexpr int LD = LDX ? LDX : Geo<T, V>::LD;
   constexpr int KS = (T + 3) / 4;
   constexpr int RP = COSKAD_RP;   // row tiles per item: they share the B operand and give independent MFMA chains
   static_assert(T <= 16, "temporal_mfma: one 16-wide column tile");
@@ -86,9 +88,9 @@ __device__ __forceinline__ void temporal_mfma(float* img, int rows, const float*
   }
 }
 
-template <int T, int V, bool ADJ>
+template <int T, int V, bool ADJ, int LDX = 0>
 __device__ __forceinline__ void spatial_mfma(float* img, int rows, const float* AwL, int tid = -1) {
-  constexpr int LD = Geo<T, V>::LD;
+  constexpr int LD = LDX ? LDX : Geo<T, V>::LD;
   constexpr int KS = (V + 3) / 4;
   constexpr int RP = COSKAD_RP;   // row tiles per item (share B, independent chains)
   // column tiles on MFMA; up to 2 leftover columns (V = 17, 18) are cheaper on the VALU
@@ -179,16 +181,16 @@ __device__ __forceinline__ void spatial_mfma(float* img, int rows, const float* 
   }
 }
 
-template <int T, int V, bool ADJ>
+template <int T, int V, bool ADJ, int LDX = 0>
 __device__ __forceinline__ void gcn_mfma(float* img, int rows, const float* AwL, const float* TwL, int tid = -1) {
   if constexpr (!ADJ) {
-    temporal_mfma<T, V, false>(img, rows, TwL, tid);
+    temporal_mfma<T, V, false, LDX>(img, rows, TwL, tid);
     __syncthreads();
-    spatial_mfma<T, V, false>(img, rows, AwL, tid);
+    spatial_mfma<T, V, false, LDX>(img, rows, AwL, tid);
   } else {
-    spatial_mfma<T, V, true>(img, rows, AwL, tid);
+    spatial_mfma<T, V, true, LDX>(img, rows, AwL, tid);
     __syncthreads();
-    temporal_mfma<T, V, true>(img, rows, TwL, tid);
+    temporal_mfma<T, V, true, LDX>(img, rows, TwL, tid);
   }
 }
 

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kBlock, (NTC <= 2 ? 6 : 4)) void k_fwd_moments(cons
                                                        const float* __restrict__ in_slope,
                                                        float* __restrict__ partials, int B, int Ci,
                                                        int NB, int need_x, float* __restrict__ Zout) {
-  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int TV = Geo<T, V>::TV, LD = TV + 2;   // even stride == 2 (mod 4): no strip phase here, conflict-free (row, k) reads
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* scratch = lds;                 // kScratchFloats, aliased onto the row image (only used after the tile loop)
   float* AwL = lds + max(NB * Ci * LD, kScratchFloats);
@@ -46,17 +46,17 @@ __global__ __launch_bounds__(kBlock, (NTC <= 2 ? 6 : 4)) void k_fwd_moments(cons
     const int nb = min(NB, B - clip0);
     const int rows = nb * Ci;
     __syncthreads();  // previous tile's MFMA reads are done
-    stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, lds, rows * TV, pre, a_in);
+    stage_rows<T, V, LD>(in + (size_t)clip0 * Ci * TV, lds, rows * TV, pre, a_in);
     __syncthreads();
     if (need_x) {
-      for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC>(lds + n * Ci * LD, Ci, mx, sx);
+      for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC, LD>(lds + n * Ci * LD, Ci, mx, sx);
       __syncthreads();
     }
-    gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
+    gcn_mfma<T, V, false, LD>(lds, rows, AwL, TwL);
     __syncthreads();
     // Z = gcn(X) is kept for the rest of the step (apply and both backward kernels read it instead of recomputing)
-    if (Zout) unstage_rows<T, V>(Zout + (size_t)clip0 * Ci * TV, lds, rows * TV);
-    for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC>(lds + n * Ci * LD, Ci, mz, sz);
+    if (Zout) unstage_rows<T, V, LD>(Zout + (size_t)clip0 * Ci * TV, lds, rows * TV);
+    for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC, LD>(lds + n * Ci * LD, Ci, mz, sz);
   }
   // partial layout: [MX Ci*Ci][sumX Ci][MZ Ci*Ci][sumZ Ci]
   float* dst = partials + (size_t)blockIdx.x * (2 * (Ci * Ci + Ci));
@@ -229,7 +229,8 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
                               float* rv_r, long long* nbt_r, float momentum, float* wfold, float* bias,
                               float* stat, void* ws, size_t ws_bytes, int B, int Ci, int Co,
                               hipStream_t st, float* Zout = nullptr) {
-  constexpr int LD = Geo<T, V>::LD, TV = Geo<T, V>::TV;
+  constexpr int TV = Geo<T, V>::TV, LD = TV + 2;   // k_fwd_moments' row stride
+  static_assert(TV % 4 == 0, "the moments kernel stages with float4 and needs TV + 2 == 2 (mod 4)");
   if (Ci > 64) return fail(COSKAD_ERR_SHAPE, "train_stats: C_in=%d > 64 not supported", Ci);
   if (ws_bytes < train_stats_ws_bytes(Ci))
     return fail(COSKAD_ERR_WORKSPACE, "train_stats: workspace %zu < %zu bytes", ws_bytes, train_stats_ws_bytes(Ci));

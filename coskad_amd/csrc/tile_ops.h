@@ -66,10 +66,10 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* l
 }
 
 // Write the LDS row image back to a contiguous HBM tile.
-template <int T, int V>
+template <int T, int V, int LDX = 0>
 __device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* lds, int nfloats, int tid = -1) {
   if (tid < 0) tid = threadIdx.x;
-  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int TV = Geo<T, V>::TV, LD = LDX ? LDX : Geo<T, V>::LD;
   if constexpr (TV % 4 == 0) {
     float4* g4 = reinterpret_cast<float4*>(g);
     const int n4 = nfloats >> 2;
@@ -244,9 +244,9 @@ __device__ __forceinline__ void outer_accum(const float* ldsA, int va, const flo
 // Symmetric: only tiles tb >= ta are computed, and the A fragment of tile t IS the B fragment of tile t
 // (lane (i,k) holds X[16t+i][p0+k] either way), so one LDS read per tile and k-step feeds everything.
 // Row sums ride along on the VALU (one add per tile and k-step) instead of an extra MFMA against ones.
-template <int T, int V, int NT>
+template <int T, int V, int NT, int LDX = 0>
 __device__ __forceinline__ void moment_accum(const float* img, int valid, f32x4 (&acc)[NT][NT], float (&rs)[NT]) {
-  constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+  constexpr int TV = Geo<T, V>::TV, LD = LDX ? LDX : Geo<T, V>::LD;
   static_assert(TV % 4 == 0, "positions must be a multiple of the MFMA K step");
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
