@@ -63,6 +63,15 @@ __device__ __forceinline__ int tid_here() {
   return t;
 }
 
+// Block barrier for phases that exchange data through LDS only.  __syncthreads() also drains the vector-memory
+// counter (a workgroup-scope release covers global memory), so every barrier after a store phase (unstage, epilogue)
+// or with prefetched global loads in flight would wait for HBM round trips.  Here only the LDS/scalar counter is
+// drained: the compiler still waits for a global load where its value is used, and no tile kernel passes data
+// between waves through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // wave-uniform value -> SGPR (lets hipcc use s_load for everything indexed by it)
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 

@@ -185,11 +185,11 @@ template <int T, int V, bool ADJ, int LDX = 0>
 __device__ __forceinline__ void gcn_mfma(float* img, int rows, const float* AwL, const float* TwL, int tid = -1) {
   if constexpr (!ADJ) {
     temporal_mfma<T, V, false, LDX>(img, rows, TwL, tid);
-    __syncthreads();
+    lds_barrier();
     spatial_mfma<T, V, false, LDX>(img, rows, AwL, tid);
   } else {
     spatial_mfma<T, V, true, LDX>(img, rows, AwL, tid);
-    __syncthreads();
+    lds_barrier();
     temporal_mfma<T, V, true, LDX>(img, rows, TwL, tid);
   }
 }

@@ -134,26 +134,26 @@ __global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
     const float* gdu = dU + (size_t)clip0 * Co * TV;
-    __syncthreads();
+    lds_barrier();
     stage_rows<T, V>(in + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, pre, a_in);
     if (need_q) {
       for (int ch = 0; ch < NCH; ++ch) {
         const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
-        __syncthreads();
+        lds_barrier();
         stage_chunk<T, V>(gdu, ldu, nb * Co, pbeg, npos);
-        __syncthreads();
+        lds_barrier();
         for (int n = 0; n < nb; ++n)
           outer_accum2<NTO, NTC, false>(ldu + n * Co * LDC, LDC, 0, Co, ldx + n * Ci * LD, LD, pbeg, Ci, npos, qacc, sdummy);
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (Zg) stage_rows<T, V>(Zg + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, false, 0.f);   // stored gcn(X)
     else gcn_mfma<T, V, false>(ldx, nb * Ci, AwL, TwL);
     for (int ch = 0; ch < NCH; ++ch) {
       const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
-      __syncthreads();
+      lds_barrier();
       stage_chunk<T, V>(gdu, ldu, nb * Co, pbeg, npos);
-      __syncthreads();
+      lds_barrier();
       for (int n = 0; n < nb; ++n)
         outer_accum2<NTO, NTC, true>(ldu + n * Co * LDC, LDC, 0, Co, ldx + n * Ci * LD, LD, pbeg, Ci, npos, pacc, srow);
     }
@@ -224,14 +224,14 @@ __global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
     const float* gdu = dU + (size_t)clip0 * Co * TV;
-    __syncthreads();
+    lds_barrier();
     stage_rows<T, V, LD>(Zg + (size_t)clip0 * Ci * TV, ldz, nb * Ci * TV, false, 0.f);
     if (need_q) stage_rows<T, V, LD>(in + (size_t)clip0 * Ci * TV, ldx, nb * Ci * TV, pre, a_in);
     for (int ch = 0; ch < NCH; ++ch) {
       const int pbeg = ch * CH, npos = min(CH, TV - pbeg);
-      if (ch > 0) __syncthreads();          // the previous slab has been consumed
+      if (ch > 0) lds_barrier();          // the previous slab has been consumed
       stage_chunk<T, V, LDC>(gdu, ldu, nb * Co, pbeg, npos);
-      __syncthreads();
+      lds_barrier();
       for (int n = 0; n < nb; ++n)
         outer_accum_pq<NTO, NTC>(ldu + n * Co * LDC, LDC, Co, ldx + n * Ci * LD, ldz + n * Ci * LD, LD, pbeg, Ci, npos,
                                  need_q != 0, pacc, qacc, srow);
@@ -443,15 +443,15 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
     const float* gin = in + (size_t)clip0 * Ci * TV;
     const float* gdu = dU + (size_t)clip0 * Co * TV;
 
-    __syncthreads();
+    lds_barrier();
     if (Zg) {
       stage_rows<T, V>(Zg + (size_t)clip0 * Ci * TV, lds, rows * TV, false, 0.f);   // stored gcn(X): X itself is only read in phase B
     } else {
       stage_rows<T, V>(gin, lds, rows * TV, pre, a_in);
-      __syncthreads();
+      lds_barrier();
       gcn_mfma<T, V, false>(lds, rows, AwL, TwL);
     }
-    __syncthreads();
+    lds_barrier();
     // phase A (MFMA): dZ[:,p] = kt + Kt Z[:,p] + Bt dU[:,p], in place over Z.  One item = all channels of a
     // strip, so every Z column is fully read before it is overwritten.
     for (int n = 0; n < nb; ++n) {
@@ -465,14 +465,14 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
       conv_mfma_s<T, V, OTI>(img, KZ, Ci, gdu + (size_t)n * Co * TV, K1, Co, nullptr, 0, 1, false, 0.f, WlA, CiP, 0,
                              (wave + n) % (kBlock / 64), kBlock / 64, epiA);
     }
-    __syncthreads();
+    lds_barrier();
     if (dZout) {
       unstage_rows<T, V>(dZout + (size_t)clip0 * Ci * TV, lds, rows * TV);
-      __syncthreads();   // the adjoint mixing below overwrites dZ in place: every wave must have copied it out
+      lds_barrier();   // the adjoint mixing below overwrites dZ in place: every wave must have copied it out
     }
     if (dIn) {
       gcn_mfma<T, V, true>(lds, rows, AwL, TwL);
-      __syncthreads();
+      lds_barrier();
       // phase B (MFMA): dX = gcn^T(dZ) + kr + Br dU + Kr X ; dU_prev = dX * PReLU'(U_prev)
       for (int n = 0; n < nb; ++n) {
         const float* img = lds + n * Ci * LD;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
   if (da_partials) {
     da = wave_sum(da);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = da;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
       float t = 0.f;
       for (int w = 0; w < kBlock / 64; ++w) t += sred[w];
@@ -624,19 +624,19 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
         accB[n][t][0] = accB[n][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     refresh();
-    __syncthreads();
+    lds_barrier();
     if (!(abl & 1)) stage_rows<T, V>(gin, imgt, rows * TV, pre, a_in, tid);
-    __syncthreads();
+    lds_barrier();
     // phase 0: accB = Kr . X  (LDS, before the mixing overwrites X)
     if (mine && !(abl & 2)) {
 #pragma unroll
       for (int n = 0; n < NBF; ++n)
         if (n < nb) lds_conv(WlB + K1 * CiP, accB[n], imgt + n * Ci * LD);
     }
-    __syncthreads();
+    lds_barrier();
     if (Zg) stage_rows<T, V>(Zg + (size_t)clip * Ci * TV, imgt, rows * TV, false, 0.f, tid);   // stored gcn(X) replaces X
     else if (!(abl & 4)) gcn_mfma<T, V, false>(imgt, rows, AwL, TwL, tid);
-    __syncthreads();
+    lds_barrier();
     // phase A: accA = Kt.Z (LDS) + Bt.dU ; accB += Br.dU -- ONE pass over dU
     if (mine) {
 #pragma unroll
@@ -692,10 +692,10 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
       }
      }
     }
-    __syncthreads();
+    lds_barrier();
     if (dZout && !(abl & 32)) {
       unstage_rows<T, V>(dZout + (size_t)clip * Ci * TV, imgt, rows * TV, tid);
-      __syncthreads();   // the adjoint mixing below overwrites dZ in place: every wave must have copied it out
+      lds_barrier();   // the adjoint mixing below overwrites dZ in place: every wave must have copied it out
     }
     if (dIn) {
       // the PReLU masks of the epilogue (pre-activations of the layer input) are fetched before the adjoint mixing,
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
             }
       }
       if (!(abl & 64)) gcn_mfma<T, V, true>(imgt, rows, AwL, TwL, tid);
-      __syncthreads();
+      lds_barrier();
       if (pok && !(abl & 128)) {
 #pragma unroll
        for (int n = 0; n < NBF; ++n) {
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
   if (da_partials) {
     da = wave_sum(da);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = da;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
       float t = 0.f;
       for (int w = 0; w < kBlock / 64; ++w) t += sred[w];
@@ -848,12 +848,12 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
     const int nb = min(NB, B - clip0);
     const int rows = nb * Ci;
     const float* gin = in + (size_t)clip0 * Ci * TV;
-    __syncthreads();
+    lds_barrier();
     if (!(abl & 64)) stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
     if (!(abl & 1)) stage_rows<T, V>(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
-    __syncthreads();
+    lds_barrier();
     if (!(abl & 2)) temporal_mfma<T, V, false>(img1, rows, TwL);  // Y = temporal(X)
-    __syncthreads();
+    lds_barrier();
     // dA[t] += Y[:, t, :]^T dZ[:, t, :]   (K = rows)
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
@@ -905,10 +905,10 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restri
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (!(abl & 8)) spatial_mfma<T, V, true>(img2, rows, AwL);  // dY = spatial^T(dZ)
     if (!(abl & 16)) stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);  // X again (img1 is free: dA is done)
-    __syncthreads();
+    lds_barrier();
     // dT[v][t][q] += sum_rows X[t*V+v] dY[q*V+v]
 #pragma unroll
     for (int vv = 0; vv < VPW; ++vv) {

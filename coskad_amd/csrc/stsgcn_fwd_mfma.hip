@@ -37,15 +37,15 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
     const int nb = min(NB, B - clip0);
     const int rows = nb * Ci;
     const float* gin = in + (size_t)clip0 * Ci * TV;
-    __syncthreads();  // tables ready / previous tile's conv reads done
+    lds_barrier();  // tables ready / previous tile's conv reads done
     if (Zg) {              // stored Z = gcn(X) (training: written by the statistics pass): stage it, skip the mixing
       stage_rows<T, V>(Zg + (size_t)clip0 * Ci * TV, img, rows * TV, false, 0.f);
     } else {
       if (!(dbg & 4)) stage_rows<T, V>(gin, img, rows * TV, pre, a_in);
-      __syncthreads();
+      lds_barrier();
       if (!(dbg & 1)) gcn_mfma<T, V, false>(img, rows, AwL, TwL);
     }
-    __syncthreads();
+    lds_barrier();
     for (int n = 0; n < nb && !(dbg & 2); ++n) {
       float* og = out + (size_t)(clip0 + n) * Co * TV;
       auto epi = [&](int o, int p, bool pok, float v0, float v1) {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_layer_apply_z(
     Wl[e] = c < Ci ? wfold[(size_t)(src * Ci + c) * CoP + o] : 0.f;
   }
   for (int e = threadIdx.x; e < CoP; e += 256) bl[e] = bias[e];
-  __syncthreads();
+  lds_barrier();
   const int NOG = (CoP / 16 + OTI - 1) / OTI;
   const int wave = uniform(threadIdx.x >> 6);
   const int KS = KZ / 4;                       // k-steps per source

@@ -45,15 +45,15 @@ __global__ __launch_bounds__(kBlock, (NTC <= 2 ? 6 : 4)) void k_fwd_moments(cons
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
     const int rows = nb * Ci;
-    __syncthreads();  // previous tile's MFMA reads are done
+    lds_barrier();  // previous tile's MFMA reads are done
     stage_rows<T, V, LD>(in + (size_t)clip0 * Ci * TV, lds, rows * TV, pre, a_in);
-    __syncthreads();
+    lds_barrier();
     if (need_x) {
       for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC, LD>(lds + n * Ci * LD, Ci, mx, sx);
-      __syncthreads();
+      lds_barrier();
     }
     gcn_mfma<T, V, false, LD>(lds, rows, AwL, TwL);
-    __syncthreads();
+    lds_barrier();
     // Z = gcn(X) is kept for the rest of the step (apply and both backward kernels read it instead of recomputing)
     if (Zout) unstage_rows<T, V, LD>(Zout + (size_t)clip0 * Ci * TV, lds, rows * TV);
     for (int n = 0; n < nb; ++n) moment_accum<T, V, NTC, LD>(lds + n * Ci * LD, Ci, mz, sz);

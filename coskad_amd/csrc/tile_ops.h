@@ -182,11 +182,11 @@ __device__ __forceinline__ void gcn_rows(float* lds, int rows, const float* __re
                                          const float* __restrict__ Tw) {
   if constexpr (!ADJ) {
     mix_rows<T, V, true, false>(lds, rows, Tw);
-    __syncthreads();
+    lds_barrier();
     mix_rows<T, V, false, false>(lds, rows, Aw);
   } else {
     mix_rows<T, V, false, true>(lds, rows, Aw);
-    __syncthreads();
+    lds_barrier();
     mix_rows<T, V, true, true>(lds, rows, Tw);
   }
 }
@@ -278,10 +278,10 @@ __device__ __forceinline__ void store_moments(const f32x4 (&acc)[NT][NT], const 
   for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
     for (int tb = ta; tb < NT; ++tb) {
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int r = 0; r < 4; ++r) scratch[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[ta][tb][r];
-      __syncthreads();
+      lds_barrier();
       const int e = threadIdx.x;
       if (e < 256) {
         const int row = e >> 4, col = e & 15;
@@ -300,9 +300,9 @@ __device__ __forceinline__ void store_moments(const f32x4 (&acc)[NT][NT], const 
     float v = rs[t];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    __syncthreads();
+    lds_barrier();
     if (lane < 16) scratch[wave * 16 + lane] = v;
-    __syncthreads();
+    lds_barrier();
     const int e = threadIdx.x;
     if (e < 16 && 16 * t + e < valid) {
       float s = 0.f;
@@ -324,10 +324,10 @@ __device__ __forceinline__ void store_outer(const f32x4 (&acc)[NTA][NTB], float*
   for (int ta = 0; ta < NTA; ++ta)
 #pragma unroll
     for (int tb = 0; tb < NTB; ++tb) {
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int r = 0; r < 4; ++r) scratch[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[ta][tb][r];
-      __syncthreads();
+      lds_barrier();
       const int e = threadIdx.x;  // first 256 threads <-> 16x16 tile elements
       if (e < 256) {
         const int row = e >> 4, col = e & 15;
@@ -345,12 +345,12 @@ __device__ __forceinline__ void store_sums(const f32x4 (&sacc)[NTA], float* scra
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int ta = 0; ta < NTA; ++ta) {
-    __syncthreads();
+    lds_barrier();
     if ((lane & 15) == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) scratch[wave * 16 + 4 * (lane >> 4) + r] = sacc[ta][r];
     }
-    __syncthreads();
+    lds_barrier();
     const int e = threadIdx.x;
     if (e < 16 && 16 * ta + e < va) {
       float s = 0.f;
@@ -371,9 +371,9 @@ __device__ __forceinline__ void store_rowsums(const float (&rs)[NT], float* scra
     float v = rs[t];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    __syncthreads();
+    lds_barrier();
     if (lane < 16) scratch[wave * 16 + lane] = v;
-    __syncthreads();
+    lds_barrier();
     const int e = threadIdx.x;
     if (e < 16 && 16 * t + e < valid) {
       float s = 0.f;
