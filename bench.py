@@ -179,7 +179,7 @@ def main():
             # SURVEY 8d, backward of one layer: read dOut (C_out), read the saved input (C_in), write dIn (C_in)
             byts = B * tvb * (HID + 2 * CHANNELS[-1])
             ach = byts / (probe_ms.value * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_bwd_data_f<12,17,2> (layer 4 backward data path, 64 -> 32 channels, fused single-read variant)",
+            roof = {"bound": "hbm", "kernel": "k_bwd_data_f<12,17,2,1> (layer 4 backward data path, 64 -> 32 channels, single-read variant)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": (traffic.get("bwd_data layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
                     "traffic_source": "profiles/r01_hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE, B=4096)",

@@ -111,7 +111,7 @@ def main(tag: str) -> None:
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, B=4096); "
                    "counters are KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE reads "
                    "1/2 of a wide coalesced stream; narrower accesses uncalibrated: upper bound)"}
-    for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2>"), ("layer_apply layer4", "k_layer_apply_m<12,17,4>")):
+    for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2,1>"), ("layer_apply layer4", "k_layer_apply_m<12,17,4>")):
         b = biggest(prefix)
         if b:
             (k, lds, wg), (fe, wr, hbm) = b
