@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import ops, parallel
 from .models.sts.ae import STSE
-from .trainer import STSETrainStep
+from .trainer import STSETrainStep, make_train_step
 from .utils import eval_utils
 
 
@@ -106,13 +106,13 @@ class LitEncoder(nn.Module):
             mu = self.model.c if self.static_center else self._temp
             self.model.inv_cov_matrix.copy_(inv_cov_from_moments(gram, acc, mu, L))
         self.model.train()
-        self._engine = STSETrainStep(self.model, lr=self.learning_rate, alpha=float(getattr(self.args, "alpha", 0.0)),
+        self._engine = make_train_step(self.model, lr=self.learning_rate, alpha=float(getattr(self.args, "alpha", 0.0)),
                                      head="poincare" if self.hyperbolic else ("mahalanobis" if maha else "euclidean"))
         self._epoch = 0
 
     # ---- one optimisation step -----------------------------------------------------------
     def training_step(self, batch, batch_idx: int) -> torch.Tensor:
-        dev = self._engine.fp.flat.device
+        dev = self.model.c.device
         stats = self._engine.step(batch[0].to(dev, non_blocking=True))
         if batch_idx % 20 == 0:                           # log_every_n_steps=20 (train_COSKAD.py:76)
             reg = self._engine.reg_loss()

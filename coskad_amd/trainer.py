@@ -195,3 +195,82 @@ class STSETrainStep:
         self.model.c.copy_(c)
         self.center_acc.zero_()
         return self.model.c
+
+
+class AutogradTrainStep:
+    """Same interface as STSETrainStep for models the flat-buffer fast path does not take: the `mlp` projector (what 5
+    of the reference's 7 yamls select), the plain-GCN encoders, wide stacks.  Forward / backward go through the module
+    surface (autograd nodes around the HIP kernels, library GEMMs where the module uses them); the one-class head and
+    its gradient are the HIP head kernels (`z.backward(dz)`), the regulariser gradient is added to `.grad`, the
+    optimiser is torch's Adam (calc_reg_loss / configure_optimizers of the reference wrappers)."""
+
+    def __init__(self, model, lr: float = 1e-4, alpha: float = 1e-6, head: str = 'euclidean', betas=(0.9, 0.999),
+                 eps: float = 1e-8, process_group=None) -> None:
+        self.model, self.head, self.alpha, self.pg = model, head, float(alpha), process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.params = [(n, p) for n, p in model.named_parameters()]
+        self.reg_params = [p for n, p in self.params if 'bias' not in n]          # model_utils.py:92
+        self.reg_scale = 0.5 / max(1, len(self.reg_params))
+        self.opt = torch.optim.Adam([p for _, p in self.params], lr=lr, betas=betas, eps=eps)
+        dev = self.params[0][1].device
+        self.center_acc = torch.zeros(ops.HEAD_SLOTS, device=dev, dtype=torch.float32)
+        L = model.latent_dim
+        self.gram_acc = torch.zeros(L, L, device=dev, dtype=torch.float32) if head == 'mahalanobis' else None
+        self.steps = 0
+
+    def set_lr(self, lr: float) -> None:
+        for g in self.opt.param_groups:
+            g['lr'] = lr
+
+    def step(self, x: Tensor) -> Tensor:
+        self.steps += 1
+        m = self.model
+        self.opt.zero_grad(set_to_none=True)
+        z = m(x)
+        zd = z.detach().contiguous()
+        if self.head == 'euclidean':
+            stats, dz, _ = ops.mse_head(zd, m.c, acc=self.center_acc)
+        elif self.head == 'poincare':
+            stats, dz, _, _ = ops.poincare_head(zd, m.c, acc=self.center_acc)
+        elif self.head == 'mahalanobis':
+            stats, dz, _ = ops.mahalanobis_head(zd, m.c, m.inv_cov_matrix, acc=self.center_acc, gram=self.gram_acc)
+        else:
+            raise ValueError(f"unknown head {self.head}")
+        z.backward(dz)
+        with torch.no_grad():
+            coef = self.alpha * 2.0 * self.reg_scale          # d/dp of alpha * reg_scale * sum p^2
+            for p in self.reg_params:
+                if p.grad is not None:
+                    p.grad.add_(p, alpha=coef)
+            if self.world > 1:
+                for _, p in self.params:
+                    if p.grad is not None:
+                        dist.all_reduce(p.grad, group=self.pg)
+                        p.grad.div_(self.world)
+        self.opt.step()
+        return stats
+
+    def reg_loss(self) -> Tensor:
+        with torch.no_grad():
+            return self.reg_scale * sum((p.float() ** 2).sum() for p in self.reg_params).reshape(1)
+
+    def refresh_center(self, eps: float = 1e-3) -> Tensor:
+        parallel.allreduce_sum_(self.center_acc, self.pg)
+        L = self.model.latent_dim
+        c = ops.center_finalize(self.center_acc, eps, L) if self.head != 'poincare' else ops.midpoint_finalize(self.center_acc, L)
+        self.model.c.copy_(c)
+        self.center_acc.zero_()
+        return self.model.c
+
+    refresh_inv_cov = STSETrainStep.refresh_inv_cov
+
+
+def make_train_step(model, **kw):
+    """STSETrainStep when the model is the fused STS-GCN encoder + linear projector, AutogradTrainStep otherwise."""
+    from .models.common.components import Encoder
+    fast = (isinstance(getattr(model, 'btlnk', None), torch.nn.Linear) and isinstance(getattr(model, 'encoder', None), Encoder)
+            and not any(l.is_wide for l in model.encoder.model) and model.latent_dim <= 16)
+    if fast:
+        return STSETrainStep(model, **kw)
+    kw.pop('use_graph', None); kw.pop('side_stream', None)
+    return AutogradTrainStep(model, **kw)

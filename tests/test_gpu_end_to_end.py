@@ -21,7 +21,7 @@ def make_args(**kw):
     return Namespace(**a)
 
 
-@pytest.mark.parametrize("mode", ["euclid_dynamic", "euclid_static", "hyperbolic", "mahalanobis_static"])
+@pytest.mark.parametrize("mode", ["euclid_dynamic", "euclid_static", "hyperbolic", "mahalanobis_static", "euclid_mlp"])
 def test_train_score_auc_parity(mode, tmp_path):
     from coskad_amd.lit import LitEncoder, Trainer, load_checkpoint
     from coskad_amd.utils.synthetic import batches, make_dataset
@@ -29,7 +29,8 @@ def test_train_score_auc_parity(mode, tmp_path):
     train, _ = make_dataset(n_scenes=2, n_clips=3, n_persons=2, clip_len=100, num_transform=2, anomaly=False, seed=1)
     test, gts = make_dataset(n_scenes=1, n_clips=3, n_persons=2, clip_len=100, num_transform=2, anomaly=True, seed=2)
     args = make_args(hyperbolic=(mode == "hyperbolic"), static_center=mode in ("euclid_static", "mahalanobis_static"),
-                     distance="mahalanobis" if mode == "mahalanobis_static" else "euclidean")
+                     distance="mahalanobis" if mode == "mahalanobis_static" else "euclidean",
+                     projector="mlp" if mode == "euclid_mlp" else "linear")   # 'mlp': what 5 of the 7 reference yamls select
     lit = LitEncoder(args).cuda()
     lit.gts = gts
     tr = Trainer(max_epochs=3, ckpt_dir=str(tmp_path))

@@ -228,3 +228,38 @@ def test_wide_stack_c256_vs_oracle():
             continue
         ref = params[k].grad.numpy()
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-3, atol=1e-3 * np.abs(ref).max() + 1e-9, err_msg=k)
+
+
+def test_autograd_train_step_matches_fast_path_and_handles_mlp():
+    """AutogradTrainStep (module surface + torch Adam) == STSETrainStep (flat buffers + HIP Adam) on a model both take;
+    make_train_step routes the `mlp` projector and the plain-GCN encoders to it."""
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import AutogradTrainStep, STSETrainStep, make_train_step
+    from oracle import ref_cpu as R
+    x = R.synthetic_clips(48, seed=4).cuda()
+    outs = []
+    for cls in (STSETrainStep, AutogradTrainStep):
+        st = R.init_stse_state(2, (8, 4, 8), 8, 8, 12, 17, seed=1)
+        st["c"] = torch.full((8,), 0.1)
+        m = STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+        m.load_state_dict(st, strict=True)
+        eng = cls(m.cuda().train(), lr=1e-3, alpha=1e-4, head='euclidean')
+        losses = [float(eng.step(x)[0]) for _ in range(3)]
+        outs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, float(eng.reg_loss())))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-5)
+    for k in outs[0][1]:
+        if k.endswith(("tcn.0.bias", "residual.0.bias")):
+            continue      # zero-gradient biases: torch's autograd noise makes torch Adam move them by +-lr (DESIGN 5)
+        np.testing.assert_allclose(outs[0][1][k].float().numpy(), outs[1][1][k].float().numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+    for kw in (dict(projector='mlp'), dict(encoder_type='learnable_gcn')):
+        args = dict(encoder_type='sts_gcn', projector='linear')
+        args.update(kw)
+        m = STSE(2, [8, 4, 8], 8, 8, 12, 17, args['encoder_type'], args['projector'], 'euclidean', 0.0).cuda().train()
+        eng = make_train_step(m, lr=1e-3, alpha=1e-6, head='euclidean')
+        assert isinstance(eng, AutogradTrainStep)
+        l0 = float(eng.step(x)[0])
+        for _ in range(5):
+            l1 = float(eng.step(x)[0])
+        assert np.isfinite(l1) and l1 < l0
+    assert isinstance(make_train_step(STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0).cuda(), lr=1e-3), STSETrainStep)
