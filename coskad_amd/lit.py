@@ -22,6 +22,7 @@ from typing import Callable, Dict, Iterable, List, Optional, Tuple
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops, parallel
 from .models.sts.ae import STSE
@@ -190,14 +191,188 @@ class LitEncoder(nn.Module):
         return out
 
     def post_processing(self, hidden_out, trans, meta, frames) -> float:
+        return self._score_windows(self.window_scores(hidden_out), trans, meta, frames)
+
+    def _score_windows(self, scores, trans, meta, frames) -> float:
+        """window scores -> frames -> persons -> smoothing -> transformations -> AUC (eval_COSKAD.py:140-253)."""
         num_transform = max(1, int(getattr(self.args, "dataset_num_transform", 1)))
-        scores = self.window_scores(hidden_out)
         auc, per_t, gt = eval_utils.score_dataset(scores, trans, meta, frames, self._load_gts(), num_transform,
                                                   smoothing=int(getattr(self.args, "smoothing", 50)),
                                                   dataname=getattr(self.args, "dataset_choice", "UBnormal"))
         self.log("validation_auc", auc)
         self.last_scores = per_t
         return auc
+
+
+class _AutogradLit(LitEncoder):
+    """Shared machinery of the wrappers whose loss involves the decoder (autoencoder, spherical VAE): the model runs
+    through its module surface (autograd nodes around the HIP kernels), torch's Adam optimises, gradients are averaged
+    over ranks.  Validation outputs are per-window scores computed on the device."""
+
+    model_cls = None
+
+    def _build(self, args: Namespace, **extra) -> None:
+        nn.Module.__init__(self)
+        self.args, self.hparams = args, Namespace(args=args)
+        self.hyperbolic, self.static_center, self.distance = False, True, 'euclidean'
+        self.eps = float(getattr(args, "center_tolerance", 1e-3))
+        self.model = self.model_cls(c_in=args.num_coords, h_dim=args.h_dim, latent_dim=args.latent_dim,
+                                    n_frames=args.dataset_seg_len, dropout=args.dropout, n_joints=_joints(args),
+                                    channels=list(getattr(args, "channels", [32, 16, 32])), **extra)
+        self.learning_rate = args.opt_lr
+        self.batch_size = getattr(args, "dataset_batch_size", 2048)
+        self.logged: Dict[str, float] = {}
+        self.gts = None
+        object.__setattr__(self, "_engine", self)   # the Trainer's plateau rule calls _engine.set_lr (not a submodule)
+        self._opt = None
+
+    def set_lr(self, lr: float) -> None:
+        for g in self._opt.param_groups:
+            g['lr'] = lr
+
+    def _reg_loss(self) -> torch.Tensor:
+        """utils/model_utils.py:90-105 (differentiable: it is part of these wrappers' loss)."""
+        ps = [p for n, p in self.model.named_parameters() if 'bias' not in n]
+        return 0.5 * sum((p ** 2).sum() for p in ps) / len(ps)
+
+    def _optimise(self, loss: torch.Tensor) -> None:
+        self._opt.zero_grad(set_to_none=True)
+        loss.backward()
+        w = parallel.world_size()
+        if w > 1:
+            for p in self.model.parameters():
+                if p.grad is not None:
+                    parallel.allreduce_mean_(p.grad)
+        self._opt.step()
+
+    def validation_step(self, batch, batch_idx: int = 0):
+        dev = self.model.c.device
+        with torch.no_grad():
+            return self.window_scores_from_batch(batch[0].to(dev)), batch[1], batch[2], batch[3]
+
+    predict_step = validation_step
+
+    def validation_epoch_end(self, outputs: List) -> float:
+        scores, trans, meta, frames = (torch.cat([o[i] for o in outputs], 0) for i in range(4))
+        return self._score_windows(scores, trans, meta, frames)
+
+    def on_train_epoch_end(self) -> None:
+        pass
+
+    training_epoch_end = on_train_epoch_end
+
+
+class LitAutoEncoder(_AutogradLit):
+    """models/euclidean_autoencoder.py: STSAE with loss lambda_ * MSE(x_rec, x) + MSE(z, c) + alpha * reg (:106-118),
+    static centre from the initial latents (:76-100), window score = reconstruction error (eval_utils.py:77-105 with its
+    default loss_type 'rec').  The reference unpacks the model's outputs in the order of its missing old module
+    (SURVEY 8a row a9); the intent -- first the reconstruction, then the latent -- is what is implemented."""
+
+    from .models.sts.ae import STSAE as model_cls
+
+    def __init__(self, args: Namespace) -> None:
+        self._build(args)
+        self.lambda_ = float(getattr(args, "lambda_", 0.01))
+
+    def forward(self, x):
+        z, x_rec = self.model(x[0])
+        return x_rec, z, x[0], x[1], x[2], x[3]
+
+    def setup(self, stage: str = None, train_loader=None) -> None:
+        if stage != "fit":
+            return
+        dev = self.model.c.device
+        acc = torch.zeros(ops.HEAD_SLOTS, device=dev)
+        self.model.eval()
+        with torch.no_grad():
+            for batch in train_loader():
+                z, _ = self.model(batch[0].to(dev))
+                ops.mse_head(z.contiguous(), self.model.c, need_grad=False, acc=acc)
+        parallel.allreduce_sum_(acc)
+        self.model.c.copy_(ops.center_finalize(acc, self.eps, self.model.latent_dim))
+        self.model.train()
+        self._opt = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate)
+
+    def training_step(self, batch, batch_idx: int) -> torch.Tensor:
+        x = batch[0].to(self.model.c.device, non_blocking=True)
+        z, x_rec = self.model(x)
+        loss_reco = F.mse_loss(x_rec, x)
+        loss_h = F.mse_loss(z, self.model.c.expand_as(z))
+        loss_reg = self._reg_loss()
+        loss = self.lambda_ * loss_reco + loss_h + float(getattr(self.args, "alpha", 0.0)) * loss_reg
+        self._optimise(loss)
+        if batch_idx % 20 == 0:
+            self.log("loss", loss.detach()); self.log("reconstruction_loss", loss_reco.detach())
+            self.log("hypersphere_loss", loss_h.detach()); self.log("regularization", loss_reg.detach())
+        return loss.detach()
+
+    def window_scores_from_batch(self, x: torch.Tensor) -> torch.Tensor:
+        _, x_rec = self.model(x)
+        return ((x_rec - x) ** 2).reshape(x.shape[0], -1).mean(-1)
+
+
+class LitVAE(_AutogradLit):
+    """models/spherical_vae.py: STSVAE with loss phi * MSE(x_rec, x) + alpha * reg + beta * KL(q || p) + gamma * mean(1/kappa)
+    (:81-107), `mean_vector` = mean of the epoch's sampled latents (:110-116), window score = 1 - cos(z, mean_vector)
+    of the SAMPLED latent (:76-78, 200) -- stochastic, as in the reference."""
+
+    from .models.sts.vae import STSVAE as model_cls
+
+    def __init__(self, args: Namespace) -> None:
+        self.distribution = str(getattr(args, "distribution", "ps")).lower()
+        self._build(args, distribution=self.distribution, projector=getattr(args, "projector", "linear"))
+        self.phi, self.beta, self.gamma = float(args.phi), float(args.beta), float(args.gamma)
+        self.warmup_counter = int(getattr(args, "warmup_epochs", 0))
+        if not hasattr(self.model, "mean_vector"):
+            self.model.register_buffer("mean_vector", torch.zeros(1, args.latent_dim))
+        self._zsum, self._zn = None, 0
+
+    def forward(self, x):
+        z, x_rec, _ = self.model(x[0])
+        return z, x_rec, x[1], x[2], x[3]
+
+    def setup(self, stage: str = None, train_loader=None) -> None:
+        if stage == "fit":
+            self.model.train()
+            self._opt = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate)
+
+    def training_step(self, batch, batch_idx: int) -> torch.Tensor:
+        from .models.sts.vae import kl_ps_uniform
+        x = batch[0].to(self.model.c.device, non_blocking=True)
+        z, x_rec, (q, p, kappa) = self.model(x)
+        with torch.no_grad():
+            s = z.sum(0, keepdim=True)
+            self._zsum = s if self._zsum is None else self._zsum + s
+            self._zn += z.shape[0]
+        if self.distribution == 'normal':
+            loss_kl = torch.distributions.kl.kl_divergence(q, p).sum(-1).mean()
+        else:
+            loss_kl = kl_ps_uniform(q, p).mean()
+        loss_rec = F.mse_loss(x_rec, x)
+        loss_reg = self._reg_loss()
+        loss_exp = (1 / kappa).mean()
+        loss = self.phi * loss_rec + float(getattr(self.args, "alpha", 0.0)) * loss_reg + self.beta * loss_kl + self.gamma * loss_exp
+        self._optimise(loss)
+        if batch_idx % 20 == 0:
+            self.log("loss", loss.detach()); self.log("reconstruction_loss", loss_rec.detach())
+            self.log("kl_loss", loss_kl.detach()); self.log("exp_dist_loss", loss_exp.detach())
+            self.log("regularization", loss_reg.detach())
+        return loss.detach()
+
+    def on_train_epoch_end(self) -> None:                    # update_state (:110-116)
+        if self._zn:
+            zs = torch.cat([self._zsum.reshape(-1), self._zsum.new_tensor([float(self._zn)])])
+            parallel.allreduce_sum_(zs)
+            self.model.mean_vector.copy_((zs[:-1] / zs[-1]).reshape(1, -1))
+        if self.warmup_counter > 0:
+            self.warmup_counter -= 1
+        self._zsum, self._zn = None, 0
+
+    training_epoch_end = on_train_epoch_end
+
+    def window_scores_from_batch(self, x: torch.Tensor) -> torch.Tensor:
+        z, _, _ = self.model(x)
+        return 1 - F.cosine_similarity(self.model.mean_vector.expand_as(z), z)
 
 
 class Trainer:

@@ -18,7 +18,14 @@ def main():
     args = argparse.Namespace(**yaml.load(open(parser.parse_args().config), Loader=yaml.FullLoader))
     args, dataset_args, ae_args, res_args, opt_args = init_sub_args(args)
     torch.cuda.set_device(0)
-    model = LitEncoder(args).cuda()
+    if args.use_vae:                                 # wrapper selection: eval_COSKAD.py:60-80
+        from coskad_amd.lit import LitVAE
+        model = LitVAE(args).cuda()
+    elif args.use_decoder:
+        from coskad_amd.lit import LitAutoEncoder
+        model = LitAutoEncoder(args).cuda()
+    else:
+        model = LitEncoder(args).cuda()
     path = os.path.join(args.exp_dir, args.dataset_choice, args.dir_name, args.load_ckpt)
     print('Loading model from {}'.format(path))
     trainer = Trainer()

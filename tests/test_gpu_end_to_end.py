@@ -85,3 +85,38 @@ def test_train_score_auc_parity(mode, tmp_path):
     lit2 = LitEncoder(args).cuda()
     load_checkpoint(lit2, ck[-1])
     assert all(k.startswith("model.") for k in torch.load(ck[-1], weights_only=False)["state_dict"])
+
+
+@pytest.mark.parametrize("kind", ["autoencoder", "spherical_vae"])
+def test_decoder_wrappers_fit_and_score(kind, tmp_path):
+    """LitAutoEncoder (euclidean_autoencoder.py) and LitVAE (spherical_vae.py): fit on synthetic windows, per-window
+    scores against the oracle on the same trained weights (autoencoder; the VAE score uses a sampled latent)."""
+    from coskad_amd.lit import LitAutoEncoder, LitVAE, Trainer
+    from coskad_amd.utils.synthetic import batches, make_dataset
+    torch.manual_seed(0)
+    train, _ = make_dataset(n_scenes=2, n_clips=2, n_persons=2, clip_len=80, num_transform=2, anomaly=False, seed=1)
+    test, gts = make_dataset(n_scenes=1, n_clips=2, n_persons=2, clip_len=80, num_transform=2, anomaly=True, seed=2)
+    args = make_args(latent_dim=8, lambda_=0.01, phi=1.0, beta=1e-3, gamma=1e-2, distribution="ps", warmup_epochs=1,
+                     decoder_channels=[8, 8], use_decoder=(kind == "autoencoder"), use_vae=(kind == "spherical_vae"))
+    lit = (LitAutoEncoder if kind == "autoencoder" else LitVAE)(args).cuda()
+    lit.gts = gts
+    tr = Trainer(max_epochs=2, ckpt_dir=str(tmp_path))
+    tr.fit(lit, lambda: batches(train, 256, shuffle=True, seed=0), lambda: batches(test, 512))
+    assert len(tr.history) == 2 and all(0.0 <= h["validation_auc"] <= 1.0 for h in tr.history)
+    assert np.isfinite(tr.history[-1]["loss"]) and tr.history[-1]["reconstruction_loss"] > 0
+    x = test[0]
+    lit.model.eval()
+    with torch.no_grad():
+        s_hip = lit.window_scores_from_batch(x.cuda()).cpu()
+    assert s_hip.shape == (x.shape[0],) and torch.isfinite(s_hip).all()
+    if kind == "autoencoder":
+        st = {k: v.detach().cpu().clone() for k, v in lit.model.state_dict().items()}
+        with torch.no_grad():
+            z = R.stse_encode(x, st, training=False)
+            xr = R.stsae_decode(z, st, 16, 12, 17, training=False)
+        s_ref = ((xr - x) ** 2).reshape(x.shape[0], -1).mean(-1)
+        np.testing.assert_allclose(s_hip.numpy(), s_ref.numpy(), rtol=2e-4, atol=1e-5)
+        assert float(lit.model.c.abs().min()) >= 1e-3 - 1e-9            # clamped centre (:97-98)
+    else:
+        assert float(lit.model.mean_vector.abs().sum()) > 0             # update_state ran (:110-116)
+        assert (s_hip >= -1e-6).all() and (s_hip <= 2 + 1e-6).all()     # 1 - cos in [0, 2]

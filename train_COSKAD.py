@@ -33,9 +33,14 @@ def main():
     if rank == 0:
         os.makedirs(args.ckpt_dir, exist_ok=True)
         shutil.copy(config_path, os.path.join(args.ckpt_dir, "config.yaml"))      # train_COSKAD.py:33
-    if args.use_decoder or args.use_vae:
-        raise NotImplementedError("autoencoder / VAE wrappers are outside this round's scope (SURVEY 8f)")
-    model = LitEncoder(args).cuda()                  # hyperbolic / static_center switches: train_COSKAD.py:36-55
+    if args.use_vae:                                 # wrapper selection: train_COSKAD.py:36-55
+        from coskad_amd.lit import LitVAE
+        model = LitVAE(args).cuda()
+    elif args.use_decoder:
+        from coskad_amd.lit import LitAutoEncoder
+        model = LitAutoEncoder(args).cuda()
+    else:
+        model = LitEncoder(args).cuda()              # hyperbolic / static_center switches inside
     bs = args.dataset_batch_size
     trainer = Trainer(max_epochs=args.ae_epochs, ckpt_dir=args.ckpt_dir, save_top_k=2)
     if args.data_dir == 'synthetic':
