@@ -44,6 +44,13 @@ class LayerTensors:
     nbt_r: Optional[Tensor]
     slope: Tensor           # prelu.weight [1]
     momentum: float = 0.1
+    cache: Optional[dict] = None   # owned by the layer module: eval-mode folded weights, keyed by tensor versions
+
+    def fold_key(self):
+        """Identity + in-place version of everything the eval-mode fold reads (optimizer steps, load_state_dict and
+        running-stat updates bump the versions)."""
+        ts = (self.Wt, self.bt, self.gt, self.bet, self.rm_t, self.rv_t, self.Wr, self.br, self.gr, self.ber, self.rm_r, self.rv_r)
+        return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
 
     @property
     def Co(self) -> int:
@@ -122,8 +129,14 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
                 h, L.A, L.T, slope, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
                 L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum, Z=Z)
         else:
-            wfold, bias = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t,
-                                      L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
+            key = L.fold_key() if L.cache is not None else None
+            if key is not None and L.cache.get("key") == key:
+                wfold, bias = L.cache["fold"]              # weights unchanged since the last eval forward
+            else:
+                wfold, bias = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t,
+                                          L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
+                if key is not None:
+                    L.cache["key"], L.cache["fold"] = key, (wfold, bias)
             stat = None
         if Z is not None:
             u = ops.layer_apply_z(Z, h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)

@@ -68,7 +68,8 @@ def layer_tensors(layer: "ST_GCNN_layer") -> engine.LayerTensors:
         gr=rb.weight if has_res else None, ber=rb.bias if has_res else None,
         rm_r=rb.running_mean if has_res else None, rv_r=rb.running_var if has_res else None,
         nbt_r=rb.num_batches_tracked if has_res else None, slope=layer.prelu.weight,
-        momentum=tb.momentum if tb.momentum is not None else 0.1)
+        momentum=tb.momentum if tb.momentum is not None else 0.1,
+        cache=layer.__dict__.setdefault("_fold_cache", {}))
 
 
 class _ChainFn(torch.autograd.Function):

@@ -263,3 +263,24 @@ def test_autograd_train_step_matches_fast_path_and_handles_mlp():
             l1 = float(eng.step(x)[0])
         assert np.isfinite(l1) and l1 < l0
     assert isinstance(make_train_step(STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0).cuda(), lr=1e-3), STSETrainStep)
+
+
+def test_eval_fold_cache_tracks_weight_changes(golden):
+    """Eval-mode folded weights are cached per layer and refreshed when any input of the fold changes in place."""
+    g = golden("stse_default.npz")
+    m, st = build_stse(g)
+    x = torch.from_numpy(g["x"]).cuda()
+    m.eval()
+    with torch.no_grad():
+        z0 = m(x).clone()
+        z1 = m(x)                                   # served from the cache
+        assert torch.equal(z0, z1)
+        layer = m.encoder.model[1]
+        assert "fold" in layer.__dict__["_fold_cache"]
+        layer.tcn[1].running_var.mul_(1.5)          # in-place change of a BN buffer -> stale cache must not be used
+        z2 = m(x)
+        assert not torch.allclose(z0, z2)
+        layer.tcn[1].running_var.div_(1.5)
+        np.testing.assert_allclose(m(x).cpu().numpy(), z0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        layer.tcn[0].weight.data.copy_(layer.tcn[0].weight.data * 1.0)      # version bump, same values
+        assert torch.equal(m(x), m(x))
