@@ -47,8 +47,8 @@ class LayerTensors:
     cache: Optional[dict] = None   # owned by the layer module: eval-mode folded weights, keyed by tensor versions
 
     def fold_key(self):
-        """Identity + in-place version of everything the eval-mode fold reads (optimizer steps, load_state_dict and
-        running-stat updates bump the versions)."""
+        """Identity + in-place version of everything the eval-mode fold reads (torch optimizers and load_state_dict bump
+        the versions; a training forward clears the cache because this library's kernels write through raw pointers)."""
         ts = (self.Wt, self.bt, self.gt, self.bet, self.rm_t, self.rv_t, self.Wr, self.br, self.gr, self.ber, self.rm_r, self.rv_r)
         return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
 
@@ -122,6 +122,9 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
             raise ValueError(f"layer expects {L.Ci} input channels, got {h.shape[1]}")
         Z = None
         if training:
+            if L.cache:
+                L.cache.clear()   # running stats (and, after the optimiser, the weights) change through raw-pointer kernels
+                                  # that do not bump torch's version counters: drop the eval-mode fold
             buf = ws.get(ops.train_stats_ws_bytes(L.Ci), x.device)
             if STORE_Z:
                 Z = torch.empty_like(h)     # gcn(PReLU(h)): written by the statistics pass, read by everything after
