@@ -790,7 +790,7 @@ __device__ __forceinline__ void rowk_accum(const float* img1, int a0, int na, co
 }
 
 template <int T, int V>
-__global__ __launch_bounds__(kBlock) void k_bwd_gcn_params(const float* __restrict__ in,
+__global__ __launch_bounds__(kBlock, (V <= 17 ? 6 : 4)) void k_bwd_gcn_params(const float* __restrict__ in,
                                                           const float* __restrict__ dZ,
                                                           const float* __restrict__ Aw,
                                                           const float* __restrict__ Tw,
@@ -1140,12 +1140,17 @@ static int launch_layer_gcn_params(const float* in, const float* in_slope, const
                                    float* dslope = nullptr) {
   constexpr int LD = Geo<T, V>::LD;
   const int E = T * V * V + V * T * T;
-  int NB = Ci >= 32 ? 1 : 32 / Ci;
-  if (NB > B) NB = B;
-  const size_t lds = ((size_t)2 * NB * Ci * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
+  // Both products sum over rows = (clip, channel) and the mixing is per row, so a tile is ANY run of consecutive rows
+  // of the [B*C_in, T*V] matrix: 16-row tiles (one MFMA row tile) keep two images + tables under a third of the LDS
+  // -> three blocks per CU.  The kernel is told "C_in = 1, B = rows".
+  const int rows_total = B * Ci;
+  const int RTILE = rows_total < 16 ? rows_total : 16;
+  const size_t lds = ((size_t)2 * RTILE * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
   if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
-  const int ntiles = ceil_div(B, NB);
-  const int grid = ntiles < 512 ? ntiles : 512;
+  const int ntiles = ceil_div(rows_total, RTILE);
+  const int per_cu = (lds <= (size_t)52 * 1024 && V <= 17) ? 3 : (lds <= (size_t)80 * 1024 ? 2 : 1);
+  const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+  const int NB = RTILE;
   auto k = k_bwd_gcn_params<T, V>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   {
@@ -1153,9 +1158,9 @@ static int launch_layer_gcn_params(const float* in, const float* in_slope, const
 #ifdef COSKAD_ABLATE
     static int ablg = -1;
     if (ablg < 0) { const char* e = getenv("COSKAD_ABLG"); ablg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, B, Ci, NB, ablg);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, rows_total, 1, NB, ablg);
 #else
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, B, Ci, NB);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, rows_total, 1, NB);
 #endif
   }
   int rc;
