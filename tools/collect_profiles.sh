@@ -23,4 +23,6 @@ rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $out/mfma -o run 
 echo "mfma pass done"
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/lds -o run -- python3 $args > $out/lds.log 2>&1
 echo "lds pass done"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $out/sq -o run -- python3 $args > $out/sq.log 2>&1
+echo "sq pass done"
 tail -1 $out/stats.log

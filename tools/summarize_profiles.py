@@ -104,6 +104,24 @@ def main(tag: str) -> None:
                 lds = 100.0 * conf / idx if idx else float("nan")
                 f.write(f"\"{key[0]}\",{key[1]},{key[2]},{util:.1f},{lds:.1f}\n")
 
+    # wave-cycle breakdown (optional pass): waits / issue stalls / active, as a share of SQ_WAVE_CYCLES per kernel symbol
+    hits = glob.glob(f"{src}/sq/**/*counter_collection.csv", recursive=True)
+    if hits:
+        sq = defaultdict(lambda: defaultdict(list))
+        with open(hits[0]) as f:
+            for r in csv.DictReader(f):
+                sq[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        names = ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VALU")
+        rows_ = []
+        for k, c in sq.items():
+            wc = sum(c.get("SQ_WAVE_CYCLES", [0.0]))
+            if wc > 0 and k.startswith("k_"):
+                rows_.append((wc, k, [100.0 * sum(c.get(n, [0.0])) / wc for n in names]))
+        with open(f"{dst}/{tag}_sq_wait_pmc.csv", "w") as f:
+            f.write("kernel,wait_any_pct,wait_inst_any_pct,wait_inst_lds_pct,active_inst_any_pct,active_inst_lds_pct,active_inst_valu_pct\n")
+            for _, k, v in sorted(rows_, reverse=True):
+                f.write(f"\"{k}\"," + ",".join(f"{x:.1f}" for x in v) + "\n")
+
     def biggest(prefix: str):
         c = [(k, v) for k, v in summary.items() if k[0].startswith(prefix)]
         return max(c, key=lambda kv: kv[1][2]) if c else None
