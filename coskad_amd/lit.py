@@ -82,7 +82,7 @@ class LitEncoder(nn.Module):
         self.model.eval()
         with torch.no_grad():
             for batch in train_loader():
-                z = self.model(batch[0].to(dev))
+                z = self.model(batch[0].to(dev).contiguous())
                 if self.hyperbolic:
                     ops.poincare_head(z, None, need_grad=False, acc=acc)
                 elif maha:                                  # centre sums + second moments in one pass
@@ -114,7 +114,7 @@ class LitEncoder(nn.Module):
     # ---- one optimisation step -----------------------------------------------------------
     def training_step(self, batch, batch_idx: int) -> torch.Tensor:
         dev = self.model.c.device
-        stats = self._engine.step(batch[0].to(dev, non_blocking=True))
+        stats = self._engine.step(batch[0].to(dev, non_blocking=True).contiguous())
         if batch_idx % 20 == 0:                           # log_every_n_steps=20 (train_COSKAD.py:76)
             reg = self._engine.reg_loss()
             name = "poincare_loss" if self.hyperbolic else "hypersphere_loss"
@@ -158,7 +158,7 @@ class LitEncoder(nn.Module):
     def validation_step(self, batch, batch_idx: int = 0):
         dev = next(self.model.parameters()).device
         with torch.no_grad():
-            return self.forward([batch[0].to(dev), batch[1], batch[2], batch[3]])
+            return self.forward([batch[0].to(dev).contiguous(), batch[1], batch[2], batch[3]])
 
     predict_step = validation_step
 
@@ -409,6 +409,9 @@ class Trainer:
                         model._engine.set_lr(lr)
                         bad = 0
                 self._checkpoint(model, epoch, auc)
+            elif "loss" in rec:
+                # no validation: ModelCheckpoint(monitor='loss', mode='min') (train_COSKAD.py:70-73)
+                self._checkpoint(model, epoch, rec["loss"], monitor="loss", mode="min")
             self.history.append(rec)
 
     def validate(self, model: LitEncoder, loader) -> float:
@@ -424,14 +427,15 @@ class Trainer:
         model.model.eval()
         return [model.predict_step(b, i) for i, b in enumerate(loader())]
 
-    def _checkpoint(self, model: LitEncoder, epoch: int, value: float) -> None:
+    def _checkpoint(self, model: LitEncoder, epoch: int, value: float, monitor: Optional[str] = None,
+                    mode: str = "max") -> None:
         if not self.ckpt_dir or parallel.rank() != 0:
             return
         os.makedirs(self.ckpt_dir, exist_ok=True)
-        path = os.path.join(self.ckpt_dir, f"epoch={epoch}-{self.monitor}={value:.4f}.ckpt")
+        path = os.path.join(self.ckpt_dir, f"epoch={epoch}-{monitor or self.monitor}={value:.4f}.ckpt")
         save_checkpoint(model, path, epoch)
         self._best.append((value, path))
-        self._best.sort(key=lambda t: -t[0])
+        self._best.sort(key=lambda t: -t[0] if mode == "max" else t[0])
         for _, p in self._best[self.save_top_k:]:
             if os.path.exists(p):
                 os.remove(p)

@@ -38,7 +38,7 @@ def make_dataset(n_scenes=2, n_clips=3, n_persons=2, clip_len=120, T=12, V=17, n
                         trans.append(tr)
                         meta.append((sc, cl, pe, s0))
                         frames.append(np.arange(s0 + 1, s0 + T + 1))              # 1-based like the reference
-    x = torch.from_numpy(np.stack(xs).astype(np.float32))
+    x = torch.from_numpy(np.ascontiguousarray(np.stack(xs), dtype=np.float32))
     return (x, torch.tensor(trans, dtype=torch.int64), torch.tensor(meta, dtype=torch.int64),
             torch.tensor(np.stack(frames), dtype=torch.int32)), gts
 

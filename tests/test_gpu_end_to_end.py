@@ -120,3 +120,19 @@ def test_decoder_wrappers_fit_and_score(kind, tmp_path):
     else:
         assert float(lit.model.mean_vector.abs().sum()) > 0             # update_state ran (:110-116)
         assert (s_hip >= -1e-6).all() and (s_hip <= 2 + 1e-6).all()     # 1 - cos in [0, 2]
+
+
+def test_checkpoints_without_validation_monitor_loss(tmp_path):
+    """No validation loader: top-2 checkpoints on the training loss, lower is better (train_COSKAD.py:70-73)."""
+    import glob
+    from coskad_amd.lit import LitEncoder, Trainer
+    from coskad_amd.utils.synthetic import batches, make_dataset
+    train, _ = make_dataset(n_scenes=1, n_clips=2, n_persons=2, clip_len=60, num_transform=1, anomaly=False, seed=1)
+    lit = LitEncoder(make_args(validation=False)).cuda()
+    tr = Trainer(max_epochs=3, ckpt_dir=str(tmp_path))
+    tr.fit(lit, lambda: batches(train, 128, shuffle=True, seed=0), None)
+    ck = sorted(glob.glob(str(tmp_path / "*.ckpt")))
+    assert len(ck) == 2 and all("loss=" in c for c in ck)
+    kept = sorted(float(c.split("loss=")[1][:-5]) for c in ck)
+    losses = sorted(h["loss"] for h in tr.history)
+    np.testing.assert_allclose(kept, losses[:2], atol=1e-4)
