@@ -154,6 +154,7 @@ class STSETrainStep:
     def step(self, x: Tensor) -> Tensor:
         """One optimisation step on clips x [B,C,T,V]; returns the head's stats block (stats[0] = loss)."""
         self.steps += 1
+        x = x.contiguous()
         if not self.use_graph:
             return self._body(x)
         if self._graph is None or self._x_static.shape != x.shape:
