@@ -1,5 +1,5 @@
-"""Two ranks on ONE GPU (gloo carries the collectives; RCCL refuses two ranks per device): the data-parallel train
-step -- shard clips r::W, per-rank BatchNorm statistics, ONE all-reduce of the flat gradient buffer, Adam with the
+"""Two / four ranks on ONE GPU (gloo carries the collectives; RCCL refuses two ranks per device): the data-parallel train
+step -- shard clips r::W, per-rank BatchNorm statistics, the two-bucket all-reduce of the flat gradient buffer, Adam with the
 1/W scale -- must equal the oracle's two-shard computation (mean of shard gradients, torch Adam)."""
 import os
 import socket
@@ -48,8 +48,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_oracle():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_step_matches_oracle(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -81,10 +82,12 @@ def test_two_rank_step_matches_oracle():
             if k.endswith(("tcn.0.bias", "residual.0.bias")):
                 continue   # analytically zero gradient; autograd noise makes torch's Adam move them
             np.testing.assert_allclose(got[k], p.detach().numpy(), rtol=2e-3, atol=3e-4, err_msg=f"rank {r} {k}")
-    # both ranks hold identical parameters and the same all-reduced centre = mean over ALL clips
-    for k in res[0][1]:
-        if "running" not in k:
-            np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
+    # all ranks hold identical parameters and the same all-reduced centre = mean over ALL clips
+    for r in range(1, world):
+        for k in res[0][1]:
+            if "running" not in k:
+                np.testing.assert_array_equal(res[0][1][k], res[r][1][k], err_msg=k)
     zall = torch.cat(zs).mean(0)
     np.testing.assert_allclose(res[0][3], R.clamp_center(zall, 1e-3).numpy(), rtol=1e-3, atol=1e-5)
-    np.testing.assert_array_equal(res[0][3], res[1][3])
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[0][3], res[r][3])
