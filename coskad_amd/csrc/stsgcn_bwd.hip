@@ -1,21 +1,24 @@
-// Backward of one ST_GCNN_layer in training mode (reference stsgcn.py:94-116 under autograd),
-// recomputing the cheap intermediates instead of saving them.
+// Backward of one ST_GCNN_layer in training mode (reference stsgcn.py:94-116 under autograd).  Saved from the forward:
+// the layer input (pre-activation of the producer), the small stat block and -- stored-Z path -- Z = gcn(X); without
+// Z the kernels recompute the mixing (k_bwd_reduce / gcn phases below).
 //
 // Forward (per position):  Z = gcn(X),  S = Wt Z + bt,  R = Wr X + br,
 //                          U = BN_s(S) + BN_r(R),       next layer's input = PReLU(U).
 // Given dU (gradient w.r.t. the pre-activation U):
 //
-//  1. k_bwd_reduce : batch reductions  sdU = sum dU,  P = sum dU Z^T,  Q = sum dU X^T
+//  1. k_bwd_reduce(_z) : batch reductions  sdU = sum dU,  P = sum dU Z^T,  Q = sum dU X^T
 //                    (GEMMs with K = positions -> MFMA f32).  Everything BatchNorm's backward
 //                    needs is linear in these: e.g. sum dU*S = rowdot(Wt, P) + bt*sdU.
+//                    _z: X and the stored Z both in LDS, ONE pass over dU.
 //  2. k_bwd_fold   : one block.  Parameter gradients (dWt, dgamma, dbeta, ...; conv biases in
 //                    front of a train-mode BN get exactly 0) and the coefficient matrices of
 //                    the data path:
 //                        dZ      = Bt dU + Kt Z + kt          (BN_s and conv_t transposed)
 //                        dX_res  = Br dU + Kr X + kr          (BN_r and conv_r transposed)
-//  3. k_bwd_data   : dZ per position, adjoint gcn, + dX_res, then the PReLU derivative of the
+//  3. k_bwd_data(_f) : dZ per position, adjoint gcn, + dX_res, then the PReLU derivative of the
 //                    producer layer -> dU_prev; also the slope gradient of that PReLU.
-//                    Optionally stores dZ for step 4.
+//                    Stores dZ for step 4.  _f: single pass over dU (tiles of 32 rows = 1 clip of >= 32
+//                    channels or 2 clips of 16), the default wherever it applies.
 //  4. k_bwd_gcn_params : dA[t,v,w] = sum_rows Y[t,v] dZ[t,w],  dT[v,t,q] = sum_rows X[t,v] dY[q,v]
 //                    (GEMMs with K = rows (clip,channel) -> MFMA f32).
 #include "mfma_ops.h"

@@ -9,7 +9,8 @@
 // GEMMs with K = positions -> v_mfma_f32_16x16x4_f32 (exact fp32) per tile, fp64 across
 // tiles.  The layer kernel (stsgcn_fwd.hip) then runs once with the folded weights.
 //
-//   k_fwd_moments   : per-block partials of  sum x x^T, sum x, sum z z^T, sum z
+//   k_fwd_moments   : per-block partials of  sum x x^T, sum x, sum z z^T, sum z; optionally stores Z = gcn(X) for
+//                     the rest of the step (coskad_layer_train_stats_z_f32)
 //   k_reduce_partials: fp64 sum over blocks (deterministic: fixed order, no atomics)
 //   k_train_fold    : stats -> folded weights, saved stats for backward, running-stat update
 #include "mfma_ops.h"
