@@ -3,7 +3,10 @@
 
 Workload (BASELINE.json configs[1]): euclidean_encoder_dynamicCenter, synthetic clips
 B=4096 per GPU, T=12, V=17, C=2, channels 2->32->16->32->64, latent 16, fp32.
-  python bench.py --gpus N --steps K --warmup W       (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver's
+form), or, when WORLD_SIZE is unset, this script starts those N ranks itself as a child process BEFORE touching the
+GPU, forwards their output and exits with the child's code.
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.
 
 roofline  : the dominant kernel's ALGORITHMIC bytes per launch / its average duration, measured with HIP
@@ -38,7 +41,32 @@ def algorithmic_bytes_per_clip():
     return fwd, bwd
 
 
-def cpu_baseline(sample_b: int, iters: int):
+def _median_time(fn, warmup: int, iters: int) -> float:
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_b: int, fwd_b: int):
+    """SURVEY 8d protocol: 3 warm-ups, median of 10 iterations; (a) the train step (fwd + mse-to-centre + 1e-6 reg + bwd +
+    Adam) on `sample_b` clips, (b) the eval-mode forward under no_grad on `fwd_b` clips (the B = 4096 forward leg)."""
     import torch
     from oracle import ref_cpu as R
     # the GPU box gives a one-GPU job a 16-core share; os.cpu_count() reports the whole host and
@@ -61,35 +89,56 @@ def cpu_baseline(sample_b: int, iters: int):
         loss.backward()
         opt.step()
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    dt = (time.perf_counter() - t0) / iters
+    dt = _median_time(step, 3, 10)
+    xf = R.synthetic_clips(fwd_b, seed=2)
+
+    def fwd():
+        with torch.no_grad():
+            R.stse_encode(xf, st, training=False)
+
+    dtf = _median_time(fwd, 3, 10)
     return {"value": round(sample_b / dt, 1), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} train steps (fwd+loss+reg+bwd+Adam) of the CPU oracle on B={sample_b} synthetic clips"}
+            "cpu_model": _cpu_model(), "host_cores_visible": ncpu,
+            "sample": f"median of 10 train steps (fwd+loss+reg+bwd+Adam) after 3 warm-ups, CPU oracle, B={sample_b} "
+                      f"synthetic clips [B,2,12,17], default stack 2-32-16-32-64, latent 16",
+            "forward": {"value": round(fwd_b / dtf, 1), "unit": "clips/s", "ms": round(dtf * 1e3, 2),
+                        "sample": f"median of 10 eval-mode forwards (no_grad) after 3 warm-ups on B={fwd_b} clips"}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU (weak scaling)")
     ap.add_argument("--head", default="euclidean", choices=["euclidean", "poincare"])
     ap.add_argument("--graph", type=int, default=int(os.environ.get("COSKAD_GRAPH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to "
                     "rehearse the multi-rank control flow on a single GPU)")
-    ap.add_argument("--cpu-sample", type=int, default=512)
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="clips per CPU-baseline train step")
+    ap.add_argument("--cpu-fwd-sample", type=int, default=4096, help="clips per CPU-baseline forward")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one rank per GPU as a CHILD of this process, before anything here initialises the GPU
+        # (never re-exec a process that has touched the device); stdout/stderr pass through, the child's code is ours
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
     from coskad_amd import _lib
     from coskad_amd.models.sts.ae import STSE
     from coskad_amd.trainer import STSETrainStep
-    from oracle import ref_cpu as R  # synthetic inputs / initialisers only (and cpu_baseline)
+    from coskad_amd.utils.synthetic import synthetic_clips
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,13 +154,12 @@ def main():
             dist.init_process_group(args.backend)
 
     B = args.batch
-    st = R.init_stse_state(C_IN, CHANNELS, HID, LATENT, T, V, seed=0)   # same weights on every rank
-    st["c"] = torch.full((LATENT,), 0.1)
+    torch.manual_seed(0)                     # the modules' own (reference) initialisers; same weights on every rank
     model = STSE(C_IN, CHANNELS, HID, LATENT, T, V, 'sts_gcn', 'linear', 'euclidean', 0.0)
-    model.load_state_dict(st, strict=True)
+    model.c.fill_(0.1)
     model.cuda().train()
     eng = STSETrainStep(model, lr=1e-4, alpha=1e-6, head=args.head, use_graph=bool(args.graph))
-    x = R.synthetic_clips(B, C_IN, T, V, seed=100 + rank).cuda()   # each rank: its own shard of clips
+    x = synthetic_clips(B, C_IN, T, V, seed=100 + rank).cuda()   # each rank: its own shard of clips
 
     def sync():
         if world > 1:
@@ -146,6 +194,15 @@ def main():
             eng.step(x)
         sync()
         lib.coskad_probe_end(ctypes.byref(fwd_ms), ctypes.byref(fwd_n))
+    # the WHOLE layer-4 backward (every kernel that shares SURVEY 8d's layer-backward bytes: reductions, folds, data
+    # path, dA/dT), so that the dominant kernel's fraction is not read as the layer's
+    lbw_ms, lbw_n = ctypes.c_float(0), ctypes.c_int(0)
+    if probing:
+        lib.coskad_probe_begin(6, CHANNELS[-1], HID)
+        for _ in range(5):
+            eng.step(x)
+        sync()
+        lib.coskad_probe_end(ctypes.byref(lbw_ms), ctypes.byref(lbw_n))
     # forward-only (eval-mode encoder + bottleneck; SURVEY 8d's forward roofline target), outside the timed region
     model.eval()
     with torch.no_grad():
@@ -192,6 +249,14 @@ def main():
             tf = flops / (probe_ms.value * 1e-3) / 1e12
             roof["mfma_f32"] = {"achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": flops}
+        roof_lbw = None
+        if lbw_n.value:
+            byts = B * tvb * (HID + 2 * CHANNELS[-1])
+            ach = byts / (lbw_ms.value * 1e-3) / 1e9
+            roof_lbw = {"bound": "hbm", "what": "layer 4 backward, ALL its kernels (batch reductions, fp64 folds, data path, "
+                        "dA/dT) against the layer's algorithmic bytes (read dOut, read saved input, write dIn)",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes": byts, "avg_us": round(lbw_ms.value * 1e3, 2), "calls": lbw_n.value}
         if fwd_n.value:
             byts = B * tvb * (CHANNELS[-1] + HID)        # layer 4 forward: read 32 channels, write 64
             ach = byts / (fwd_ms.value * 1e-3) / 1e9
@@ -217,9 +282,10 @@ def main():
                              "what": "eval-mode STSE forward (4 layer kernels + bottleneck), BN folded from running stats"},
             "roofline": roof,
             "roofline_fwd_layer4": roof_fwd,
+            "roofline_layer4_backward": roof_lbw,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 8)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_fwd_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

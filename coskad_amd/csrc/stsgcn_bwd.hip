@@ -1322,8 +1322,12 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     hipLaunchKernelGGL(k, dim3(grid_d), dim3(kBlock), lds, st, in, dU, Aw, Tw, w.coef, in_slope, dIn,    \
                        w.dz, dap, B, Ci, Co, Zg ABL_ARG);                                               \
   } while (0)
+#ifdef COSKAD_ABLATE
     static int fused_ok = -1;
     if (fused_ok < 0) { const char* e = getenv("COSKAD_BWD_UNFUSED"); fused_ok = (e && e[0] == '1') ? 0 : 1; }
+#else
+    constexpr int fused_ok = 1;
+#endif
     constexpr bool strips_fit = (Geo<T, V>::TV + 31) / 32 <= kBlock / 64;
     // single-read variant: tiles of 32 rows = one clip of >= 32 channels, or two clips of exactly 16
     const bool two_clip = Ci == 16;            // NB was kept at 2 above
@@ -1420,6 +1424,7 @@ int coskad_layer_bwd_f32(const float* in, const float* dU, const float* A, const
   if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd: residual grads missing");
   if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_bwd: identity residual needs Ci == Co");
   if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd: B=%d Ci=%d Co=%d", B, Ci, Co);
+  ProbeScope layer_probe(KID_LAYER_BWD, Ci, Co, stream);   // bench.py: the whole layer backward (all its launches)
 #define CALL(T_, V_)                                                                                       \
   return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
                                   dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
@@ -1440,6 +1445,7 @@ int coskad_layer_bwd_z_f32(const float* in, const float* dU, const float* A, con
   if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd: residual grads missing");
   if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_bwd: identity residual needs Ci == Co");
   if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd: B=%d Ci=%d Co=%d", B, Ci, Co);
+  ProbeScope layer_probe(KID_LAYER_BWD, Ci, Co, stream);   // bench.py: the whole layer backward (all its launches)
 #define CALL(T_, V_)                                                                                       \
   return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
                                   dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \

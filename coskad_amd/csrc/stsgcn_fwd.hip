@@ -211,12 +211,16 @@ int launch_layer_apply_m(const float* in, float* out, const float* Aw, const flo
                          int Co, hipStream_t st, const float* Zg);  // stsgcn_fwd_mfma.hip
 
 static int use_mfma() {
+#ifdef COSKAD_ABLATE   // A/B builds only: the product library always takes the MFMA kernel when the tile fits LDS
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("COSKAD_VALU_FWD");
     v = (e && e[0] == '1') ? 0 : 1;
   }
   return v;
+#else
+  return 1;
+#endif
 }
 
 template <int T, int V>

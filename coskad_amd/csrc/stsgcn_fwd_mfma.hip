@@ -14,6 +14,9 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply_m(
     const float* __restrict__ in_slope, const float* __restrict__ out_slope, int B, int Ci, int Co,
     int CoP, int NB, int dbg, const float* __restrict__ Zg) {
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
+#ifndef COSKAD_ABLATE
+  dbg = 0;   // product build: every `dbg &` test below folds away (phase ablation needs -DCOSKAD_ABLATE)
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int KZ = round_up(Ci, 4);
   float* img = lds;
@@ -215,8 +218,12 @@ int launch_layer_apply_m(const float* in, float* out, const float* Aw, const flo
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, out, Aw, Tw, wfold, bias, in_slope,   \
                        out_slope, B, Ci, Co, CoP, NB, dbg, Zg);                                     \
   } while (0)
+#ifdef COSKAD_ABLATE   // phase-ablation builds only (tools/ablate_bwd.py): the product library has no runtime switches
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("COSKAD_DBG"); dbg = e ? atoi(e) : 0; }
+#else
+  constexpr int dbg = 0;
+#endif
   ProbeScope probe(KID_LAYER_APPLY, Ci, Co, st);
   if (CoP == 16) LAUNCH_OTI(1);
   else if (CoP == 32) LAUNCH_OTI(2);

@@ -154,8 +154,8 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
 
 
 # training forward keeps Z = gcn(X) of every layer (82 channels x 816 B per clip) instead of recomputing the mixing in the
-# apply and backward kernels; COSKAD_STORE_Z=0 selects the recompute path
-STORE_Z = os.environ.get("COSKAD_STORE_Z", "1") != "0"
+# apply and backward kernels.  A module constant, not an environment switch: tests flip it to cover the recompute path.
+STORE_Z = True
 
 
 class SideStream:

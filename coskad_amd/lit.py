@@ -190,6 +190,16 @@ class LitEncoder(nn.Module):
                 out[(sc, cl)] = np.load(os.path.join(self.args.gt_path, fn))
         return out
 
+    def _load_hr_masks(self) -> Optional[Dict[Tuple[int, int], np.ndarray]]:
+        """Human-related frame subsets (eval_COSKAD.py:86-97, utils/model_utils.py:149-161): `use_hr: True` +
+        `hr_mask_path` (a glob of `<scene>_<clip>.npy` boolean masks; the reference hard-codes its own disk path), or
+        masks assigned to `self.hr_masks`."""
+        if getattr(self, "hr_masks", None) is not None:
+            return self.hr_masks
+        if getattr(self.args, "use_hr", False) and getattr(self.args, "hr_mask_path", None):
+            return eval_utils.hr_masks_from_dir(self.args.hr_mask_path)
+        return None
+
     def post_processing(self, hidden_out, trans, meta, frames) -> float:
         return self._score_windows(self.window_scores(hidden_out), trans, meta, frames)
 
@@ -198,7 +208,9 @@ class LitEncoder(nn.Module):
         num_transform = max(1, int(getattr(self.args, "dataset_num_transform", 1)))
         auc, per_t, gt = eval_utils.score_dataset(scores, trans, meta, frames, self._load_gts(), num_transform,
                                                   smoothing=int(getattr(self.args, "smoothing", 50)),
-                                                  dataname=getattr(self.args, "dataset_choice", "UBnormal"))
+                                                  dataname=getattr(self.args, "dataset_choice", "UBnormal"),
+                                                  pad_size=int(getattr(self.args, "pad_size", -1)),
+                                                  hr_masks=self._load_hr_masks())
         self.log("validation_auc", auc)
         self.last_scores = per_t
         return auc
@@ -238,11 +250,7 @@ class _AutogradLit(LitEncoder):
     def _optimise(self, loss: torch.Tensor) -> None:
         self._opt.zero_grad(set_to_none=True)
         loss.backward()
-        w = parallel.world_size()
-        if w > 1:
-            for p in self.model.parameters():
-                if p.grad is not None:
-                    parallel.allreduce_mean_(p.grad)
+        parallel.allreduce_grads_mean_(list(self.model.parameters()))     # one flat bucket per step
         self._opt.step()
 
     def validation_step(self, batch, batch_idx: int = 0):
@@ -260,6 +268,12 @@ class _AutogradLit(LitEncoder):
         pass
 
     training_epoch_end = on_train_epoch_end
+
+    def configure_optimizers(self) -> Dict:
+        """euclidean_autoencoder.py:137-150 / spherical_vae.py:143-156: ReduceLROnPlateau with patience 2."""
+        cfg = super().configure_optimizers()
+        cfg["lr_scheduler"]["patience"] = 2
+        return cfg
 
 
 class LitAutoEncoder(_AutogradLit):
@@ -306,9 +320,14 @@ class LitAutoEncoder(_AutogradLit):
             self.log("hypersphere_loss", loss_h.detach()); self.log("regularization", loss_reg.detach())
         return loss.detach()
 
+    # score type: the wrapper's own validation calls windows_based_loss_rec_and_hy with its default 'rec'
+    # (euclidean_autoencoder.py:197); eval_COSKAD.py derives 'hyp' from its rec_loss_weight = 0 (:58-66) and sets it here
+    score_type = 'rec'
+    rec_loss_weight = 0.2
+
     def window_scores_from_batch(self, x: torch.Tensor) -> torch.Tensor:
-        _, x_rec = self.model(x)
-        return ((x_rec - x) ** 2).reshape(x.shape[0], -1).mean(-1)
+        z, x_rec = self.model(x)
+        return eval_utils.rec_and_hy_window_scores(x, x_rec, z, self.model.c, self.rec_loss_weight, self.score_type)
 
 
 class LitVAE(_AutogradLit):
@@ -388,6 +407,8 @@ class Trainer:
         self._best: List[Tuple[float, str]] = []
 
     def fit(self, model: LitEncoder, train_loader, val_loader=None) -> None:
+        # DDP wrap semantics (train_COSKAD.py:75-78): every rank starts from rank 0's parameters and buffers
+        parallel.broadcast_module_(model.model)
         model.setup("fit", train_loader)
         sched = model.configure_optimizers()["lr_scheduler"]
         best, bad, lr = -float("inf"), 0, model.learning_rate
@@ -417,8 +438,13 @@ class Trainer:
     def validate(self, model: LitEncoder, loader) -> float:
         model.model.eval()
         outs = [model.validation_step(b, i) for i, b in enumerate(loader())]
-        outs = [(parallel.gather_rows(o[0]), parallel.gather_rows(o[1].to(o[0].device)),
-                 parallel.gather_rows(o[2].to(o[0].device)), parallel.gather_rows(o[3].to(o[0].device))) for o in outs]
+        if parallel.world_size() > 1:
+            # shards are wrap-padded to equal length (same number of collectives on every rank): gather, then drop the
+            # duplicated windows -- a window is identified by (transformation, scene, clip, person, start)
+            cat = [torch.cat([o[i].to(outs[0][0].device) for o in outs], 0) for i in range(4)]
+            cat = [parallel.gather_rows(t) for t in cat]
+            keep = parallel.dedupe_rows(torch.cat([cat[1].long().reshape(-1, 1), cat[2].long()], 1))
+            outs = [tuple(t[keep] for t in cat)]
         return model.validation_epoch_end(outs)
 
     def predict(self, model: LitEncoder, loader, ckpt_path: Optional[str] = None):

@@ -43,6 +43,25 @@ def allreduce_mean_(flat_grad: Tensor, group=None) -> Tensor:
     return flat_grad
 
 
+def allreduce_grads_mean_(params, group=None) -> None:
+    """Mean over ranks of the `.grad` of every parameter as ONE flat bucket (one collective per step instead of one
+    per parameter tensor: the model is ~1 MB, the cost is latency)."""
+    w = world_size(group)
+    if w == 1:
+        return
+    gs = [p.grad for p in params if p.grad is not None]
+    if not gs:
+        return
+    flat = torch.cat([g.reshape(-1) for g in gs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(w)
+    off = 0
+    for g in gs:
+        k = g.numel()
+        g.copy_(flat[off:off + k].view(g.shape))
+        off += k
+
+
 def allreduce_sum_(stats: Tensor, group=None) -> Tensor:
     """In-place sum over ranks of additive statistics (centre sums / counts, gyromidpoint sums)."""
     if world_size(group) > 1:
@@ -56,6 +75,38 @@ def broadcast_(t: Tensor, src: int = 0, group=None) -> Tensor:
     return t
 
 
+def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Rank `src`'s parameters and buffers to every rank -- what Lightning's DDP wrap does before the first step
+    (train_COSKAD.py:75-78): without it every process would start from its own random initialisation and only the
+    gradients would be shared.  Floating-point tensors travel as ONE flat buffer, integer buffers
+    (`num_batches_tracked`) as another."""
+    if world_size(group) == 1:
+        return
+    with torch.no_grad():
+        ts = [p for p in module.parameters()] + [b for b in module.buffers()]
+        for is_float in (True, False):
+            sel = [t for t in ts if t.is_floating_point() == is_float and t.numel() > 0]
+            if not sel:
+                continue
+            dt = torch.float32 if is_float else torch.int64
+            flat = torch.cat([t.detach().reshape(-1).to(dt) for t in sel])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in sel:
+                k = t.numel()
+                t.copy_(flat[off:off + k].view(t.shape).to(t.dtype))
+                off += k
+
+
+def dedupe_rows(keys: Tensor):
+    """Indices of the first occurrence of every distinct row of `keys` [N, K] (int64), in first-occurrence order:
+    removes the wrap-padding duplicates that equal-length validation shards carry after a gather."""
+    uniq, inv = torch.unique(keys, dim=0, return_inverse=True)
+    first = torch.full((uniq.shape[0],), keys.shape[0], dtype=torch.int64, device=keys.device)
+    first = first.scatter_reduce(0, inv, torch.arange(keys.shape[0], device=keys.device), reduce="amin", include_self=True)
+    return torch.sort(first).values
+
+
 def gather_rows(t: Tensor, group=None) -> Tensor:
     """all_gather of per-rank row blocks [N_r, ...] -> [sum N_r, ...] in rank order (validation: latents + metadata
     to score on every rank).  Ranks may hold different row counts (an r::W split of the last batch): blocks are
@@ -63,6 +114,14 @@ def gather_rows(t: Tensor, group=None) -> Tensor:
     w = world_size(group)
     if w == 1:
         return t
+    home = t.device
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        t = t.cpu()                      # gloo's all_gather takes host tensors only (single-GPU rehearsals of the N-rank flow)
+    out = _gather_rows(t, w, group)
+    return out.to(home)
+
+
+def _gather_rows(t: Tensor, w: int, group=None) -> Tensor:
     n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
     counts = [torch.empty_like(n) for _ in range(w)]
     dist.all_gather(counts, n, group=group)

@@ -99,7 +99,7 @@ class STSETrainStep:
             self.grads.append({k: self.fp.gviews[n] for k, n in g.items() if n in self.fp.gviews})
         # optional: dA / dT on a second stream beside the next layer's reductions.  Measured SLOWER on MI355X (2.43 vs
         # 2.28 ms/step: the two LDS-heavy persistent kernels halve each other's occupancy), so it is off by default.
-        self.side = engine.SideStream() if (side_stream or os.environ.get("COSKAD_SIDE_STREAM", "0") == "1") else None
+        self.side = engine.SideStream() if side_stream else None
         # gradient buckets for the data-parallel all-reduce: [encoder | bottleneck]; the bottleneck parameters are the
         # tail of the flat buffer (named_parameters order) and their gradients are final before the encoder backward
         names = self.fp.names
@@ -192,7 +192,9 @@ class STSETrainStep:
         """c <- statistics accumulated since the last refresh (all-reduced over ranks), then reset them."""
         parallel.allreduce_sum_(self.center_acc, self.pg)
         L = self.model.latent_dim
-        c = ops.center_finalize(self.center_acc, eps, L) if self.head == 'euclidean' else ops.midpoint_finalize(self.center_acc, L)
+        # Euclidean and Mahalanobis heads accumulate plain sums (mean centre); only the Poincare head's sums are the
+        # gyromidpoint's
+        c = ops.center_finalize(self.center_acc, eps, L) if self.head != 'poincare' else ops.midpoint_finalize(self.center_acc, L)
         self.model.c.copy_(c)
         self.center_acc.zero_()
         return self.model.c
@@ -243,11 +245,7 @@ class AutogradTrainStep:
             for p in self.reg_params:
                 if p.grad is not None:
                     p.grad.add_(p, alpha=coef)
-            if self.world > 1:
-                for _, p in self.params:
-                    if p.grad is not None:
-                        dist.all_reduce(p.grad, group=self.pg)
-                        p.grad.div_(self.world)
+            parallel.allreduce_grads_mean_([p for _, p in self.params], self.pg)   # one flat bucket
         self.opt.step()
         return stats
 

@@ -225,7 +225,8 @@ class DeviceWindows:
 
 class DeviceLoader:
     """Batches `[x (device), trans_idx, meta, frames]` like the reference's DataLoader over PoseDatasetRobust; rank r of
-    W takes items r::W of the (optionally shuffled) index list, as DistributedSampler does under Lightning DDP."""
+    W takes items r, r+W, ... of the (optionally shuffled) index list with the tail wrap-padded to ceil(n / W) items per
+    rank, as DistributedSampler does under Lightning DDP: every rank runs the same number of batches (and collectives)."""
 
     def __init__(self, windows: DeviceWindows, batch_size: int, shuffle: bool = False, seed: int = 0, rank: int = 0,
                  world: int = 1) -> None:
@@ -233,7 +234,7 @@ class DeviceLoader:
         self.epoch = 0
 
     def __len__(self) -> int:
-        n = len(range(self.rank, len(self.w.ds), self.world))
+        n = (len(self.w.ds) + self.world - 1) // self.world
         return (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self) -> Iterator[List[torch.Tensor]]:
@@ -243,7 +244,8 @@ class DeviceLoader:
             self.epoch += 1
         else:
             idx = torch.arange(n)
-        idx = idx[self.rank::self.world]
+        from ..parallel import shard_indices
+        idx = idx[shard_indices(n, self.rank, self.world)]
         for i in range(0, idx.numel(), self.batch_size):
             j = idx[i:i + self.batch_size]
             s = j % self.w.N

@@ -43,12 +43,24 @@ def make_dataset(n_scenes=2, n_clips=3, n_persons=2, clip_len=120, T=12, V=17, n
             torch.tensor(np.stack(frames), dtype=torch.int32)), gts
 
 
-def batches(data, batch_size, shuffle=False, seed=0, rank=0, world=1):
-    """Minimal DataLoader: yields [x, trans, meta, frames]; shards r::W like DistributedSampler."""
+def batches(data, batch_size, shuffle=False, seed=0, rank=0, world=1, epoch=0):
+    """Minimal DataLoader: yields [x, trans, meta, frames].  Sharding has DistributedSampler semantics: rank r takes
+    items r, r+W, ... of the (per-epoch reshuffled: seed + epoch) index list, the tail wrap-padded so that EVERY rank
+    gets ceil(n / W) items and therefore issues the same number of collectives per epoch."""
+    from ..parallel import shard_indices
     x, trans, meta, frames = data
     n = x.shape[0]
-    idx = torch.randperm(n, generator=torch.Generator().manual_seed(seed)) if shuffle else torch.arange(n)
-    idx = idx[rank::world]
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(seed + epoch)) if shuffle else torch.arange(n)
+    idx = idx[shard_indices(n, rank, world)]
     for i in range(0, idx.numel(), batch_size):
         j = idx[i:i + batch_size]
         yield [x[j], trans[j], meta[j], frames[j]]
+
+
+def synthetic_clips(B: int, C: int = 2, T: int = 12, V: int = 17, seed: int = 0) -> torch.Tensor:
+    """SURVEY 8d benchmark input: 0.5 * N(0,1) clipped to +-3 (RobustScaler-ed, bbox-centred poses are O(1)) with 2 %
+    exact zeros marking missing joints."""
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, C, T, V, generator=g) * 0.5).clamp(-3, 3)
+    mask = torch.rand(B, 1, T, V, generator=g) < 0.02
+    return torch.where(mask, torch.zeros(()), x).contiguous()

@@ -18,12 +18,15 @@ def main():
     args = argparse.Namespace(**yaml.load(open(parser.parse_args().config), Loader=yaml.FullLoader))
     args, dataset_args, ae_args, res_args, opt_args = init_sub_args(args)
     torch.cuda.set_device(0)
-    if args.use_vae:                                 # wrapper selection: eval_COSKAD.py:60-80
-        from coskad_amd.lit import LitVAE
-        model = LitVAE(args).cuda()
-    elif args.use_decoder:
+    if args.use_decoder:                             # wrapper selection order: eval_COSKAD.py:55-83
         from coskad_amd.lit import LitAutoEncoder
         model = LitAutoEncoder(args).cuda()
+        from coskad_amd.utils.eval_utils import eval_loss_type
+        model.rec_loss_weight = 0                      # eval_COSKAD.py:58-66: the script's constant selects 'hyp'
+        model.score_type = eval_loss_type(model.rec_loss_weight)
+    elif args.use_vae:
+        from coskad_amd.lit import LitVAE
+        model = LitVAE(args).cuda()
     else:
         model = LitEncoder(args).cuda()
     path = os.path.join(args.exp_dir, args.dataset_choice, args.dir_name, args.load_ckpt)

@@ -23,7 +23,8 @@ int coskad_abi_version(void);
 const char* coskad_last_error(void);
 
 /* Timing probe for benchmarks: after coskad_probe_begin(kernel, Ci, Co) every launch of that tile kernel
- * (1 = layer_apply, 2 = bwd_data, 3 = bwd_reduce, 4 = fwd_moments) with those channel counts is bracketed by
+ * (1 = layer_apply, 2 = bwd_data, 3 = bwd_reduce, 4 = fwd_moments, 5 = gcn_params; 6 = ALL launches of one
+ * coskad_layer_bwd*_f32 call together; 7 = the fused eval-mode encoder kernel) with those channel counts is bracketed by
  * HIP events on its launch stream; coskad_probe_end() waits for them and returns the average duration. */
 int coskad_probe_begin(int kernel, int Ci, int Co);
 int coskad_probe_end(float* avg_ms, int* launches);

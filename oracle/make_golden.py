@@ -12,6 +12,8 @@ What is pinned:
                     parameter gradients, BN running stats after one step.
   stse_v25.npz      same on a small V=25 stack.
   stsae_small.npz   models/sts/ae.py::STSAE (decoder path), eval + train + grads.
+  stsae_v25.npz     STSAE at the DEFAULT widths (channels 32-16-32, hidden 64, latent 8) on the 25-joint layout
+                    (BASELINE config 4's model shape): eval + train + grads.
   hyper_math.npz    utils/hyper_math.py expmap0/project/mobius_add/dist/dist0/
                     logmap0/poincare_mean + autograd of the Poincare loss.
 """
@@ -178,8 +180,12 @@ def hyper_case(name, seed=11):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "v25":       # only the round-2 fixture (the others are unchanged)
+        stsae_case("stsae_v25.npz", 3, dict(input_dim=2, channels=[32, 16, 32], hidden=64, latent=8, V=25), seed=50)
+        sys.exit(0)
     stse_case("stse_default.npz", 8, dict(input_dim=2, channels=[32, 16, 32], hidden=64, latent=16, V=17), seed=0)
     stse_case("stse_v25.npz", 4, dict(input_dim=2, channels=[8, 4, 8], hidden=8, latent=8, V=25), seed=20)
     stse_case("stse_b1.npz", 1, dict(input_dim=2, channels=[4, 4, 8], hidden=4, latent=4, V=17), seed=30)
     stsae_case("stsae_small.npz", 4, dict(input_dim=2, channels=[16, 8, 16], hidden=16, latent=8, V=17), seed=40)
+    stsae_case("stsae_v25.npz", 3, dict(input_dim=2, channels=[32, 16, 32], hidden=64, latent=8, V=25), seed=50)
     hyper_case("hyper_math.npz")

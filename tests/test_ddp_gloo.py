@@ -84,3 +84,46 @@ def test_shard_indices_cover_and_pad():
     assert len(a) == len(b) == len(c) == 4
     assert sorted(set(torch.cat([a, b, c]).tolist())) == list(range(10))
     assert a.tolist() == [0, 3, 6, 9] and b.tolist() == [1, 4, 7, 0]
+
+
+def _worker_bcast(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coskad_amd import parallel
+    from coskad_amd.utils.synthetic import batches, make_dataset
+    torch.manual_seed(100 + rank)                      # every rank: its own random initialisation
+    m = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 1), torch.nn.BatchNorm2d(4), torch.nn.PReLU())
+    m[1].num_batches_tracked.fill_(7 + rank)
+    parallel.broadcast_module_(m)
+    flat = torch.cat([t.detach().reshape(-1).double() for t in list(m.parameters()) + list(m.buffers())])
+    # equal-length shards: n % (W * bs) == 1 used to give rank 0 one more batch than rank 1 (mismatched collectives)
+    data, _ = make_dataset(n_scenes=1, n_clips=1, n_persons=1, clip_len=12 + 16, anomaly=False, seed=0)   # 17 windows
+    n = data[0].shape[0]
+    nb = sum(1 for _ in batches(data, 4, rank=rank, world=world))
+    outs = list(batches(data, 4, rank=rank, world=world))
+    cat = [torch.cat([o[i] for o in outs], 0) for i in range(4)]
+    cat = [parallel.gather_rows(t) for t in cat]
+    keep = parallel.dedupe_rows(torch.cat([cat[1].long().reshape(-1, 1), cat[2].long()], 1))
+    q.put((rank, flat.numpy(), n, nb, cat[2][keep][:, 3].tolist(), int(cat[0].shape[0])))
+    dist.destroy_process_group()
+
+
+def test_module_broadcast_and_equal_shards():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bcast, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])          # rank 1 now holds rank 0's parameters and buffers
+    torch.manual_seed(100)
+    m0 = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 1), torch.nn.BatchNorm2d(4), torch.nn.PReLU())
+    np.testing.assert_array_equal(res[0][1][:8], m0[0].weight.detach().reshape(-1).double().numpy())
+    n = res[0][2]
+    assert n == 17 and res[0][3] == res[1][3] == 3                # ceil(ceil(17/2)/4) batches on BOTH ranks
+    for r in res:
+        assert r[5] == 18 and sorted(r[4]) == list(range(17))     # 18 gathered rows, 17 distinct windows after the dedupe

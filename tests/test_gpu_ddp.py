@@ -91,3 +91,62 @@ def test_multi_rank_step_matches_oracle(world):
     np.testing.assert_allclose(res[0][3], R.clamp_center(zall, 1e-3).numpy(), rtol=1e-3, atol=1e-5)
     for r in range(1, world):
         np.testing.assert_array_equal(res[0][3], res[r][3])
+
+
+def _worker_unsynced(rank, world, port, q, backend):
+    """Every rank builds its model from its OWN random initialisation (no shared load_state_dict): the broadcast that
+    Trainer.fit performs (Lightning's DDP wrap, train_COSKAD.py:75-78) must make the replicas identical, and one
+    data-parallel step must keep them identical."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coskad_amd import parallel
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import STSETrainStep
+    torch.manual_seed(1000 + rank)
+    m = STSE(2, list(CFG["layer_channels"]), CFG["hidden"], CFG["latent"], 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0).cuda()
+    before = float(m.btlnk.weight.detach().abs().sum())
+    parallel.broadcast_module_(m)
+    m.train()
+    eng = STSETrainStep(m, lr=1e-3, alpha=1e-6, head='euclidean')
+    x = R.synthetic_clips(48, seed=9)
+    eng.step(x[parallel.shard_indices(48, rank, world)].cuda())
+    eng.refresh_center(eps=1e-3)
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if v.is_floating_point()}
+    q.put((rank, sd, before, dist.get_world_size(), dist.get_backend()))
+    dist.barrier(device_ids=[dev]) if backend == "nccl" else dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_unsynced(world, backend):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_unsynced, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(r[3] == world and r[4] == backend for r in res)
+    assert res[0][2] != res[1][2]                       # the ranks really started from different weights
+    for r in range(1, world):
+        for k, v in res[0][1].items():
+            if "running" not in k:                      # BatchNorm running statistics stay per rank (no SyncBN)
+                np.testing.assert_array_equal(v, res[r][1][k], err_msg=k)
+
+
+def test_unsynced_init_is_broadcast_gloo():
+    _run_unsynced(2, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (>= 2 GPUs)")
+def test_two_rank_step_rccl():
+    """The same check over RCCL (backend 'nccl'), one rank per GPU."""
+    _run_unsynced(2, "nccl")

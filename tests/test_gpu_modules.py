@@ -60,9 +60,12 @@ def test_legacy_keywords(golden):
         STSE(c_in=2, h_dim=64, latent_dim=16, n_frames=12, dropout=0.0, n_joints=17, channels=[32, 16, 32], encoder_type='nope')
 
 
-def test_stsae(golden):
+@pytest.mark.parametrize("name", ["stsae_small.npz", "stsae_v25.npz"])
+def test_stsae(golden, name):
+    """stsae_v25: the DEFAULT widths (32-16-32, hidden 64, latent 8) on the 25-joint layout = BASELINE config 4's model
+    shape (different LDS budgets and kernel dispatch than V = 17), encoder + decoder, eval + train + every gradient."""
     from coskad_amd.models.sts.ae import STSAE
-    g = golden("stsae_small.npz")
+    g = golden(name)
     m, st = build_stse(g, cls=STSAE)
     x = torch.from_numpy(g["x"]).cuda()
     m.eval()
@@ -284,3 +287,38 @@ def test_eval_fold_cache_tracks_weight_changes(golden):
         np.testing.assert_allclose(m(x).cpu().numpy(), z0.cpu().numpy(), rtol=1e-5, atol=1e-6)
         layer.tcn[0].weight.data.copy_(layer.tcn[0].weight.data * 1.0)      # version bump, same values
         assert torch.equal(m(x), m(x))
+
+
+def test_stsvae_v25_default_width_vs_reference_golden(golden):
+    """BASELINE config 4's model (spherical VAE, 25 joints, default widths 32-16-32 / 64, latent 8): encoder, mean head
+    and decoder pinned by the REFERENCE's STSAE outputs on the same weights -- with the `linear` projector the VAE's
+    `fc_mean` is the autoencoder's bottleneck (vae.py:147-150) and its decoder is the autoencoder's (vae.py:93-132) --
+    then one stochastic training step through the whole wrapper loss."""
+    from coskad_amd.models.sts.vae import STSVAE, kl_ps_uniform
+    g = golden("stsae_v25.npz")
+    st = state_from(g)
+    m = STSVAE(2, [32, 16, 32], 64, 8, 12, 25, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='ps')
+    own = m.state_dict()
+    for k, v in st.items():
+        if k.startswith(("encoder.", "decoder.", "rev_btlnk.")):
+            assert own[k].shape == v.shape, k
+            own[k] = v
+    own["fc_mean.weight"], own["fc_mean.bias"] = st["btlnk.weight"], st["btlnk.bias"]
+    m.load_state_dict(own, strict=True)
+    m.cuda().eval()
+    x = torch.from_numpy(g["x"]).cuda()
+    with torch.no_grad():
+        zm, zv = m.encode(x)
+        zref = torch.from_numpy(g["eval.z"]).cuda()
+        np.testing.assert_allclose(zm.cpu().numpy(), (zref / zref.norm(dim=-1, keepdim=True)).cpu().numpy(), rtol=1e-4, atol=1e-4)
+        assert bool((zv >= 1).all())                                                  # softplus + 1 (vae.py:85)
+        xr = m.decode(zref, (x.shape[0], 64, 12, 25, 1))
+        np.testing.assert_allclose(xr.cpu().numpy(), g["eval.xrec"], rtol=1e-4, atol=1e-4)
+    m.train()
+    torch.manual_seed(0)
+    z, xr, (q, p, kappa) = m(x)
+    assert xr.shape == x.shape
+    np.testing.assert_allclose(z.norm(dim=-1).detach().cpu().numpy(), 1.0, atol=1e-4)
+    loss = ((xr - x) ** 2).mean() + kl_ps_uniform(q, p).mean() + (1 / kappa).mean()    # spherical_vae.py:81-107
+    loss.backward()
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in m.parameters())

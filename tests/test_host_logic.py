@@ -146,3 +146,13 @@ def test_static_gcn_adjacency_matches_reference_buffer():
     enc = EncoderStaticPlainGCN(2, [8, 4], 8, 12, 17, 0.0)
     np.testing.assert_array_equal(enc.Adj.numpy(), g["static_gcn.sd.encoder.Adj"])
     np.testing.assert_allclose(enc.Adj.sum(1).numpy(), 1.0, rtol=1e-6)
+
+
+def test_legacy_wrapper_import_names():
+    """The reference's Lightning wrappers import their models under package names that are absent from the snapshot
+    (models/euclidean_encoder_staticCenter.py:19, spherical_vae.py:16, euclidean_autoencoder.py:18)."""
+    from coskad_amd.models.sts import ae, vae
+    from coskad_amd.models.stsae.stsae_hidden_hypersphere import STSAE
+    from coskad_amd.models.stse.stse_hidden_hypersphere import STSE
+    from coskad_amd.models.stsve.stsve_hidden_hypersphere import STSVE
+    assert STSE is ae.STSE and STSAE is ae.STSAE and STSVE is vae.STSVAE

@@ -68,19 +68,20 @@ def test_stse_poincare_head(golden):
     np.testing.assert_allclose(R.weighted_midpoint(t(g["hyp.zh"])).numpy(), g["hyp.center"], rtol=1e-3, atol=2e-5)
 
 
-def test_stsae(golden):
-    g = golden("stsae_small.npz")
+@pytest.mark.parametrize("name,hid,V", [("stsae_small.npz", 16, 17), ("stsae_v25.npz", 64, 25)])
+def test_stsae(golden, name, hid, V):
+    g = golden(name)
     st = state_from(g)
     x = t(g["x"])
     with torch.no_grad():
         z = R.stse_encode(x, st, training=False)
-        xr = R.stsae_decode(z, st, 16, 12, 17, training=False)
+        xr = R.stsae_decode(z, st, hid, 12, V, training=False)
     np.testing.assert_allclose(z.numpy(), g["eval.z"], **TOL)
     np.testing.assert_allclose(xr.numpy(), g["eval.xrec"], **TOL)
     params = {k: v.requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
     st.update(params)
     z = R.stse_encode(x, st, training=True)
-    xr = R.stsae_decode(z, st, 16, 12, 17, training=True)
+    xr = R.stsae_decode(z, st, hid, 12, V, training=True)
     np.testing.assert_allclose(z.detach().numpy(), g["train.z"], **TOL)
     np.testing.assert_allclose(xr.detach().numpy(), g["train.xrec"], rtol=1e-4, atol=1e-5)
     loss = ((xr - x) ** 2).mean() + R.mse_to_center(z, t(g["c"]))

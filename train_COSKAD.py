@@ -4,8 +4,10 @@
   python train_COSKAD.py --config config/synthetic/euclidean_encoder.yaml
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_COSKAD.py --config ...
 
-`data_dir: synthetic` uses coskad_amd.utils.synthetic (no datasets are reachable from this environment); the
-Morais-CSV data pipeline of the reference (utils/dataset.py) is the next scope row."""
+`data_dir: synthetic` uses coskad_amd.utils.synthetic (no datasets are reachable from this environment); any other
+`data_dir` goes through the Morais-CSV pipeline of coskad_amd.utils.dataset (reference utils/dataset.py).
+Multi-rank runs: every rank seeds torch with `seed`, rank 0's parameters and buffers are broadcast before the first
+step (Trainer.fit), shards are wrap-padded to equal length (DistributedSampler semantics)."""
 import argparse
 import os
 import shutil
@@ -27,18 +29,20 @@ def main():
     args, dataset_args, ae_args, res_args, opt_args = init_sub_args(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     if world > 1:
-        dist.init_process_group("nccl")
+        # "nccl" = RCCL on ROCm; COSKAD_DIST_BACKEND=gloo rehearses the multi-rank control flow on one GPU
+        dist.init_process_group(os.environ.get("COSKAD_DIST_BACKEND", "nccl"))
     if rank == 0:
         os.makedirs(args.ckpt_dir, exist_ok=True)
         shutil.copy(config_path, os.path.join(args.ckpt_dir, "config.yaml"))      # train_COSKAD.py:33
-    if args.use_vae:                                 # wrapper selection: train_COSKAD.py:36-55
-        from coskad_amd.lit import LitVAE
-        model = LitVAE(args).cuda()
-    elif args.use_decoder:
+    torch.manual_seed(int(args.seed))                # same initial weights on every rank (and reproducible runs)
+    if args.use_decoder:                             # wrapper selection order: train_COSKAD.py:36-55
         from coskad_amd.lit import LitAutoEncoder
         model = LitAutoEncoder(args).cuda()
+    elif args.use_vae:
+        from coskad_amd.lit import LitVAE
+        model = LitVAE(args).cuda()
     else:
         model = LitEncoder(args).cuda()              # hyperbolic / static_center switches inside
     bs = args.dataset_batch_size
@@ -49,7 +53,13 @@ def main():
         val, gts = make_dataset(n_scenes=2, n_clips=3, n_persons=3, clip_len=200, num_transform=args.dataset_num_transform,
                                 anomaly=True, seed=args.seed + 1)
         model.gts = gts
-        trainer.fit(model, lambda: batches(train, bs, shuffle=True, seed=args.seed, rank=rank, world=world),
+        epoch = [0]
+
+        def train_batches():                         # DataLoader(shuffle=True) reshuffles every epoch (the centre
+            epoch[0] += 1                            # initialisation pass of setup() consumes the first permutation)
+            return batches(train, bs, shuffle=True, seed=args.seed, rank=rank, world=world, epoch=epoch[0] - 1)
+
+        trainer.fit(model, train_batches,
                     (lambda: batches(val, bs, rank=rank, world=world)) if args.validation else None)
     else:
         # Morais-format trajectories (`dataset_path_to_robust`, train_COSKAD.py:80-85): window table resident in HBM,
