@@ -103,7 +103,7 @@ def test_device_loader_matches_items(tree):
     x = w.gather(index).cpu().numpy()
     ref = np.stack([tr[i][0] for i in range(len(tr))])
     np.testing.assert_allclose(x, ref, rtol=0, atol=1e-7)
-    # loader: every item exactly once over the ranks, metadata aligned with the data
+    # loader: every item covered over the ranks, metadata aligned with the data
     seen = []
     for rank in range(2):
         for xb, tb, mb, fb in DeviceLoader(w, 16, shuffle=True, seed=3, rank=rank, world=2):
@@ -113,7 +113,9 @@ def test_device_loader_matches_items(tree):
                 seen.append(int(tb[k]) * tr.num_samples + s)
                 np.testing.assert_allclose(xb[k].cpu().numpy(), tr[seen[-1]][0], rtol=0, atol=1e-7)
                 np.testing.assert_array_equal(fb[k].numpy(), tr.segs_ids[s])
-    assert sorted(seen) == list(range(len(tr)))
+    # DistributedSampler semantics: equal shards, the tail wrap-padded (an odd item count repeats one item)
+    assert sorted(set(seen)) == list(range(len(tr)))
+    assert len(seen) == 2 * ((len(tr) + 1) // 2)
     # out-of-range indices give zero clips instead of reading out of bounds
     bad = w.gather(torch.tensor([len(tr) + 5, -1]))
     assert float(bad.abs().max()) == 0.0
