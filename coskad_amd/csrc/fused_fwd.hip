@@ -1,0 +1,424 @@
+// Fused eval-mode STS-GCN encoder: the reference's whole `Encoder.forward` (models/common/components.py:94-105 = four
+// ST_GCNN_layer.forward, models/graph_layers/stsgcn.py:94-116, BatchNorm folded from its running statistics) in ONE
+// kernel, one clip per wavefront, every activation resident in LDS or registers.  HBM traffic per clip: the 1.6 KB clip
+// in, the activated last layer out (52 KB, tile-major, consumed by the bottleneck kernel with a permuted weight).
+//
+// Design ("fused forward"):
+//   * one wavefront owns one clip end to end: no workgroup barrier anywhere, only the wave's own LDS ordering;
+//     four waves per CU (one per SIMD, up to 512 VGPRs each), 39.6 KB of LDS per wave: R1 = 32 rows x 206, R2 = 16 rows;
+//   * everything is v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains): temporal mixing per joint, spatial mixing per
+//     frame, 1x1 convs per 16-position tile;
+//   * an accumulator tile D[channel][position] IS the B operand of the next 1x1 conv (register r = channel 4q + r on
+//     k slot q): spatial mixing -> conv -> (PReLU) -> next conv chain without touching LDS; the conv weights live in
+//     registers for the whole launch in that k order (coskad_amd/fused_plan.py builds the operand streams);
+//   * layer 2 (32 -> 16) is commuted: gcn(Wz X) = Wz gcn(X), so the mixing runs on 16 channels;
+//   * the 17th joint: spatial column 16 is a 5-FMA dot + two cross-lane adds, written back in place; its 12 positions
+//     form a 13th position tile;
+//   * layer 4 needs its input twice (mixing, residual conv) but LDS holds it once (mixed in place): the second copy
+//     stays in 104 registers per lane (x4[13][2]), which is why the tile loops of layers 3/4 are fully unrolled;
+//   * the mixing matrices stream from L2 as ready-made B operands (16-byte records per lane), prefetched one item ahead.
+//
+// tests/test_fused_plan.py replays exactly this schedule in numpy from the same operand streams.
+#include "common.h"
+
+namespace coskad {
+namespace ff {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int T = 12, V = 17, TV = T * V;
+constexpr int LD = 206;                 // row stride: = 2 (mod 4) -> (row, k) operand reads of the mixing phases are conflict-free
+constexpr int R1 = 0, R2 = 32 * LD;     // float offsets inside the wave's LDS image
+constexpr int PADCOL = TV;              // columns 204, 205 of every row are padding: masked lanes store there (no divergent branches)
+constexpr int WAVE_LDS = 48 * LD;       // floats per wave
+constexpr int NTILE = T + 1;
+#ifndef FF_TILE_FENCE
+#define FF_TILE_FENCE   // (A/B hook: -DFF_TILE_FENCE="__builtin_amdgcn_sched_barrier(0)" keeps the scheduler inside one tile)
+#endif
+constexpr int KP = NTILE * 4 * 64 * 4;  // tile-major output floats per clip (13 312)
+constexpr int TEMP_F4 = V * 64;         // float4 records of the temporal part of one layer
+constexpr int LAYER_F4 = TEMP_F4 + T * 3 * 64;
+enum { W1A = 0, W1B = 2, WP = 4, WR = 12, WX3 = 20, WZ3 = 28, WZ4 = 36, WX4 = 68, B1 = 100, B2 = 108, B3 = 112, B4 = 120, NWREG = 136 };
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float prelu(float x, float a) { return x > 0.f ? x : a * x; }
+__device__ __forceinline__ f32x4 prelu4(f32x4 v, float a) {
+  return f32x4{prelu(v[0], a), prelu(v[1], a), prelu(v[2], a), prelu(v[3], a)};
+}
+
+struct Lane {
+  int j, q;
+};
+
+// ---- temporal mixing of one joint column (stsgcn.py:154), in place --------------------------------------------------
+// rows of the image at `img`: row tile rt covers rows 16*rt .. 16*rt+15; ROWS < 16 masks the operand rows.
+template <int ROWS>
+__device__ __forceinline__ f32x4 temporal_mm(const float* img, int rt, int v, const float4& rec, const Lane& L) {
+  const float* p = img + (16 * rt + L.j) * LD + L.q * V + v;
+  float a0 = p[0], a1 = p[4 * V], a2 = p[8 * V];
+  if (ROWS < 16) {
+    const bool ok = L.j < ROWS;
+    a0 = ok ? a0 : 0.f; a1 = ok ? a1 : 0.f; a2 = ok ? a2 : 0.f;
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = mfma(a0, rec.x, acc);
+  acc = mfma(a1, rec.y, acc);
+  acc = mfma(a2, rec.z, acc);
+  return acc;
+}
+template <int ROWS>
+__device__ __forceinline__ void temporal_store(float* img, int rt, int v, const f32x4& acc, const Lane& L) {
+  float* rowp = img + (16 * rt + 4 * L.q) * LD;
+  float* p;
+  if (ROWS >= 16) {
+    p = rowp + (L.j < T ? L.j * V + v : PADCOL);      // masked lanes (columns 12..15 of the tile): the rows' padding column
+    p[0] = acc[0]; p[LD] = acc[1]; p[2 * LD] = acc[2]; p[3 * LD] = acc[3];
+  } else {
+    p = rowp + ((L.j < T && L.q == 0) ? L.j * V + v : PADCOL);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < ROWS) p[r * LD] = acc[r];
+  }
+}
+
+// all joints of `NRT` row tiles, two independent MFMA chains in flight; the table record of joint v+1 (v+2) is
+// fetched while joint v is multiplied
+template <int ROWS, int NRT>
+__device__ __forceinline__ void temporal_phase(float* img, const float4* __restrict__ tab, const Lane& L, int lane) {
+  if (NRT == 2) {
+    float4 rec = tab[lane];
+#pragma unroll 1
+    for (int v = 0; v < V; ++v) {
+      const float4 nxt = tab[(v + 1 < V ? v + 1 : v) * 64 + lane];
+      const f32x4 d0 = temporal_mm<ROWS>(img, 0, v, rec, L);
+      const f32x4 d1 = temporal_mm<ROWS>(img, 1, v, rec, L);
+      temporal_store<ROWS>(img, 0, v, d0, L);
+      temporal_store<ROWS>(img, 1, v, d1, L);
+      rec = nxt;
+    }
+  } else {
+    float4 r0 = tab[lane], r1 = tab[64 + lane];
+#pragma unroll 1
+    for (int v = 0; v < V - 1; v += 2) {
+      const float4 n0 = tab[(v + 2) * 64 + lane];                       // v + 2 <= 16
+      const float4 n1 = tab[(v + 3 < V ? v + 3 : v + 2) * 64 + lane];
+      const f32x4 d0 = temporal_mm<ROWS>(img, 0, v, r0, L);
+      const f32x4 d1 = temporal_mm<ROWS>(img, 0, v + 1, r1, L);
+      temporal_store<ROWS>(img, 0, v, d0, L);
+      temporal_store<ROWS>(img, 0, v + 1, d1, L);
+      r0 = n0; r1 = n1;
+    }
+    const f32x4 d = temporal_mm<ROWS>(img, 0, V - 1, r0, L);
+    temporal_store<ROWS>(img, 0, V - 1, d, L);
+  }
+}
+
+// ---- spatial mixing of one frame (stsgcn.py:155) -> accumulator tile; joint 16 goes back to the image in place -------
+struct SpatRec {
+  float4 c0, c1, c2;   // b[0..3] | b[4], bw[0..2] | bw[3], bw[4], -, -
+};
+__device__ __forceinline__ SpatRec load_spat(const float4* __restrict__ tab, int t, int lane) {
+  const float4* p = tab + TEMP_F4 + t * 3 * 64 + lane;
+  return SpatRec{p[0], p[64], p[128]};
+}
+template <int ROWS>
+__device__ __forceinline__ f32x4 spatial_mm(float* img, int rt, int t, const SpatRec& R, const Lane& L) {
+  float* row = img + (16 * rt + L.j) * LD + t * V;
+  const float* p = row + L.q;
+  float a0 = p[0], a1 = p[4], a2 = p[8], a3 = p[12];
+  float a4 = row[16];                                   // joint 16: k slot 0 of the fifth step only
+  a4 = L.q == 0 ? a4 : 0.f;
+  if (ROWS < 16) {
+    const bool ok = L.j < ROWS;
+    a0 = ok ? a0 : 0.f; a1 = ok ? a1 : 0.f; a2 = ok ? a2 : 0.f; a3 = ok ? a3 : 0.f; a4 = ok ? a4 : 0.f;
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = mfma(a0, R.c0.x, acc);
+  acc = mfma(a1, R.c0.y, acc);
+  acc = mfma(a2, R.c0.z, acc);
+  acc = mfma(a3, R.c0.w, acc);
+  acc = mfma(a4, R.c1.x, acc);
+  float ex = a0 * R.c1.y;
+  ex = fmaf(a1, R.c1.z, ex);
+  ex = fmaf(a2, R.c1.w, ex);
+  ex = fmaf(a3, R.c2.x, ex);
+  ex = fmaf(a4, R.c2.y, ex);
+  ex += __shfl_xor(ex, 16, 64);
+  ex += __shfl_xor(ex, 32, 64);
+  float* e = img + (16 * rt + L.j) * LD + ((L.q == 0 && (ROWS >= 16 || L.j < ROWS)) ? t * V + 16 : PADCOL);
+  *e = ex;
+  return acc;
+}
+
+// ---- accumulator-layout tiles in LDS -------------------------------------------------------------------------------
+// lane (j, q), register r  <->  row row0 + 4q + r, position `pos` (lane-dependent; `ok` masks the padding columns)
+__device__ __forceinline__ void tile_store(float* img, int row0, int pos, bool ok, const f32x4& a, const Lane& L) {
+  float* p = img + (row0 + 4 * L.q) * LD + (ok ? pos : PADCOL);
+  p[0] = a[0]; p[LD] = a[1]; p[2 * LD] = a[2]; p[3 * LD] = a[3];
+}
+__device__ __forceinline__ f32x4 tile_load(const float* img, int row0, int pos, const Lane& L) {
+  const float* p = img + (row0 + 4 * L.q) * LD + pos;
+  return f32x4{p[0], p[LD], p[2 * LD], p[3 * LD]};
+}
+
+__global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restrict__ x, float* __restrict__ out,
+                                                         const float4* __restrict__ tab, const float* __restrict__ wreg,
+                                                         const float* __restrict__ slopes, int B) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* lds = lds_all + wave * WAVE_LDS;
+  // Lane geometry behind an optimisation barrier, refreshed at the start of every phase: everything address-like is
+  // then recomputed where it is used (a few VALU ops) instead of being hoisted out of the persistent clip loop and
+  // held in ~150 registers across all phases.
+  auto geo = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return Lane{l & 15, l >> 4};
+  };
+  Lane L = geo();
+  float* r1 = lds + R1;
+  float* r2 = lds + R2;
+
+  // conv weights (A operands) and bias quads: registers for the whole launch
+  float w[NWREG];
+#pragma unroll
+  for (int i = 0; i < NWREG; ++i) w[i] = wreg[i * 64 + lane];
+#define BQ(row) f32x4{w[(row)], w[(row) + 1], w[(row) + 2], w[(row) + 3]}
+  const float s1 = slopes[0], s2 = slopes[1], s3 = slopes[2], s4 = slopes[3];
+
+  const int nwaves = gridDim.x * 4;
+  int clip = blockIdx.x * 4 + wave;
+  // the clip's 408 floats: element e = lane + 64 i
+  float xin[7];
+  auto load_x = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int e = lane + 64 * i;
+      xin[i] = (c < B && e < 2 * TV) ? x[(size_t)c * (2 * TV) + e] : 0.f;
+    }
+  };
+  load_x(clip);
+
+  for (; clip < B; clip += nwaves) {
+    // ---- stage: R2 rows 0,1 = mixing copy, rows 2,3 = the copy the residual conv of layer 1 reads
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int e = lane + 64 * i;
+      const int c = e >= TV ? 1 : 0;
+      const int p = e - c * TV;
+      float* d = r2 + (e < 2 * TV ? c * LD + p : PADCOL);
+      d[0] = xin[i];
+      d[2 * LD] = xin[i];
+    }
+    load_x(clip + nwaves);      // next clip's input travels while this one is computed
+
+    // ================= layer 1 (2 -> 32) and the convs of layer 2 (32 -> 16, commuted) =================
+    L = geo();
+    temporal_phase<2, 1>(r2, tab, L, lane);
+    {
+      SpatRec rec = load_spat(tab, 0, lane);
+#pragma unroll 1
+      for (int tile = 0; tile < NTILE; ++tile) {
+        const bool fr = tile < T;                       // a frame tile (joints 0..15) or the 17th-joint tile
+        const int pos = fr ? tile * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;
+        const bool ok = fr || L.j < T;
+        const SpatRec nxt = load_spat(tab, tile + 1 < T ? tile + 1 : T - 1, lane);
+        const float xc = r2[(L.q == 1 ? 2 : 3) * LD + pos];
+        float z0, z1;
+        if (fr) {
+          const f32x4 z = spatial_mm<2>(r2, 0, tile, rec, L);
+          z0 = z[0]; z1 = z[1];
+        } else {
+          z0 = r2[pos]; z1 = r2[LD + pos];
+        }
+        const float bA = L.q == 0 ? z0 : ((L.q == 1 || L.q == 2) ? xc : 0.f);
+        const float bB = L.q == 0 ? z1 : 0.f;
+        f32x4 u0 = mfma(w[W1A], bA, BQ(B1));
+        f32x4 u1 = mfma(w[W1A + 1], bA, BQ(B1 + 4));
+        u0 = mfma(w[W1B], bB, u0);
+        u1 = mfma(w[W1B + 1], bB, u1);
+        const f32x4 x20 = prelu4(u0, s1), x21 = prelu4(u1, s1);
+        f32x4 P = {0.f, 0.f, 0.f, 0.f};
+        f32x4 Rr = BQ(B2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          P = mfma(w[WP + r], x20[r], P);
+          Rr = mfma(w[WR + r], x20[r], Rr);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          P = mfma(w[WP + 4 + r], x21[r], P);
+          Rr = mfma(w[WR + 4 + r], x21[r], Rr);
+        }
+        tile_store(r1, 0, pos, ok, P, L);
+        tile_store(r1, 16, pos, ok, Rr, L);
+        rec = nxt;
+      }
+    }
+
+    // ================= layer 2 mixing on P; U2 = gcn(P) + R; X3 -> R2; residual conv of layer 3 -> R1 (in place) ======
+    L = geo();
+    temporal_phase<16, 1>(r1, tab + LAYER_F4, L, lane);
+    L = geo();
+    {
+      const float4* tb = tab + LAYER_F4;
+      SpatRec rec = load_spat(tb, 0, lane);
+#pragma unroll 1
+      for (int tile = 0; tile < NTILE; ++tile) {
+        const bool fr = tile < T;
+        const int pos = fr ? tile * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;
+        const bool ok = fr || L.j < T;
+        const SpatRec nxt = load_spat(tb, tile + 1 < T ? tile + 1 : T - 1, lane);
+        const f32x4 rr = tile_load(r1, 16, pos, L);
+        f32x4 z;
+        if (fr) z = spatial_mm<16>(r1, 0, tile, rec, L);
+        else z = tile_load(r1, 0, pos, L);
+        const f32x4 x3 = prelu4(z + rr, s2);
+        tile_store(r2, 0, pos, ok, x3, L);
+        f32x4 a0 = BQ(B3), a1 = BQ(B3 + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a0 = mfma(w[WX3 + r], x3[r], a0);
+          a1 = mfma(w[WX3 + 4 + r], x3[r], a1);
+        }
+        tile_store(r1, 0, pos, ok, a0, L);
+        tile_store(r1, 16, pos, ok, a1, L);
+        rec = nxt;
+      }
+    }
+
+    // ================= layer 3 mixing on X3; conv3 on top of the stored residual part; X4 -> R1 and registers =========
+    L = geo();
+    temporal_phase<16, 1>(r2, tab + 2 * LAYER_F4, L, lane);
+    f32x4 x4[NTILE][2];
+    L = geo();
+    {
+      const float4* tb = tab + 2 * LAYER_F4;
+      SpatRec rec = load_spat(tb, 0, lane);
+#pragma unroll
+      for (int tile = 0; tile < NTILE; ++tile) {
+        const bool fr = tile < T;
+        const int pos = fr ? tile * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;
+        const bool ok = fr || L.j < T;
+        const SpatRec nxt = load_spat(tb, tile + 1 < T ? tile + 1 : T - 1, lane);
+        f32x4 a0 = tile_load(r1, 0, pos, L), a1 = tile_load(r1, 16, pos, L);
+        f32x4 z;
+        if (fr) z = spatial_mm<16>(r2, 0, tile, rec, L);
+        else z = tile_load(r2, 0, pos, L);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a0 = mfma(w[WZ3 + r], z[r], a0);
+          a1 = mfma(w[WZ3 + 4 + r], z[r], a1);
+        }
+        a0 = prelu4(a0, s3);
+        a1 = prelu4(a1, s3);
+        tile_store(r1, 0, pos, ok, a0, L);
+        tile_store(r1, 16, pos, ok, a1, L);
+        x4[tile][0] = a0;
+        x4[tile][1] = a1;
+        rec = nxt;
+        FF_TILE_FENCE;
+      }
+    }
+
+    // ================= layer 4 (32 -> 64): mixing in place, conv from the mixing accumulators + the X4 registers ======
+    L = geo();
+    temporal_phase<16, 2>(r1, tab + 3 * LAYER_F4, L, lane);
+    L = geo();
+    {
+      const float4* tb = tab + 3 * LAYER_F4;
+      float4* o4 = reinterpret_cast<float4*>(out + (size_t)clip * KP) + lane;
+      SpatRec rec = load_spat(tb, 0, lane);
+#pragma unroll
+      for (int tile = 0; tile < NTILE; ++tile) {
+        const bool fr = tile < T;
+        const int pos = fr ? tile * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;
+        const bool ok = fr || L.j < T;
+        const SpatRec nxt = load_spat(tb, tile + 1 < T ? tile + 1 : T - 1, lane);
+        f32x4 z0, z1;
+        if (fr) {
+          z0 = spatial_mm<16>(r1, 0, tile, rec, L);
+          z1 = spatial_mm<16>(r1, 1, tile, rec, L);
+        } else {
+          z0 = tile_load(r1, 0, pos, L);
+          z1 = tile_load(r1, 16, pos, L);
+        }
+        f32x4 a[4];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) a[ot] = BQ(B4 + 4 * ot);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WX4 + 8 * ot + r], x4[tile][0][r], a[ot]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WX4 + 8 * ot + 4 + r], x4[tile][1][r], a[ot]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WZ4 + 8 * ot + r], z0[r], a[ot]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WZ4 + 8 * ot + 4 + r], z1[r], a[ot]);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+          const f32x4 v = prelu4(a[ot], s4);
+          o4[(tile * 4 + ot) * 64] = ok ? float4{v[0], v[1], v[2], v[3]} : float4{0.f, 0.f, 0.f, 0.f};
+        }
+        rec = nxt;
+        FF_TILE_FENCE;
+      }
+    }
+#undef BQ
+  }
+}
+
+// out[i] = idx[i] >= 0 ? src[idx[i]] : 0   (builds the operand streams from the concatenated parameters)
+__global__ void k_gather(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int s = idx[i];
+    out[i] = s >= 0 ? src[s] : 0.f;
+  }
+}
+
+}  // namespace ff
+}  // namespace coskad
+
+using namespace coskad;
+
+extern "C" {
+
+int coskad_gather_f32(const float* src, const int* idx, float* out, size_t n, hipStream_t stream) {
+  if (!src || !idx || !out) return fail(COSKAD_ERR_ARG, "gather: null pointer");
+  if (n == 0) return COSKAD_OK;
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(ff::k_gather, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, idx, out, n);
+  return check_launch("gather");
+}
+
+int coskad_fused_encoder_out_floats(void) { return ff::KP; }
+
+int coskad_fused_encoder_f32(const float* x, float* out, const float* tab, const float* wreg, const float* slopes, int B,
+                             int T, int V, hipStream_t stream) {
+  if (!x || !out || !tab || !wreg || !slopes) return fail(COSKAD_ERR_ARG, "fused_encoder: null pointer");
+  if (B <= 0) return fail(COSKAD_ERR_ARG, "fused_encoder: B=%d", B);
+  if (T != ff::T || V != ff::V)
+    return fail(COSKAD_ERR_SHAPE, "fused_encoder: built for n_frames=12, n_joints=17 and channels 2-32-16-32-64 (got T=%d V=%d)", T, V);
+  const size_t lds = (size_t)4 * ff::WAVE_LDS * sizeof(float);
+  auto k = ff::k_fused_encoder;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int nblk = (B + 3) / 4;
+  const int grid = nblk < 256 ? nblk : 256;          // one 4-wave block per CU, persistent over clips
+  {
+    ProbeScope probe(KID_FUSED_FWD, 2, 64, stream);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, stream, x, out, reinterpret_cast<const float4*>(tab), wreg, slopes, B);
+  }
+  return check_launch("fused_encoder");
+}
+
+}  // extern "C"

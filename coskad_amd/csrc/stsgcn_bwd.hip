@@ -1201,12 +1201,15 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     };
     const int nto = ceil_div(Co, 16), ntc = ceil_div(Ci, 16);
     const int need_q = Wr != nullptr;
-    if (Zg) {        // stored Z: one dU pass, no mixing tables in LDS
-      auto zlds = [&](int nb_) {
-        size_t img = (size_t)(need_q ? 2 : 1) * nb_ * Ci * RedGeo<T, V>::LDZ + (size_t)nb_ * Co * RedGeo<T, V>::LDCZ;
-        if (img < (size_t)kScratchFloats) img = kScratchFloats;
-        return img * sizeof(float);
-      };
+    auto zlds = [&](int nb_) {
+      size_t img = (size_t)(need_q ? 2 : 1) * nb_ * Ci * RedGeo<T, V>::LDZ + (size_t)nb_ * Co * RedGeo<T, V>::LDCZ;
+      if (img < (size_t)kScratchFloats) img = kScratchFloats;
+      return img * sizeof(float);
+    };
+    // stored Z: one dU pass with X and Z both resident, no mixing tables in LDS.  When one clip's X + Z images exceed
+    // the LDS (64 input channels at 25 joints: the default-width decoder on the NTU layout) the two-pass kernel below
+    // runs instead; it takes the stored Z as well.
+    if (Zg && zlds(1) <= (size_t)kMaxLdsBytes) {
       const bool three_z = nto * ntc <= 2;
       const size_t cap = three_z ? (size_t)52 * 1024 : (size_t)76 * 1024;
       int NBz = NB;
@@ -1394,6 +1397,25 @@ using namespace coskad;
 extern "C" {
 
 size_t coskad_layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V) { return layer_bwd_ws_bytes(B, Ci, Co, T, V); }
+
+/* 1 when one clip of a (Ci -> Co) layer fits the LDS-resident tile kernels of this library (forward, statistics,
+ * backward), 0 when it does not (more than 64 channels; 64 input channels on the 25-joint layout): the module mirror
+ * then runs that layer through its composed path (mixing kernels + library GEMMs). */
+int coskad_layer_fits(int Ci, int Co, int T, int V) {
+  if (Ci <= 0 || Co <= 0 || Ci > 64 || Co > 64) return 0;
+  const int TV = T * V, LD = TV % 2 == 0 ? TV + 1 : TV;
+  const int NB = Ci >= 32 ? 1 : 32 / Ci;
+  const int CiP = round_up(Ci, 16), KZ = round_up(Ci, 4), K1 = round_up(Co, 4);
+  const size_t tables = (size_t)T * V * V + (size_t)V * T * T;
+  // the backward data path holds the input image, both mixing tables and the four coefficient matrices
+  const size_t data = ((size_t)NB * Ci * LD + tables + 2 * (size_t)(KZ + K1) * CiP + 2 * CiP) * sizeof(float);
+  // the two-pass batch reduction: input image, a dU chunk image, both tables
+  const int CH = ((TV + 2) / 3 + 3) / 4 * 4;
+  const size_t red = ((size_t)Ci * LD + (size_t)Co * (CH + 1) + tables) * sizeof(float);
+  const size_t fwd = ((size_t)NB * Ci * LD + tables + 2 * (size_t)KZ * round_up(Co, 16) + round_up(Co, 16)) * sizeof(float);
+  const size_t cap = (size_t)kMaxLdsBytes;
+  return data <= cap && red <= cap && fwd <= cap;
+}
 
 size_t coskad_gcn_bwd_params_ws_bytes(int T, int V) {
   return (size_t)kMaxGridBwd * ((size_t)T * V * V + (size_t)V * T * T) * sizeof(float);

@@ -228,3 +228,58 @@ def _as2d(g: Dict[str, Tensor]) -> Dict[str, Tensor]:
         if out.get(k) is not None and out[k].dim() == 4:
             out[k] = out[k].view(out[k].shape[0], out[k].shape[1])
     return out
+
+
+# ---- fused eval-mode encoder (csrc/fused_fwd.hip) -------------------------------------------------------------------
+class FusedEncoderPlan:
+    """Operand streams of the fused eval-mode encoder for one model: built on the device from the BatchNorm-folded
+    weights (coskad_bn_fold_f32), the mixing matrices and the bottleneck weight by ONE gather launch per stream
+    (index maps: coskad_amd/fused_plan.py), cached until a parameter changes.
+
+    Validity: torch version counters of every tensor the streams read, plus a token left in each layer's fold cache --
+    training forwards clear those caches (their kernels and the fused Adam write through raw pointers)."""
+
+    def __init__(self) -> None:
+        self.key = None
+        self.token = None
+        self.tab = self.wreg = self.wb = self.slopes = None
+        self._idx = {}
+
+    def _indices(self, latent: int, device):
+        k = (latent, str(device))
+        if k not in self._idx:
+            from . import fused_plan as FP
+            self._idx[k] = tuple(torch.from_numpy(a.reshape(-1)).to(device) for a in
+                                 (FP.tab_index(latent), FP.wreg_index(latent), FP.wb_index(latent)))
+        return self._idx[k]
+
+    def get(self, layers: List[LayerTensors], W: Tensor, ver_extra=()):
+        key = tuple(L.fold_key() for L in layers) + tuple((t.data_ptr(), t._version) for L in layers for t in (L.A, L.T, L.slope)) \
+            + ((W.data_ptr(), W._version),) + tuple(ver_extra)
+        if self.key == key and self.token is not None and all(L.cache is not None and L.cache.get("fused") is self.token for L in layers):
+            return self
+        from . import fused_plan as FP
+        latent = W.shape[0]
+        parts = []
+        for L in layers:
+            wfold, bias = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
+            parts += [L.A.detach().reshape(-1), L.T.detach().reshape(-1), wfold.reshape(-1), bias.reshape(-1)]
+        parts.append(W.detach().reshape(-1))
+        src = torch.cat(parts)
+        assert src.numel() == FP.src_layout(latent).total
+        ti, wi, bi = self._indices(latent, src.device)
+        self.tab, self.wreg = ops.gather(src, ti), ops.gather(src, wi)
+        self.wb = ops.gather(src, bi).view(latent, FP.KP)
+        self.slopes = torch.cat([L.slope.detach().reshape(1) for L in layers]).contiguous()
+        self.key, self.token = key, object()
+        for L in layers:
+            if L.cache is not None:
+                L.cache["fused"] = self.token
+        return self
+
+
+def fused_encoder_supported(layers: List[LayerTensors], n_frames: int, n_joints: int) -> bool:
+    from . import fused_plan as FP
+    if any(L.Wr is None for L in layers):
+        return False
+    return FP.supports((layers[0].Ci,) + tuple(L.Co for L in layers), n_frames, n_joints)

@@ -436,6 +436,9 @@ class Trainer:
             self.history.append(rec)
 
     def validate(self, model: LitEncoder, loader) -> float:
+        # Lightning's DDP wrap broadcasts rank 0's buffers (BatchNorm running statistics, the centre) before every
+        # forward (broadcast_buffers=True): validation scores every shard with the model that gets checkpointed
+        parallel.broadcast_buffers_(model.model)
         model.model.eval()
         outs = [model.validation_step(b, i) for i, b in enumerate(loader())]
         if parallel.world_size() > 1:

@@ -17,6 +17,7 @@ import torch.nn as nn
 from ... import engine, ops
 
 Tensor = torch.Tensor
+_FITS: dict = {}      # (Ci, Co, T, V) -> the tile kernels take the layer (coskad_layer_fits)
 WIDE_CHANNELS = 64   # widest layer the fused tile kernels take (csrc: `channels > 64 not supported`)
 
 
@@ -178,8 +179,14 @@ class ST_GCNN_layer(nn.Module):
 
     @property
     def is_wide(self) -> bool:
-        """More than 64 channels on either side: beyond the fused tile kernels (a clip's channels no longer fit LDS)."""
-        return max(self.in_channels, self.out_channels) > WIDE_CHANNELS
+        """Beyond the LDS-resident tile kernels: more than 64 channels on either side, or a clip whose images do not fit
+        the 160 KB of LDS (64 input channels on the 25-joint layout: the default-width decoder of BASELINE config 4)."""
+        if max(self.in_channels, self.out_channels) > WIDE_CHANNELS:
+            return True
+        key = (self.in_channels, self.out_channels, self.time_dim, self.joints_dim)
+        if key not in _FITS:
+            _FITS[key] = ops.layer_fits(*key)
+        return not _FITS[key]
 
     def forward_wide(self, X: Tensor) -> Tensor:
         """Wide layers (the C = 2 -> 256 stack of BASELINE.json's north_star): the block is GEMM-dominated, so it runs

@@ -105,6 +105,9 @@ class STSE(nn.Module):
     def encode(self, X: Tensor, return_shape: bool = False):
         assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
         B = X.shape[0]
+        Zf = self._encode_fused(X)
+        if Zf is not None:
+            return (Zf, (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)) if return_shape else Zf
         if hasattr(self.encoder, 'forward_preact'):
             U, slope = self.encoder.forward_preact(X)   # [B, hid, T, V] pre-activation of the last layer
         else:
@@ -117,6 +120,26 @@ class STSE(nn.Module):
         if return_shape:
             return Z, X_shape
         return Z
+
+    def _encode_fused(self, X: Tensor) -> Optional[Tensor]:
+        """Eval-mode fast path: the whole encoder in ONE kernel (csrc/fused_fwd.hip: every activation stays in LDS /
+        registers) + the bottleneck on its tile-major output.  Taken for the reference's default geometry (T = 12,
+        V = 17, channels 2-32-16-32-64, linear projector, latent <= 16) when no gradient is needed; everything else
+        runs layer by layer."""
+        if self.training or torch.is_grad_enabled() or not X.is_cuda or not isinstance(self.btlnk, nn.Linear):
+            return None
+        if self.latent_dim > 16 or not isinstance(self.encoder, Encoder):
+            return None
+        from ..graph_layers.stsgcn import layer_tensors
+        mods = list(self.encoder.model)
+        if len(mods) != 4 or any(m.is_wide for m in mods):
+            return None
+        layers = [layer_tensors(m) for m in mods]
+        if not engine.fused_encoder_supported(layers, self.n_frames, self.n_joints):
+            return None
+        plan = self.__dict__.setdefault("_fused_plan", engine.FusedEncoderPlan()).get(layers, self.btlnk.weight)
+        H = ops.fused_encoder(X.contiguous(), plan.tab, plan.wreg, plan.slopes)
+        return ops.btlnk_fwd(H, plan.wb, self.btlnk.bias, None)
 
     def forward(self, X: Tensor) -> Tensor:
         return self.encode(X)

@@ -82,6 +82,13 @@ def layer_apply(x: Tensor, A: Tensor, Tm: Tensor, wfold: Tensor, bias: Tensor, C
     return out
 
 
+def layer_fits(Ci: int, Co: int, T: int, V: int) -> bool:
+    """Do the LDS-resident tile kernels take a (Ci -> Co) layer at this geometry?  (pure host arithmetic)"""
+    fn = _lib.lib().coskad_layer_fits
+    fn.restype = ctypes.c_int
+    return bool(fn(i32(Ci), i32(Co), i32(T), i32(V)))
+
+
 def stat_floats(Ci: int, Co: int) -> int:
     fn = _lib.lib().coskad_stat_floats
     fn.restype = ctypes.c_int
@@ -137,6 +144,36 @@ def layer_apply_z(Z, x, A, Tm, wfold, bias, Co, in_slope=None, out_slope=None, o
     _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
     call("coskad_layer_apply_z_f32", ptr(Z), ptr(x), ptr(out), ptr(A), ptr(Tm), ptr(wfold), ptr(bias), ptr(in_slope), ptr(out_slope),
          i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
+    return out
+
+
+def gather(src: Tensor, idx: Tensor) -> Tensor:
+    """out[i] = src[idx[i]] (0 where idx < 0): operand streams of the fused encoder from the concatenated parameters."""
+    _chk(src, "src"); _chk(idx, "idx", dtype=torch.int32)
+    out = torch.empty(idx.shape, device=src.device, dtype=torch.float32)
+    call("coskad_gather_f32", ptr(src), ptr(idx), ptr(out), ctypes.c_size_t(idx.numel()), _stream())
+    return out
+
+
+def fused_encoder_out_floats() -> int:
+    fn = _lib.lib().coskad_fused_encoder_out_floats
+    fn.restype = ctypes.c_int
+    return fn()
+
+
+def fused_encoder(x: Tensor, tab: Tensor, wreg: Tensor, slopes: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """Eval-mode Encoder.forward (components.py:94-105) of the default stack in one kernel -> [B, KP]: the activated last
+    layer in tile-major order (coskad_amd/fused_plan.py), zero in the padding columns."""
+    B, C, T, V = x.shape
+    _chk(x, "x"); _chk(tab, "tab"); _chk(wreg, "wreg"); _chk(slopes, "slopes", (4,))
+    if C != 2:
+        raise ValueError(f"fused_encoder: 2 input channels expected, got {C}")
+    kp = fused_encoder_out_floats()
+    if out is None:
+        out = torch.empty(B, kp, device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "out", (B, kp))
+    call("coskad_fused_encoder_f32", ptr(x), ptr(out), ptr(tab), ptr(wreg), ptr(slopes), i32(B), i32(T), i32(V), _stream())
     return out
 
 

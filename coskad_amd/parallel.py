@@ -98,6 +98,26 @@ def broadcast_module_(module: torch.nn.Module, src: int = 0, group=None) -> None
                 off += k
 
 
+def broadcast_buffers_(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Rank `src`'s buffers (BatchNorm running statistics, centre, inverse covariance) to every rank -- DDP's
+    `broadcast_buffers=True`, which Lightning's DDPStrategy keeps on."""
+    if world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for is_float in (True, False):
+            sel = [b for b in module.buffers() if b.is_floating_point() == is_float and b.numel() > 0]
+            if not sel:
+                continue
+            dt = torch.float32 if is_float else torch.int64
+            flat = torch.cat([b.detach().reshape(-1).to(dt) for b in sel])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for b in sel:
+                k = b.numel()
+                b.copy_(flat[off:off + k].view(b.shape).to(b.dtype))
+                off += k
+
+
 def dedupe_rows(keys: Tensor):
     """Indices of the first occurrence of every distinct row of `keys` [N, K] (int64), in first-occurrence order:
     removes the wrap-padding duplicates that equal-length validation shards carry after a gather."""

@@ -95,9 +95,26 @@ int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const 
                              const float* wfold, const float* bias, const float* in_slope, const float* out_slope,
                              int B, int Ci, int Co, int T, int V, hipStream_t stream);
 
+/* ---- fused eval-mode encoder (models/common/components.py:94-105 in one kernel) ------------------------------
+ * Built for the reference's default geometry: n_frames 12, n_joints 17, channels 2-32-16-32-64.
+ * coskad_gather_f32 : out[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- builds the operand streams (coskad_amd/fused_plan.py
+ *                     holds the index maps) from the concatenated A / T / folded-weight / bias / bottleneck tensors.
+ * x     [B,2,12,17]; tab, wreg: operand streams; slopes[4]: the PReLU weights of the four layers;
+ * out   [B][coskad_fused_encoder_out_floats()]: PReLU(last layer) in tile-major order, zero in the padding columns:
+ *       the bottleneck (coskad_btlnk_fwd_f32 with slope NULL) reads it with the weight permuted the same way. */
+int coskad_gather_f32(const float* src, const int* idx, float* out, size_t n, hipStream_t stream);
+int coskad_fused_encoder_out_floats(void);
+int coskad_fused_encoder_f32(const float* x, float* out, const float* tab, const float* wreg, const float* slopes, int B,
+                             int T, int V, hipStream_t stream);
+
 /* ---- backward of one ST_GCNN_layer (autograd of stsgcn.py:94-116 in training mode) ------ */
 
 size_t coskad_layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V);
+
+/* 1 when one clip of a (Ci -> Co) ST_GCNN layer fits the LDS-resident tile kernels (forward, statistics, backward);
+ * 0 otherwise (more than 64 channels, or 64 input channels on the 25-joint layout): callers then compose the layer
+ * from coskad_gcn_f32 + GEMMs. */
+int coskad_layer_fits(int Ci, int Co, int T, int V);
 
 /* in   : the layer's input as stored by the producer (pre-activation; in_slope = its PReLU weight,
  *        NULL when `in` is the raw network input)

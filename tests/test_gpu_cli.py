@@ -30,7 +30,7 @@ def _free_port():
 
 def _cfg(tmp_path, name, **over):
     cfg = yaml.load(open(os.path.join(ROOT, "config", "synthetic", name)), Loader=yaml.FullLoader)
-    cfg.update(exp_dir=str(tmp_path / "ckpt"), ae_epochs=2, **over)
+    cfg.update(dict(dict(exp_dir=str(tmp_path / "ckpt"), ae_epochs=2), **over))
     path = str(tmp_path / name)
     yaml.safe_dump(cfg, open(path, "w"))
     return cfg, path
