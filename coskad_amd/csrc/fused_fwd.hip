@@ -52,20 +52,49 @@ struct Lane {
   int j, q;
 };
 
-// ---- temporal mixing of one joint column (stsgcn.py:154), in place --------------------------------------------------
-// rows of the image at `img`: row tile rt covers rows 16*rt .. 16*rt+15; ROWS < 16 masks the operand rows.
+// Buffer-addressed global memory (a 128-bit descriptor in SGPRs + ONE 32-bit lane offset + a wave-uniform SGPR/immediate
+// offset): with flat addressing hipcc precomputes a 64-bit VGPR address pair per 4 KB window of every stream and holds
+// ~70 of them across the clip loop.  Out-of-range lanes read 0 / do not store (hardware bounds check).
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using BufRes = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufRes make_res(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(BufRes r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return float4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
+__device__ __forceinline__ float buf_load1(BufRes r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store4(BufRes r, int voff, int soff, const float4& v) {
+  const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+}
+
+// ---- temporal mixing (stsgcn.py:154), in place -----------------------------------------------------------------------
+// One item = one joint column v of one row tile: D[row][q] = sum_t X[row][t,v] T[v][t][q].  The phase is software-
+// pipelined by hand: the operands of group g+1 are read BEFORE the results of group g are written (the compiler cannot
+// prove that those LDS accesses never alias, so program order is what it executes), which keeps several independent
+// MFMA chains and LDS round trips in flight from one wave.
+struct TOp {
+  float a0, a1, a2;
+};
 template <int ROWS>
-__device__ __forceinline__ f32x4 temporal_mm(const float* img, int rt, int v, const float4& rec, const Lane& L) {
+__device__ __forceinline__ TOp temporal_read(const float* img, int rt, int v, const Lane& L) {
   const float* p = img + (16 * rt + L.j) * LD + L.q * V + v;
-  float a0 = p[0], a1 = p[4 * V], a2 = p[8 * V];
+  TOp o{p[0], p[4 * V], p[8 * V]};
   if (ROWS < 16) {
     const bool ok = L.j < ROWS;
-    a0 = ok ? a0 : 0.f; a1 = ok ? a1 : 0.f; a2 = ok ? a2 : 0.f;
+    o.a0 = ok ? o.a0 : 0.f; o.a1 = ok ? o.a1 : 0.f; o.a2 = ok ? o.a2 : 0.f;
   }
+  return o;
+}
+__device__ __forceinline__ f32x4 temporal_mm(const TOp& o, const float4& rec) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = mfma(a0, rec.x, acc);
-  acc = mfma(a1, rec.y, acc);
-  acc = mfma(a2, rec.z, acc);
+  acc = mfma(o.a0, rec.x, acc);
+  acc = mfma(o.a1, rec.y, acc);
+  acc = mfma(o.a2, rec.z, acc);
   return acc;
 }
 template <int ROWS>
@@ -83,35 +112,48 @@ __device__ __forceinline__ void temporal_store(float* img, int rt, int v, const 
   }
 }
 
-// all joints of `NRT` row tiles, two independent MFMA chains in flight; the table record of joint v+1 (v+2) is
-// fetched while joint v is multiplied
+// the table of one layer's temporal mixing as B operands: 17 records per lane
+struct TTab {
+  float4 r[V];
+};
+// tabres: the whole tab stream; `base4`: float4 index of the layer's first record; l16 = lane * 16 bytes
+__device__ __forceinline__ void load_ttab(TTab& t, BufRes tabres, int base4, int l16) {
+#pragma unroll
+  for (int v = 0; v < V; ++v) t.r[v] = buf_load4(tabres, l16, (base4 + v * 64) * 16);
+}
+
 template <int ROWS, int NRT>
-__device__ __forceinline__ void temporal_phase(float* img, const float4* __restrict__ tab, const Lane& L, int lane) {
-  if (NRT == 2) {
-    float4 rec = tab[lane];
-#pragma unroll 1
-    for (int v = 0; v < V; ++v) {
-      const float4 nxt = tab[(v + 1 < V ? v + 1 : v) * 64 + lane];
-      const f32x4 d0 = temporal_mm<ROWS>(img, 0, v, rec, L);
-      const f32x4 d1 = temporal_mm<ROWS>(img, 1, v, rec, L);
-      temporal_store<ROWS>(img, 0, v, d0, L);
-      temporal_store<ROWS>(img, 1, v, d1, L);
-      rec = nxt;
-    }
-  } else {
-    float4 r0 = tab[lane], r1 = tab[64 + lane];
-#pragma unroll 1
-    for (int v = 0; v < V - 1; v += 2) {
-      const float4 n0 = tab[(v + 2) * 64 + lane];                       // v + 2 <= 16
-      const float4 n1 = tab[(v + 3 < V ? v + 3 : v + 2) * 64 + lane];
-      const f32x4 d0 = temporal_mm<ROWS>(img, 0, v, r0, L);
-      const f32x4 d1 = temporal_mm<ROWS>(img, 0, v + 1, r1, L);
-      temporal_store<ROWS>(img, 0, v, d0, L);
-      temporal_store<ROWS>(img, 0, v + 1, d1, L);
-      r0 = n0; r1 = n1;
-    }
-    const f32x4 d = temporal_mm<ROWS>(img, 0, V - 1, r0, L);
-    temporal_store<ROWS>(img, 0, V - 1, d, L);
+__device__ __forceinline__ void temporal_phase(float* img, const TTab& tt, const Lane& L) {
+  constexpr int GV = NRT == 2 ? 2 : 4;          // joints per group: 4 independent chains in flight either way
+  constexpr int NG = (V + GV - 1) / GV;
+  TOp cur[GV][NRT], nxt[GV][NRT];
+#pragma unroll
+  for (int u = 0; u < GV; ++u)
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) cur[u][rt] = temporal_read<ROWS>(img, rt, u, L);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int v0 = g * GV;
+#pragma unroll
+    for (int u = 0; u < GV; ++u)
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        if (v0 + GV + u < V) nxt[u][rt] = temporal_read<ROWS>(img, rt, v0 + GV + u, L);
+    f32x4 d[GV][NRT];
+#pragma unroll
+    for (int u = 0; u < GV; ++u)
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        if (v0 + u < V) d[u][rt] = temporal_mm(cur[u][rt], tt.r[v0 + u < V ? v0 + u : V - 1]);
+#pragma unroll
+    for (int u = 0; u < GV; ++u)
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        if (v0 + u < V) temporal_store<ROWS>(img, rt, v0 + u, d[u][rt], L);
+#pragma unroll
+    for (int u = 0; u < GV; ++u)
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) cur[u][rt] = nxt[u][rt];
   }
 }
 
@@ -119,37 +161,54 @@ __device__ __forceinline__ void temporal_phase(float* img, const float4* __restr
 struct SpatRec {
   float4 c0, c1, c2;   // b[0..3] | b[4], bw[0..2] | bw[3], bw[4], -, -
 };
-__device__ __forceinline__ SpatRec load_spat(const float4* __restrict__ tab, int t, int lane) {
-  const float4* p = tab + TEMP_F4 + t * 3 * 64 + lane;
-  return SpatRec{p[0], p[64], p[128]};
+__device__ __forceinline__ SpatRec load_spat(BufRes tabres, int base4, int t, int l16) {
+  const int o = (base4 + TEMP_F4 + t * 3 * 64) * 16;
+  return SpatRec{buf_load4(tabres, l16, o), buf_load4(tabres, l16, o + 1024), buf_load4(tabres, l16, o + 2048)};
 }
+struct SOp {
+  float a0, a1, a2, a3, a4;
+};
 template <int ROWS>
-__device__ __forceinline__ f32x4 spatial_mm(float* img, int rt, int t, const SpatRec& R, const Lane& L) {
-  float* row = img + (16 * rt + L.j) * LD + t * V;
+__device__ __forceinline__ SOp spatial_read(const float* img, int rt, int t, const Lane& L) {
+  const float* row = img + (16 * rt + L.j) * LD + t * V;
   const float* p = row + L.q;
-  float a0 = p[0], a1 = p[4], a2 = p[8], a3 = p[12];
-  float a4 = row[16];                                   // joint 16: k slot 0 of the fifth step only
-  a4 = L.q == 0 ? a4 : 0.f;
+  SOp o{p[0], p[4], p[8], p[12], row[16]};
+  o.a4 = L.q == 0 ? o.a4 : 0.f;                        // joint 16: k slot 0 of the fifth step only
   if (ROWS < 16) {
     const bool ok = L.j < ROWS;
-    a0 = ok ? a0 : 0.f; a1 = ok ? a1 : 0.f; a2 = ok ? a2 : 0.f; a3 = ok ? a3 : 0.f; a4 = ok ? a4 : 0.f;
+    o.a0 = ok ? o.a0 : 0.f; o.a1 = ok ? o.a1 : 0.f; o.a2 = ok ? o.a2 : 0.f; o.a3 = ok ? o.a3 : 0.f; o.a4 = ok ? o.a4 : 0.f;
   }
+  return o;
+}
+__device__ __forceinline__ f32x4 spatial_mm(const SOp& o, const SpatRec& R) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = mfma(a0, R.c0.x, acc);
-  acc = mfma(a1, R.c0.y, acc);
-  acc = mfma(a2, R.c0.z, acc);
-  acc = mfma(a3, R.c0.w, acc);
-  acc = mfma(a4, R.c1.x, acc);
-  float ex = a0 * R.c1.y;
-  ex = fmaf(a1, R.c1.z, ex);
-  ex = fmaf(a2, R.c1.w, ex);
-  ex = fmaf(a3, R.c2.x, ex);
-  ex = fmaf(a4, R.c2.y, ex);
-  ex += __shfl_xor(ex, 16, 64);
-  ex += __shfl_xor(ex, 32, 64);
+  acc = mfma(o.a0, R.c0.x, acc);
+  acc = mfma(o.a1, R.c0.y, acc);
+  acc = mfma(o.a2, R.c0.z, acc);
+  acc = mfma(o.a3, R.c0.w, acc);
+  acc = mfma(o.a4, R.c1.x, acc);
+  return acc;
+}
+// sum over the four k slots (lanes l, l^16, l^32, l^48) without leaving the VALU: v_permlane16_swap / v_permlane32_swap
+__device__ __forceinline__ float quad_sum(float x) {
+  unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  unsigned u2 = __float_as_uint(s);
+  auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// joint 16 of the frame: Z[row][t,16] = sum_v Y[row][t,v] A[t][v][16], written over Y[row][t,16] (dead by now)
+template <int ROWS>
+__device__ __forceinline__ void spatial_extra(float* img, int rt, int t, const SOp& o, const SpatRec& R, const Lane& L) {
+  float ex = o.a0 * R.c1.y;
+  ex = fmaf(o.a1, R.c1.z, ex);
+  ex = fmaf(o.a2, R.c1.w, ex);
+  ex = fmaf(o.a3, R.c2.x, ex);
+  ex = fmaf(o.a4, R.c2.y, ex);
+  ex = quad_sum(ex);
   float* e = img + (16 * rt + L.j) * LD + ((L.q == 0 && (ROWS >= 16 || L.j < ROWS)) ? t * V + 16 : PADCOL);
   *e = ex;
-  return acc;
 }
 
 // ---- accumulator-layout tiles in LDS -------------------------------------------------------------------------------
@@ -183,9 +242,16 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
   float* r2 = lds + R2;
 
   // conv weights (A operands) and bias quads: registers for the whole launch
+  // (rows WZ3.. and the layer-4 biases; the operands of layers 1-2 and of the residual conv of layer 3 are re-read from
+  // L2 at the start of every clip, so that their 48 registers are free while layers 3-4 hold X4 in registers)
+  const int l4 = lane * 4, l16 = lane * 16;
+  const BufRes tabres = make_res(tab, 4u * LAYER_F4 * 16u);
+  const BufRes wres = make_res(wreg, NWREG * 64u * 4u);
   float w[NWREG];
 #pragma unroll
-  for (int i = 0; i < NWREG; ++i) w[i] = wreg[i * 64 + lane];
+  for (int i = WZ3; i < B1; ++i) w[i] = buf_load1(wres, l4, i * 256);
+#pragma unroll
+  for (int i = B4; i < NWREG; ++i) w[i] = buf_load1(wres, l4, i * 256);
 #define BQ(row) f32x4{w[(row)], w[(row) + 1], w[(row) + 2], w[(row) + 3]}
   const float s1 = slopes[0], s2 = slopes[1], s3 = slopes[2], s4 = slopes[3];
 
@@ -193,14 +259,20 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
   int clip = blockIdx.x * 4 + wave;
   // the clip's 408 floats: element e = lane + 64 i
   float xin[7];
-  auto load_x = [&](int c) {
+  auto load_x = [&](int c) {      // (bounds-checked: elements >= 408 and clips >= B read 0)
+    const BufRes xr = make_res(x + (size_t)(c < B ? c : 0) * (2 * TV), c < B ? 2 * TV * 4 : 0);
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int e = lane + 64 * i;
-      xin[i] = (c < B && e < 2 * TV) ? x[(size_t)c * (2 * TV) + e] : 0.f;
-    }
+    for (int i = 0; i < 7; ++i) xin[i] = buf_load1(xr, l4, i * 256);
   };
   load_x(clip);
+  TTab tt;                          // temporal table of the phase about to run (loaded while the previous chain computes)
+  load_ttab(tt, tabres, 0, l16);
+
+  // position of this lane's column in tile `tile` (frame tiles: joints 0..15 of frame `tile`; tile 12: joint 16 of frame j)
+#define TILE_GEO(tile)                                                                   \
+  const bool fr = (tile) < T;                                                           \
+  const int pos = fr ? (tile) * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;              \
+  const bool ok = fr || L.j < T
 
   for (; clip < B; clip += nwaves) {
     // ---- stage: R2 rows 0,1 = mixing copy, rows 2,3 = the copy the residual conv of layer 1 reads
@@ -214,22 +286,30 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
       d[2 * LD] = xin[i];
     }
     load_x(clip + nwaves);      // next clip's input travels while this one is computed
+#pragma unroll
+    for (int i = 0; i < WZ3; ++i) w[i] = buf_load1(wres, l4, i * 256);
+#pragma unroll
+    for (int i = B1; i < B4; ++i) w[i] = buf_load1(wres, l4, i * 256);
 
     // ================= layer 1 (2 -> 32) and the convs of layer 2 (32 -> 16, commuted) =================
     L = geo();
-    temporal_phase<2, 1>(r2, tab, L, lane);
+    temporal_phase<2, 1>(r2, tt, L);
+    load_ttab(tt, tabres, LAYER_F4, l16);              // layer 2's temporal table: needed after this chain
+    L = geo();
     {
-      SpatRec rec = load_spat(tab, 0, lane);
+      SpatRec rec = load_spat(tabres, 0, 0, l16);
+      SOp op = spatial_read<2>(r2, 0, 0, L);
 #pragma unroll 1
       for (int tile = 0; tile < NTILE; ++tile) {
-        const bool fr = tile < T;                       // a frame tile (joints 0..15) or the 17th-joint tile
-        const int pos = fr ? tile * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;
-        const bool ok = fr || L.j < T;
-        const SpatRec nxt = load_spat(tab, tile + 1 < T ? tile + 1 : T - 1, lane);
+        TILE_GEO(tile);
+        const int tn = tile + 1 < T ? tile + 1 : T - 1;
+        const SpatRec nxt = load_spat(tabres, 0, tn, l16);
+        const SOp opn = spatial_read<2>(r2, 0, tn, L);            // next frame's operands before this tile's stores
         const float xc = r2[(L.q == 1 ? 2 : 3) * LD + pos];
         float z0, z1;
         if (fr) {
-          const f32x4 z = spatial_mm<2>(r2, 0, tile, rec, L);
+          const f32x4 z = spatial_mm(op, rec);
+          spatial_extra<2>(r2, 0, tile, op, rec, L);
           z0 = z[0]; z1 = z[1];
         } else {
           z0 = r2[pos]; z1 = r2[LD + pos];
@@ -256,26 +336,33 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
         tile_store(r1, 0, pos, ok, P, L);
         tile_store(r1, 16, pos, ok, Rr, L);
         rec = nxt;
+        op = opn;
       }
     }
 
     // ================= layer 2 mixing on P; U2 = gcn(P) + R; X3 -> R2; residual conv of layer 3 -> R1 (in place) ======
     L = geo();
-    temporal_phase<16, 1>(r1, tab + LAYER_F4, L, lane);
+    temporal_phase<16, 1>(r1, tt, L);
+    load_ttab(tt, tabres, 2 * LAYER_F4, l16);
     L = geo();
     {
-      const float4* tb = tab + LAYER_F4;
-      SpatRec rec = load_spat(tb, 0, lane);
+      constexpr int tb = LAYER_F4;
+      SpatRec rec = load_spat(tabres, tb, 0, l16);
+      SOp op = spatial_read<16>(r1, 0, 0, L);
 #pragma unroll 1
       for (int tile = 0; tile < NTILE; ++tile) {
-        const bool fr = tile < T;
-        const int pos = fr ? tile * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;
-        const bool ok = fr || L.j < T;
-        const SpatRec nxt = load_spat(tb, tile + 1 < T ? tile + 1 : T - 1, lane);
+        TILE_GEO(tile);
+        const int tn = tile + 1 < T ? tile + 1 : T - 1;
+        const SpatRec nxt = load_spat(tabres, tb, tn, l16);
+        const SOp opn = spatial_read<16>(r1, 0, tn, L);
         const f32x4 rr = tile_load(r1, 16, pos, L);
         f32x4 z;
-        if (fr) z = spatial_mm<16>(r1, 0, tile, rec, L);
-        else z = tile_load(r1, 0, pos, L);
+        if (fr) {
+          z = spatial_mm(op, rec);
+          spatial_extra<16>(r1, 0, tile, op, rec, L);
+        } else {
+          z = tile_load(r1, 0, pos, L);
+        }
         const f32x4 x3 = prelu4(z + rr, s2);
         tile_store(r2, 0, pos, ok, x3, L);
         f32x4 a0 = BQ(B3), a1 = BQ(B3 + 4);
@@ -287,27 +374,33 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
         tile_store(r1, 0, pos, ok, a0, L);
         tile_store(r1, 16, pos, ok, a1, L);
         rec = nxt;
+        op = opn;
       }
     }
 
     // ================= layer 3 mixing on X3; conv3 on top of the stored residual part; X4 -> R1 and registers =========
     L = geo();
-    temporal_phase<16, 1>(r2, tab + 2 * LAYER_F4, L, lane);
+    temporal_phase<16, 1>(r2, tt, L);
     f32x4 x4[NTILE][2];
     L = geo();
     {
-      const float4* tb = tab + 2 * LAYER_F4;
-      SpatRec rec = load_spat(tb, 0, lane);
+      constexpr int tb = 2 * LAYER_F4;
+      SpatRec rec = load_spat(tabres, tb, 0, l16);
+      SOp op = spatial_read<16>(r2, 0, 0, L);
 #pragma unroll
       for (int tile = 0; tile < NTILE; ++tile) {
-        const bool fr = tile < T;
-        const int pos = fr ? tile * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;
-        const bool ok = fr || L.j < T;
-        const SpatRec nxt = load_spat(tb, tile + 1 < T ? tile + 1 : T - 1, lane);
+        TILE_GEO(tile);
+        const int tn = tile + 1 < T ? tile + 1 : T - 1;
+        const SpatRec nxt = load_spat(tabres, tb, tn, l16);
+        const SOp opn = spatial_read<16>(r2, 0, tn, L);
         f32x4 a0 = tile_load(r1, 0, pos, L), a1 = tile_load(r1, 16, pos, L);
         f32x4 z;
-        if (fr) z = spatial_mm<16>(r2, 0, tile, rec, L);
-        else z = tile_load(r2, 0, pos, L);
+        if (fr) {
+          z = spatial_mm(op, rec);
+          spatial_extra<16>(r2, 0, tile, op, rec, L);
+        } else {
+          z = tile_load(r2, 0, pos, L);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           a0 = mfma(w[WZ3 + r], z[r], a0);
@@ -320,28 +413,33 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
         x4[tile][0] = a0;
         x4[tile][1] = a1;
         rec = nxt;
+        op = opn;
         FF_TILE_FENCE;
       }
     }
 
     // ================= layer 4 (32 -> 64): mixing in place, conv from the mixing accumulators + the X4 registers ======
+    load_ttab(tt, tabres, 3 * LAYER_F4, l16);
     L = geo();
-    temporal_phase<16, 2>(r1, tab + 3 * LAYER_F4, L, lane);
+    temporal_phase<16, 2>(r1, tt, L);
     L = geo();
     {
-      const float4* tb = tab + 3 * LAYER_F4;
-      float4* o4 = reinterpret_cast<float4*>(out + (size_t)clip * KP) + lane;
-      SpatRec rec = load_spat(tb, 0, lane);
+      constexpr int tb = 3 * LAYER_F4;
+      const BufRes ores = make_res(out + (size_t)clip * KP, KP * 4);
+      SpatRec rec = load_spat(tabres, tb, 0, l16);
+      SOp op0 = spatial_read<16>(r1, 0, 0, L), op1 = spatial_read<16>(r1, 1, 0, L);
 #pragma unroll
       for (int tile = 0; tile < NTILE; ++tile) {
-        const bool fr = tile < T;
-        const int pos = fr ? tile * V + L.j : (L.j < T ? L.j : T - 1) * V + 16;
-        const bool ok = fr || L.j < T;
-        const SpatRec nxt = load_spat(tb, tile + 1 < T ? tile + 1 : T - 1, lane);
+        TILE_GEO(tile);
+        const int tn = tile + 1 < T ? tile + 1 : T - 1;
+        const SpatRec nxt = load_spat(tabres, tb, tn, l16);
+        const SOp opn0 = spatial_read<16>(r1, 0, tn, L), opn1 = spatial_read<16>(r1, 1, tn, L);
         f32x4 z0, z1;
         if (fr) {
-          z0 = spatial_mm<16>(r1, 0, tile, rec, L);
-          z1 = spatial_mm<16>(r1, 1, tile, rec, L);
+          z0 = spatial_mm(op0, rec);
+          z1 = spatial_mm(op1, rec);
+          spatial_extra<16>(r1, 0, tile, op0, rec, L);
+          spatial_extra<16>(r1, 1, tile, op1, rec, L);
         } else {
           z0 = tile_load(r1, 0, pos, L);
           z1 = tile_load(r1, 16, pos, L);
@@ -368,14 +466,18 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
           const f32x4 v = prelu4(a[ot], s4);
-          o4[(tile * 4 + ot) * 64] = ok ? float4{v[0], v[1], v[2], v[3]} : float4{0.f, 0.f, 0.f, 0.f};
+          buf_store4(ores, l16, (tile * 4 + ot) * 1024, ok ? float4{v[0], v[1], v[2], v[3]} : float4{0.f, 0.f, 0.f, 0.f});
         }
         rec = nxt;
+        op0 = opn0;
+        op1 = opn1;
         FF_TILE_FENCE;
       }
     }
-#undef BQ
+    load_ttab(tt, tabres, 0, l16);   // layer 1's table for the next clip
   }
+#undef BQ
+#undef TILE_GEO
 }
 
 // out[i] = idx[i] >= 0 ? src[idx[i]] : 0   (builds the operand streams from the concatenated parameters)
