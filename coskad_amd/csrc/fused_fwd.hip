@@ -291,31 +291,39 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
 #pragma unroll
     for (int i = B1; i < B4; ++i) w[i] = buf_load1(wres, l4, i * 256);
 
+    // Every chain below is a two-stage software pipeline written out by hand: iteration `tile` issues the operand reads
+    // of frame tile+2, runs the spatial mixing of frame tile+1 and the convolutions of tile `tile` -- two independent
+    // dependency chains per iteration, so that the in-order wave always has MFMAs to issue while the other chain waits
+    // for its accumulators, LDS round trips or the VALU epilogue.
     // ================= layer 1 (2 -> 32) and the convs of layer 2 (32 -> 16, commuted) =================
     L = geo();
     temporal_phase<2, 1>(r2, tt, L);
     load_ttab(tt, tabres, LAYER_F4, l16);              // layer 2's temporal table: needed after this chain
     L = geo();
     {
-      SpatRec rec = load_spat(tabres, 0, 0, l16);
-      SOp op = spatial_read<2>(r2, 0, 0, L);
+      SpatRec rec1 = load_spat(tabres, 0, 0, l16);
+      SOp op1 = spatial_read<2>(r2, 0, 0, L);
+      f32x4 zc = spatial_mm(op1, rec1);
+      spatial_extra<2>(r2, 0, 0, op1, rec1, L);
+      rec1 = load_spat(tabres, 0, 1, l16);
+      op1 = spatial_read<2>(r2, 0, 1, L);
 #pragma unroll 1
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
-        const int tn = tile + 1 < T ? tile + 1 : T - 1;
-        const SpatRec nxt = load_spat(tabres, 0, tn, l16);
-        const SOp opn = spatial_read<2>(r2, 0, tn, L);            // next frame's operands before this tile's stores
-        const float xc = r2[(L.q == 1 ? 2 : 3) * LD + pos];
-        float z0, z1;
-        if (fr) {
-          const f32x4 z = spatial_mm(op, rec);
-          spatial_extra<2>(r2, 0, tile, op, rec, L);
-          z0 = z[0]; z1 = z[1];
-        } else {
-          z0 = r2[pos]; z1 = r2[LD + pos];
+        const int t2 = tile + 2 < T ? tile + 2 : T - 1;
+        const SpatRec rec2 = load_spat(tabres, 0, t2, l16);
+        const SOp op2 = spatial_read<2>(r2, 0, t2, L);            // frame tile+2's operands before this tile's stores
+        f32x4 zn;
+        if (tile + 1 < T) {
+          zn = spatial_mm(op1, rec1);
+          spatial_extra<2>(r2, 0, tile + 1, op1, rec1, L);
+        } else {                                                    // next = the 17th-joint tile: joint 16 of frame j
+          const int pe = (L.j < T ? L.j : T - 1) * V + 16;
+          zn = f32x4{r2[pe], r2[LD + pe], 0.f, 0.f};
         }
-        const float bA = L.q == 0 ? z0 : ((L.q == 1 || L.q == 2) ? xc : 0.f);
-        const float bB = L.q == 0 ? z1 : 0.f;
+        const float xc = r2[(L.q == 1 ? 2 : 3) * LD + pos];
+        const float bA = L.q == 0 ? zc[0] : ((L.q == 1 || L.q == 2) ? xc : 0.f);
+        const float bB = L.q == 0 ? zc[1] : 0.f;
         f32x4 u0 = mfma(w[W1A], bA, BQ(B1));
         f32x4 u1 = mfma(w[W1A + 1], bA, BQ(B1 + 4));
         u0 = mfma(w[W1B], bB, u0);
@@ -335,8 +343,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
         }
         tile_store(r1, 0, pos, ok, P, L);
         tile_store(r1, 16, pos, ok, Rr, L);
-        rec = nxt;
-        op = opn;
+        zc = zn; rec1 = rec2; op1 = op2;
       }
     }
 
@@ -347,23 +354,27 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
     L = geo();
     {
       constexpr int tb = LAYER_F4;
-      SpatRec rec = load_spat(tabres, tb, 0, l16);
-      SOp op = spatial_read<16>(r1, 0, 0, L);
+      SpatRec rec1 = load_spat(tabres, tb, 0, l16);
+      SOp op1 = spatial_read<16>(r1, 0, 0, L);
+      f32x4 zc = spatial_mm(op1, rec1);
+      spatial_extra<16>(r1, 0, 0, op1, rec1, L);
+      rec1 = load_spat(tabres, tb, 1, l16);
+      op1 = spatial_read<16>(r1, 0, 1, L);
 #pragma unroll 1
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
-        const int tn = tile + 1 < T ? tile + 1 : T - 1;
-        const SpatRec nxt = load_spat(tabres, tb, tn, l16);
-        const SOp opn = spatial_read<16>(r1, 0, tn, L);
+        const int t2 = tile + 2 < T ? tile + 2 : T - 1;
+        const SpatRec rec2 = load_spat(tabres, tb, t2, l16);
+        const SOp op2 = spatial_read<16>(r1, 0, t2, L);
         const f32x4 rr = tile_load(r1, 16, pos, L);
-        f32x4 z;
-        if (fr) {
-          z = spatial_mm(op, rec);
-          spatial_extra<16>(r1, 0, tile, op, rec, L);
+        f32x4 zn;
+        if (tile + 1 < T) {
+          zn = spatial_mm(op1, rec1);
+          spatial_extra<16>(r1, 0, tile + 1, op1, rec1, L);
         } else {
-          z = tile_load(r1, 0, pos, L);
+          zn = tile_load(r1, 0, (L.j < T ? L.j : T - 1) * V + 16, L);
         }
-        const f32x4 x3 = prelu4(z + rr, s2);
+        const f32x4 x3 = prelu4(zc + rr, s2);
         tile_store(r2, 0, pos, ok, x3, L);
         f32x4 a0 = BQ(B3), a1 = BQ(B3 + 4);
 #pragma unroll
@@ -373,8 +384,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
         }
         tile_store(r1, 0, pos, ok, a0, L);
         tile_store(r1, 16, pos, ok, a1, L);
-        rec = nxt;
-        op = opn;
+        zc = zn; rec1 = rec2; op1 = op2;
       }
     }
 
@@ -385,26 +395,30 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
     L = geo();
     {
       constexpr int tb = 2 * LAYER_F4;
-      SpatRec rec = load_spat(tabres, tb, 0, l16);
-      SOp op = spatial_read<16>(r2, 0, 0, L);
+      SpatRec rec1 = load_spat(tabres, tb, 0, l16);
+      SOp op1 = spatial_read<16>(r2, 0, 0, L);
+      f32x4 zc = spatial_mm(op1, rec1);
+      spatial_extra<16>(r2, 0, 0, op1, rec1, L);
+      rec1 = load_spat(tabres, tb, 1, l16);
+      op1 = spatial_read<16>(r2, 0, 1, L);
 #pragma unroll
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
-        const int tn = tile + 1 < T ? tile + 1 : T - 1;
-        const SpatRec nxt = load_spat(tabres, tb, tn, l16);
-        const SOp opn = spatial_read<16>(r2, 0, tn, L);
+        const int t2 = tile + 2 < T ? tile + 2 : T - 1;
+        const SpatRec rec2 = load_spat(tabres, tb, t2, l16);
+        const SOp op2 = spatial_read<16>(r2, 0, t2, L);
         f32x4 a0 = tile_load(r1, 0, pos, L), a1 = tile_load(r1, 16, pos, L);
-        f32x4 z;
-        if (fr) {
-          z = spatial_mm(op, rec);
-          spatial_extra<16>(r2, 0, tile, op, rec, L);
+        f32x4 zn;
+        if (tile + 1 < T) {
+          zn = spatial_mm(op1, rec1);
+          spatial_extra<16>(r2, 0, tile + 1, op1, rec1, L);
         } else {
-          z = tile_load(r2, 0, pos, L);
+          zn = tile_load(r2, 0, (L.j < T ? L.j : T - 1) * V + 16, L);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          a0 = mfma(w[WZ3 + r], z[r], a0);
-          a1 = mfma(w[WZ3 + 4 + r], z[r], a1);
+          a0 = mfma(w[WZ3 + r], zc[r], a0);
+          a1 = mfma(w[WZ3 + 4 + r], zc[r], a1);
         }
         a0 = prelu4(a0, s3);
         a1 = prelu4(a1, s3);
@@ -412,8 +426,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
         tile_store(r1, 16, pos, ok, a1, L);
         x4[tile][0] = a0;
         x4[tile][1] = a1;
-        rec = nxt;
-        op = opn;
+        zc = zn; rec1 = rec2; op1 = op2;
         FF_TILE_FENCE;
       }
     }
@@ -426,23 +439,30 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
     {
       constexpr int tb = 3 * LAYER_F4;
       const BufRes ores = make_res(out + (size_t)clip * KP, KP * 4);
-      SpatRec rec = load_spat(tabres, tb, 0, l16);
-      SOp op0 = spatial_read<16>(r1, 0, 0, L), op1 = spatial_read<16>(r1, 1, 0, L);
+      SpatRec rec1 = load_spat(tabres, tb, 0, l16);
+      SOp op10 = spatial_read<16>(r1, 0, 0, L), op11 = spatial_read<16>(r1, 1, 0, L);
+      f32x4 zc0 = spatial_mm(op10, rec1), zc1 = spatial_mm(op11, rec1);
+      spatial_extra<16>(r1, 0, 0, op10, rec1, L);
+      spatial_extra<16>(r1, 1, 0, op11, rec1, L);
+      rec1 = load_spat(tabres, tb, 1, l16);
+      op10 = spatial_read<16>(r1, 0, 1, L);
+      op11 = spatial_read<16>(r1, 1, 1, L);
 #pragma unroll
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
-        const int tn = tile + 1 < T ? tile + 1 : T - 1;
-        const SpatRec nxt = load_spat(tabres, tb, tn, l16);
-        const SOp opn0 = spatial_read<16>(r1, 0, tn, L), opn1 = spatial_read<16>(r1, 1, tn, L);
-        f32x4 z0, z1;
-        if (fr) {
-          z0 = spatial_mm(op0, rec);
-          z1 = spatial_mm(op1, rec);
-          spatial_extra<16>(r1, 0, tile, op0, rec, L);
-          spatial_extra<16>(r1, 1, tile, op1, rec, L);
+        const int t2 = tile + 2 < T ? tile + 2 : T - 1;
+        const SpatRec rec2 = load_spat(tabres, tb, t2, l16);
+        const SOp op20 = spatial_read<16>(r1, 0, t2, L), op21 = spatial_read<16>(r1, 1, t2, L);
+        f32x4 zn0, zn1;
+        if (tile + 1 < T) {
+          zn0 = spatial_mm(op10, rec1);
+          zn1 = spatial_mm(op11, rec1);
+          spatial_extra<16>(r1, 0, tile + 1, op10, rec1, L);
+          spatial_extra<16>(r1, 1, tile + 1, op11, rec1, L);
         } else {
-          z0 = tile_load(r1, 0, pos, L);
-          z1 = tile_load(r1, 16, pos, L);
+          const int pe = (L.j < T ? L.j : T - 1) * V + 16;
+          zn0 = tile_load(r1, 0, pe, L);
+          zn1 = tile_load(r1, 16, pe, L);
         }
         f32x4 a[4];
 #pragma unroll
@@ -458,19 +478,17 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WZ4 + 8 * ot + r], z0[r], a[ot]);
+          for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WZ4 + 8 * ot + r], zc0[r], a[ot]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WZ4 + 8 * ot + 4 + r], z1[r], a[ot]);
+          for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WZ4 + 8 * ot + 4 + r], zc1[r], a[ot]);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
           const f32x4 v = prelu4(a[ot], s4);
           buf_store4(ores, l16, (tile * 4 + ot) * 1024, ok ? float4{v[0], v[1], v[2], v[3]} : float4{0.f, 0.f, 0.f, 0.f});
         }
-        rec = nxt;
-        op0 = opn0;
-        op1 = opn1;
+        zc0 = zn0; zc1 = zn1; rec1 = rec2; op10 = op20; op11 = op21;
         FF_TILE_FENCE;
       }
     }
