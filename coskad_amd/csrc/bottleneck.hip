@@ -70,6 +70,83 @@ __global__ __launch_bounds__(64 * kBtlFwdWaves) void k_btlnk_fwd(const float* __
   }
 }
 
+// Split-K variant for large batches: a block = 64 clips (four MFMA row tiles per wave, which share every W operand:
+// the L2 traffic of W drops to a quarter of the HBM traffic of U) x one of KS slices of K; the four waves split the
+// slice again.  Partials [KS][B][16] are summed in a fixed order by k_btlnk_fwd_sum (deterministic, no atomics).
+constexpr int kBtlKS = 8;
+__global__ __launch_bounds__(256) void k_btlnk_fwd_t(const float* __restrict__ U, const float* __restrict__ W,
+                                                     const float* __restrict__ slope, float* __restrict__ part,
+                                                     int B, int K, int L) {
+  __shared__ float red[4][4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int clip0 = blockIdx.x * 64;
+  const bool pre = slope != nullptr;
+  const float a = pre ? slope[0] : 0.f;
+  const bool colok = i < L;
+  const float* wp = W + (size_t)(colok ? i : 0) * K + 4 * kk;
+  const float* up[4];
+  bool rowok[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int n = clip0 + 16 * ct + i;
+    rowok[ct] = n < B;
+    up[ct] = U + (size_t)(rowok[ct] ? n : 0) * K + 4 * kk;
+  }
+  const int nsteps = K / 16;                                   // K % 16 == 0 (checked by the launcher)
+  const int g = blockIdx.y * 4 + wave, G = gridDim.y * 4;      // this wave's slice of the k-steps
+  const int s0 = (int)((long long)nsteps * g / G), s1 = (int)((long long)nsteps * (g + 1) / G);
+  f32x4 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int UB = 2;
+  for (int sb = s0; sb < s1; sb += UB) {
+    float4 x[4][UB], w[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const bool ok = sb + u < s1;
+      const int k = (sb + u) * 16;
+      w[u] = (ok && colok) ? *reinterpret_cast<const float4*>(wp + k) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        x[ct][u] = (ok && rowok[ct]) ? *reinterpret_cast<const float4*>(up[ct] + k) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        float4 xv = x[ct][u];
+        if (pre) { xv.x = prelu_f(xv.x, a); xv.y = prelu_f(xv.y, a); xv.z = prelu_f(xv.z, a); xv.w = prelu_f(xv.w, a); }
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, w[u].x, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, w[u].y, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, w[u].z, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, w[u].w, acc[ct], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][ct][(4 * kk + r) * 16 + i] = acc[ct][r];
+  __syncthreads();
+  // 64 clips x 16 latents = 1024 sums of four wave partials; thread e handles 4 of them
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    const int ct = e >> 8, rc = e & 255, row = rc >> 4, col = rc & 15;
+    const int n = clip0 + 16 * ct + row;
+    if (n < B) part[((size_t)blockIdx.y * B + n) * 16 + col] = (red[0][ct][rc] + red[1][ct][rc]) + (red[2][ct][rc] + red[3][ct][rc]);
+  }
+}
+
+__global__ void k_btlnk_fwd_sum(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ z,
+                                int B, int L, int KS) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * 16) return;
+  const int n = e >> 4, col = e & 15;
+  if (col >= L) return;
+  float s = 0.f;
+  for (int k = 0; k < KS; ++k) s += part[((size_t)k * B + n) * 16 + col];
+  z[(size_t)n * L + col] = s + (bias ? bias[col] : 0.f);
+}
+
 // grid = (ceil(K/256), S clip-chunks).  dWp: [S][L][K] partials, dap: [gridDim.x*gridDim.y].
 __global__ __launch_bounds__(kBtlBlock) void k_btlnk_bwd(const float* __restrict__ U,
                                                      const float* __restrict__ W,
@@ -225,6 +302,25 @@ int coskad_btlnk_fwd_f32(const float* U, const float* W, const float* bias, cons
   if (K % 4) return fail(COSKAD_ERR_SHAPE, "btlnk_fwd: K=%d must be a multiple of 4", K);
   hipLaunchKernelGGL(k_btlnk_fwd, dim3(ceil_div(B, 16)), dim3(64 * kBtlFwdWaves), 0, stream, U, W, bias, slope, z, B, K, L);
   return check_launch("btlnk_fwd");
+}
+
+size_t coskad_btlnk_fwd_ws_bytes(int B) { return (size_t)kBtlKS * (size_t)(B > 0 ? B : 0) * 16 * sizeof(float); }
+
+/* z = W . PReLU(U) + b like coskad_btlnk_fwd_f32, as a split-K GEMM with a caller-provided workspace of
+ * coskad_btlnk_fwd_ws_bytes(B) bytes: the fast path for large batches (K must be a multiple of 16). */
+int coskad_btlnk_fwd_ws_f32(const float* U, const float* W, const float* bias, const float* slope, float* z, void* ws,
+                            size_t ws_bytes, int B, int K, int L, hipStream_t stream) {
+  if (!U || !W || !z || !ws) return fail(COSKAD_ERR_ARG, "btlnk_fwd_ws: null pointer");
+  if (B <= 0 || K <= 0 || L <= 0) return fail(COSKAD_ERR_ARG, "btlnk_fwd_ws: B=%d K=%d L=%d", B, K, L);
+  if (L > 16) return fail(COSKAD_ERR_SHAPE, "btlnk_fwd_ws: latent_dim=%d > 16 not supported", L);
+  if (K % 16) return fail(COSKAD_ERR_SHAPE, "btlnk_fwd_ws: K=%d must be a multiple of 16", K);
+  if (ws_bytes < coskad_btlnk_fwd_ws_bytes(B)) return fail(COSKAD_ERR_WORKSPACE, "btlnk_fwd_ws: workspace too small");
+  float* part = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(k_btlnk_fwd_t, dim3(ceil_div(B, 64), kBtlKS), dim3(256), 0, stream, U, W, slope, part, B, K, L);
+  int rc;
+  if ((rc = check_launch("btlnk_fwd_t"))) return rc;
+  hipLaunchKernelGGL(k_btlnk_fwd_sum, dim3(ceil_div(B * 16, 256)), dim3(256), 0, stream, part, bias, z, B, L, kBtlKS);
+  return check_launch("btlnk_fwd_sum");
 }
 
 size_t coskad_btlnk_bwd_ws_bytes(int B, int K, int L) {

@@ -32,6 +32,16 @@ constexpr int R1 = 0, R2 = 32 * LD;     // float offsets inside the wave's LDS i
 constexpr int PADCOL = TV;              // columns 204, 205 of every row are padding: masked lanes store there (no divergent branches)
 constexpr int WAVE_LDS = 48 * LD;       // floats per wave
 constexpr int NTILE = T + 1;
+#ifndef FF_AB_UNROLL
+#define FF_AB_UNROLL _Pragma("unroll")     // tile loops of layers 1-2: fully unrolled like layers 3-4 (rolled: 213 vs 199 us at B = 4096 --
+                                           // the register rotation of the hand-written pipeline costs ~20 v_mov per iteration)
+#endif
+#ifndef FF_ABLATE
+#define FF_ABLATE 0   // timing-only builds (tools/ab_fused.sh): bit 0 skips the temporal phases, bits 1..4 the chains of layers 1..4
+#endif
+#ifndef FF_CABL
+#define FF_CABL 0     // timing-only: pieces of the layer-3 chain (1 table loads, 2 accumulator loads, 4 stores, 8 joint 16, 16 PReLU)
+#endif
 #ifndef FF_TILE_FENCE
 #define FF_TILE_FENCE   // (A/B hook: -DFF_TILE_FENCE="__builtin_amdgcn_sched_barrier(0)" keeps the scheduler inside one tile)
 #endif
@@ -297,17 +307,17 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
     // for its accumulators, LDS round trips or the VALU epilogue.
     // ================= layer 1 (2 -> 32) and the convs of layer 2 (32 -> 16, commuted) =================
     L = geo();
-    temporal_phase<2, 1>(r2, tt, L);
+    if (!(FF_ABLATE & 1)) temporal_phase<2, 1>(r2, tt, L);
     load_ttab(tt, tabres, LAYER_F4, l16);              // layer 2's temporal table: needed after this chain
     L = geo();
-    {
+    if (!(FF_ABLATE & 2)) {
       SpatRec rec1 = load_spat(tabres, 0, 0, l16);
       SOp op1 = spatial_read<2>(r2, 0, 0, L);
       f32x4 zc = spatial_mm(op1, rec1);
       spatial_extra<2>(r2, 0, 0, op1, rec1, L);
       rec1 = load_spat(tabres, 0, 1, l16);
       op1 = spatial_read<2>(r2, 0, 1, L);
-#pragma unroll 1
+      FF_AB_UNROLL
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
         const int t2 = tile + 2 < T ? tile + 2 : T - 1;
@@ -349,10 +359,10 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
 
     // ================= layer 2 mixing on P; U2 = gcn(P) + R; X3 -> R2; residual conv of layer 3 -> R1 (in place) ======
     L = geo();
-    temporal_phase<16, 1>(r1, tt, L);
+    if (!(FF_ABLATE & 1)) temporal_phase<16, 1>(r1, tt, L);
     load_ttab(tt, tabres, 2 * LAYER_F4, l16);
     L = geo();
-    {
+    if (!(FF_ABLATE & 4)) {
       constexpr int tb = LAYER_F4;
       SpatRec rec1 = load_spat(tabres, tb, 0, l16);
       SOp op1 = spatial_read<16>(r1, 0, 0, L);
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
       spatial_extra<16>(r1, 0, 0, op1, rec1, L);
       rec1 = load_spat(tabres, tb, 1, l16);
       op1 = spatial_read<16>(r1, 0, 1, L);
-#pragma unroll 1
+      FF_AB_UNROLL
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
         const int t2 = tile + 2 < T ? tile + 2 : T - 1;
@@ -390,10 +400,13 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
 
     // ================= layer 3 mixing on X3; conv3 on top of the stored residual part; X4 -> R1 and registers =========
     L = geo();
-    temporal_phase<16, 1>(r2, tt, L);
+    if (!(FF_ABLATE & 1)) temporal_phase<16, 1>(r2, tt, L);
     f32x4 x4[NTILE][2];
     L = geo();
-    {
+    if (FF_ABLATE & 8) {
+#pragma unroll
+      for (int tile = 0; tile < NTILE; ++tile) x4[tile][0] = x4[tile][1] = f32x4{xin[0], xin[1], xin[2], xin[3]};
+    } else {
       constexpr int tb = 2 * LAYER_F4;
       SpatRec rec1 = load_spat(tabres, tb, 0, l16);
       SOp op1 = spatial_read<16>(r2, 0, 0, L);
@@ -405,13 +418,13 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
         const int t2 = tile + 2 < T ? tile + 2 : T - 1;
-        const SpatRec rec2 = load_spat(tabres, tb, t2, l16);
+        const SpatRec rec2 = (FF_CABL & 1) ? rec1 : load_spat(tabres, tb, t2, l16);
         const SOp op2 = spatial_read<16>(r2, 0, t2, L);
-        f32x4 a0 = tile_load(r1, 0, pos, L), a1 = tile_load(r1, 16, pos, L);
+        f32x4 a0 = (FF_CABL & 2) ? BQ(B3) : tile_load(r1, 0, pos, L), a1 = (FF_CABL & 2) ? BQ(B3 + 4) : tile_load(r1, 16, pos, L);
         f32x4 zn;
         if (tile + 1 < T) {
           zn = spatial_mm(op1, rec1);
-          spatial_extra<16>(r2, 0, tile + 1, op1, rec1, L);
+          if (!(FF_CABL & 8)) spatial_extra<16>(r2, 0, tile + 1, op1, rec1, L);
         } else {
           zn = tile_load(r2, 0, (L.j < T ? L.j : T - 1) * V + 16, L);
         }
@@ -420,10 +433,14 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
           a0 = mfma(w[WZ3 + r], zc[r], a0);
           a1 = mfma(w[WZ3 + 4 + r], zc[r], a1);
         }
-        a0 = prelu4(a0, s3);
-        a1 = prelu4(a1, s3);
-        tile_store(r1, 0, pos, ok, a0, L);
-        tile_store(r1, 16, pos, ok, a1, L);
+        if (!(FF_CABL & 16)) {
+          a0 = prelu4(a0, s3);
+          a1 = prelu4(a1, s3);
+        }
+        if (!(FF_CABL & 4)) {
+          tile_store(r1, 0, pos, ok, a0, L);
+          tile_store(r1, 16, pos, ok, a1, L);
+        }
         x4[tile][0] = a0;
         x4[tile][1] = a1;
         zc = zn; rec1 = rec2; op1 = op2;
@@ -434,9 +451,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
     // ================= layer 4 (32 -> 64): mixing in place, conv from the mixing accumulators + the X4 registers ======
     load_ttab(tt, tabres, 3 * LAYER_F4, l16);
     L = geo();
-    temporal_phase<16, 2>(r1, tt, L);
+    if (!(FF_ABLATE & 1)) temporal_phase<16, 2>(r1, tt, L);
     L = geo();
-    {
+    if (!(FF_ABLATE & 16)) {
       constexpr int tb = 3 * LAYER_F4;
       const BufRes ores = make_res(out + (size_t)clip * KP, KP * 4);
       SpatRec rec1 = load_spat(tabres, tb, 0, l16);

@@ -270,8 +270,20 @@ def btlnk_fwd(U: Tensor, W: Tensor, bias: Optional[Tensor], slope: Optional[Tens
     L = W.shape[0]
     _chk(U, "U"); _chk(W, "W", (L, K)); _chk(bias, "bias", (L,), optional=True); _chk(slope, "slope", (1,), optional=True)
     z = torch.empty(B, L, device=U.device, dtype=torch.float32)
+    if B >= BTLNK_SPLITK_MIN_B and K % 16 == 0:
+        # large batches: blocks of 64 clips x 8 K slices (W operands shared by four clip tiles), fixed-order partial sums
+        fn = _lib.lib().coskad_btlnk_fwd_ws_bytes
+        fn.restype = ctypes.c_size_t
+        nbytes = fn(i32(B))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=U.device)
+        call("coskad_btlnk_fwd_ws_f32", ptr(U), ptr(W), ptr(bias), ptr(slope), ptr(z), ptr(ws), ctypes.c_size_t(nbytes),
+             i32(B), i32(K), i32(L), _stream())
+        return z
     call("coskad_btlnk_fwd_f32", ptr(U), ptr(W), ptr(bias), ptr(slope), ptr(z), i32(B), i32(K), i32(L), _stream())
     return z
+
+
+BTLNK_SPLITK_MIN_B = 1      # always (K % 16 == 0): a clip's latent must not depend on the batch it arrives in (bit-exact chunking)
 
 
 def btlnk_bwd_ws_bytes(B, K, L) -> int:

@@ -166,6 +166,12 @@ int coskad_gcn_bwd_params_f32(const float* x, const float* dZ, const float* A, c
 /* z[n][j] = bias[j] + sum_k W[j][k] * PReLU_slope(U[n][k]);  slope NULL: no activation. L <= 16. */
 int coskad_btlnk_fwd_f32(const float* U, const float* W, const float* bias, const float* slope, float* z,
                          int B, int K, int L, hipStream_t stream);
+
+/* The same as a split-K GEMM (blocks of 64 clips x 8 K slices, fixed-order sum of the partials) with a workspace of
+ * coskad_btlnk_fwd_ws_bytes(B) bytes: the large-batch path; K must be a multiple of 16. */
+size_t coskad_btlnk_fwd_ws_bytes(int B);
+int coskad_btlnk_fwd_ws_f32(const float* U, const float* W, const float* bias, const float* slope, float* z, void* ws,
+                            size_t ws_bytes, int B, int K, int L, hipStream_t stream);
 size_t coskad_btlnk_bwd_ws_bytes(int B, int K, int L);
 /* dU = (dz W) * PReLU'(U);  dW (+)= dz^T PReLU(U);  db (+)= sum_n dz;  dslope (+)= sum (dz W) U [U<0] */
 int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const float* slope, float* dU,
