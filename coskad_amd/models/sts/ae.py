@@ -115,6 +115,8 @@ class STSE(nn.Module):
         X_shape = (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)
         if isinstance(self.btlnk, nn.Linear) and self.latent_dim <= 16:
             Z = _BottleneckFn.apply(U, slope, self.btlnk.weight, self.btlnk.bias, self._ws)
+        elif isinstance(self.btlnk, MLP) and self.btlnk.hip_ok:
+            Z = self.btlnk.forward_preact(U, slope, self._ws, _BottleneckFn.apply)
         else:
             Z = self.btlnk((U if slope is None else _PReLUFn.apply(U, slope)).reshape(B, -1))
         if return_shape:

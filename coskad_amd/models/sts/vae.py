@@ -102,7 +102,11 @@ class STSVAE(STSAE):
         assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
         B = X.shape[0]
         U, slope = self.encoder.forward_preact(X)
-        Z = self.btlnk((U if slope is None else _PReLUFn.apply(U, slope)).reshape(B, -1))
+        if isinstance(self.btlnk, MLP) and self.btlnk.hip_ok:      # wide Linear + BN/ReLU/Linear tail on the HIP kernels
+            from .ae import _BottleneckFn
+            Z = self.btlnk.forward_preact(U, slope, self._ws, _BottleneckFn.apply)
+        else:
+            Z = self.btlnk((U if slope is None else _PReLUFn.apply(U, slope)).reshape(B, -1))
         X_shape = (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)
         Z_mean = self.fc_mean(Z)
         if self.distribution == 'ps':

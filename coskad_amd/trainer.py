@@ -61,7 +61,7 @@ def inv_cov_from_moments(gram: Tensor, acc: Tensor, mu: Tensor, L: int) -> Tenso
 
 
 class STSETrainStep:
-    """One-class training of an STSE (linear projector) without autograd.
+    """One-class training of an STSE (`linear` projector, or `mlp` within the HIP kernels' widths) without autograd.
 
     head: 'euclidean' -> F.mse_loss(z, c);  'poincare' -> dist(c, project(expmap0(z))).mean().
     """
@@ -70,8 +70,10 @@ class STSETrainStep:
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, use_graph: bool = False,
                  side_stream: bool = False) -> None:
         from .models.sts.ae import STSE
-        if not isinstance(model, STSE) or not isinstance(model.btlnk, torch.nn.Linear):
-            raise TypeError("STSETrainStep drives an STSE with projector='linear'")
+        from .models.common.components import MLP
+        self.mlp = isinstance(model.btlnk, MLP)
+        if not isinstance(model, STSE) or not (isinstance(model.btlnk, torch.nn.Linear) or (self.mlp and model.btlnk.hip_ok)):
+            raise TypeError("STSETrainStep drives an STSE with projector='linear' or an 'mlp' within the kernels' widths")
         self.model, self.head, self.alpha = model, head, float(alpha)
         self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
         self.pg = process_group
@@ -122,8 +124,25 @@ class STSETrainStep:
         B = x.shape[0]
         U, ctx = engine.chain_forward(x, self.layers, True, self.ws, want_ctx=True)
         slope = self.layers[-1].slope
-        W, b = m.btlnk.weight, m.btlnk.bias
-        z = ops.btlnk_fwd(U, W, b, slope)
+        gv = self.fp.gviews
+        if self.mlp:
+            # mlp projector (components.py:209-226): wide Linear on the bottleneck kernel (PReLU on load), then every
+            # [BatchNorm1d, ReLU, Linear] block on csrc/mlp_head.hip; parameters and gradients stay in the flat buffers
+            first, wname = m.btlnk.net[0], "btlnk.net.0."
+            W, b = first.weight, first.bias
+            y = ops.btlnk_fwd(U, W, b, slope)
+            saved = []
+            for i, (bn, lin) in enumerate(m.btlnk.blocks()):
+                z, stat = ops.mlp_head_fwd(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                           lin.weight, lin.bias, True, momentum=bn.momentum if bn.momentum is not None else 0.1,
+                                           eps=bn.eps)
+                saved.append((y, stat, bn, lin, f"btlnk.net.{3 * i + 1}.", f"btlnk.net.{3 * i + 3}."))
+                y = z
+            z = y
+        else:
+            wname = "btlnk."
+            W, b = m.btlnk.weight, m.btlnk.bias
+            z = ops.btlnk_fwd(U, W, b, slope)
         if self.head == 'euclidean':
             stats, dz, _ = ops.mse_head(z, m.c, acc=self.center_acc)
         elif self.head == 'poincare':
@@ -132,10 +151,13 @@ class STSETrainStep:
             stats, dz, _ = ops.mahalanobis_head(z, m.c, m.inv_cov_matrix, acc=self.center_acc, gram=self.gram_acc)
         else:
             raise ValueError(f"unknown head {self.head}")
+        if self.mlp:
+            for y_in, stat, bn, lin, bname, lname in reversed(saved):
+                g = {"gamma": gv[bname + "weight"], "beta": gv[bname + "bias"], "W2": gv[lname + "weight"], "b2": gv.get(lname + "bias")}
+                dz = ops.mlp_head_bwd(y_in, stat, bn.weight, bn.bias, lin.weight, dz, g, True)
         K = W.shape[1]
         buf = self.ws.get(ops.btlnk_bwd_ws_bytes(B, K, W.shape[0]), x.device)
-        dU = ops.btlnk_bwd(U, W, dz, slope, self.fp.gviews["btlnk.weight"],
-                           self.fp.gviews.get("btlnk.bias"), self.grads[-1]["slope"], buf)
+        dU = ops.btlnk_bwd(U, W, dz, slope, gv[wname + "weight"], gv.get(wname + "bias"), self.grads[-1]["slope"], buf)
         work = None
         if self.world > 1 and self.tail_off is not None:
             # bucket 1 (87 % of the bytes: the bottleneck weight) is complete now: its all-reduce runs on the collective
@@ -267,7 +289,10 @@ class AutogradTrainStep:
 def make_train_step(model, **kw):
     """STSETrainStep when the model is the fused STS-GCN encoder + linear projector, AutogradTrainStep otherwise."""
     from .models.common.components import Encoder
-    fast = (isinstance(getattr(model, 'btlnk', None), torch.nn.Linear) and isinstance(getattr(model, 'encoder', None), Encoder)
+    from .models.common.components import MLP
+    btl = getattr(model, 'btlnk', None)
+    proj_ok = isinstance(btl, torch.nn.Linear) or (isinstance(btl, MLP) and btl.hip_ok)
+    fast = (proj_ok and isinstance(getattr(model, 'encoder', None), Encoder)
             and not any(l.is_wide for l in model.encoder.model) and model.latent_dim <= 16)
     if fast:
         return STSETrainStep(model, **kw)

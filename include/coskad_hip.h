@@ -107,6 +107,21 @@ int coskad_fused_encoder_out_floats(void);
 int coskad_fused_encoder_f32(const float* x, float* out, const float* tab, const float* wreg, const float* slopes, int B,
                              int T, int V, hipStream_t stream);
 
+/* ---- `mlp` projector tail (models/common/components.py:209-226 behind its first Linear, which runs on the bottleneck
+ * kernels): z = W2 . relu(BatchNorm1d(y1)) + b2 on y1 [B, H]; H, L <= 64.
+ * forward : training != 0 -> batch statistics (biased variance normalises, running_mean / running_var (unbiased) and
+ *           num_batches_tracked are updated in place; they may be NULL), else the running statistics.
+ *           stat [2H] receives (mean, 1/sqrt(var + eps)) for the backward.
+ * backward: dy1 [B,H], dgamma, dbeta [H], dW2 [L,H], db2 [L] (may be NULL); red: [2H] floats of scratch;
+ *           accumulate != 0 adds into the parameter gradients. */
+int coskad_mlp_head_fwd_f32(const float* y1, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, float momentum, float eps, int training,
+                            const float* W2, const float* b2, float* z, float* stat, int B, int H, int L,
+                            hipStream_t stream);
+int coskad_mlp_head_bwd_f32(const float* y1, const float* stat, const float* gamma, const float* beta, const float* W2,
+                            const float* dz, float* dy1, float* dgamma, float* dbeta, float* dW2, float* db2, float* red,
+                            int training, int accumulate, int B, int H, int L, hipStream_t stream);
+
 /* ---- backward of one ST_GCNN_layer (autograd of stsgcn.py:94-116 in training mode) ------ */
 
 size_t coskad_layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V);

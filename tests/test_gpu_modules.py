@@ -260,7 +260,8 @@ def test_autograd_train_step_matches_fast_path_and_handles_mlp():
         args.update(kw)
         m = STSE(2, [8, 4, 8], 8, 8, 12, 17, args['encoder_type'], args['projector'], 'euclidean', 0.0).cuda().train()
         eng = make_train_step(m, lr=1e-3, alpha=1e-6, head='euclidean')
-        assert isinstance(eng, AutogradTrainStep)
+        # the `mlp` projector (what 5 of the 7 reference yamls select) stays on the flat-buffer HIP step
+        assert isinstance(eng, STSETrainStep if kw.get('projector') == 'mlp' else AutogradTrainStep)
         l0 = float(eng.step(x)[0])
         for _ in range(5):
             l1 = float(eng.step(x)[0])
@@ -279,7 +280,8 @@ def test_eval_fold_cache_tracks_weight_changes(golden):
         z1 = m(x)                                   # served from the cache
         assert torch.equal(z0, z1)
         layer = m.encoder.model[1]
-        assert "fold" in layer.__dict__["_fold_cache"]
+        cache = layer.__dict__["_fold_cache"]
+        assert "fold" in cache or "fused" in cache      # per-layer fold, or the fused encoder's operand streams
         layer.tcn[1].running_var.mul_(1.5)          # in-place change of a BN buffer -> stale cache must not be used
         z2 = m(x)
         assert not torch.allclose(z0, z2)
@@ -322,3 +324,66 @@ def test_stsvae_v25_default_width_vs_reference_golden(golden):
     loss = ((xr - x) ** 2).mean() + kl_ps_uniform(q, p).mean() + (1 / kappa).mean()    # spherical_vae.py:81-107
     loss.backward()
     assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in m.parameters())
+
+
+@pytest.mark.parametrize("hidden", [None, [12, 10]])
+def test_mlp_projector_hip_path_vs_oracle(hidden):
+    """projector='mlp' (components.py:209-226 intent): wide Linear on the bottleneck kernels + [BatchNorm1d, ReLU, Linear]
+    blocks on csrc/mlp_head.hip.  Forward (train + eval), every gradient, running statistics and one optimisation step
+    against the CPU oracle (`ref_cpu.mlp`), through both the autograd surface and the flat-buffer STSETrainStep."""
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import STSETrainStep
+    from oracle import ref_cpu as R
+    torch.manual_seed(3)
+    kw = {} if hidden is None else dict(projector_hidden_layers=hidden)
+    m = STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'mlp', 'euclidean', 0.0, **kw)
+    with torch.no_grad():                         # non-trivial BN statistics / affine
+        for mod in m.btlnk.net:
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.add_(0.2 * torch.randn_like(mod.weight)); mod.bias.add_(0.1 * torch.randn_like(mod.bias))
+                mod.running_mean.add_(0.1 * torch.randn_like(mod.running_mean)); mod.running_var.mul_(1.3)
+    m.c.copy_(torch.linspace(-0.1, 0.1, 8))
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = R.synthetic_clips(40, seed=6)
+    m.cuda()
+    # eval forward
+    m.eval()
+    with torch.no_grad():
+        z = m(x.cuda())
+        z_ref = R.stse_encode(x, {k: v.clone() for k, v in st.items()}, training=False)
+    np.testing.assert_allclose(z.cpu().numpy(), z_ref.numpy(), rtol=1e-4, atol=1e-4)
+    # train forward + backward through the autograd surface
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
+    so = {k: v.clone() for k, v in st.items()}
+    so.update(params)
+    zo = R.stse_encode(x, so, training=True)
+    lo = R.mse_to_center(zo, st["c"])
+    lo.backward()
+    m.train()
+    zt = m(x.cuda())
+    np.testing.assert_allclose(zt.detach().cpu().numpy(), zo.detach().numpy(), rtol=2e-4, atol=2e-4)
+    loss = ((zt - m.c) ** 2).mean()
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-4)
+    gmax = max(float(p.grad.abs().max()) for p in params.values())
+    for n, p in m.named_parameters():
+        ref = params[n].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max() + 5e-5 * gmax, err_msg=n)
+    for k, v in so.items():                       # running statistics after the step (BatchNorm1d: unbiased variance)
+        if "running" in k or "num_batches" in k:
+            np.testing.assert_allclose(m.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    # the flat-buffer step: same loss and same parameters as torch Adam on the oracle's gradients
+    m2 = STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'mlp', 'euclidean', 0.0, **kw)
+    m2.load_state_dict(st, strict=True)
+    eng = STSETrainStep(m2.cuda().train(), lr=1e-3, alpha=0.0, head='euclidean')
+    stats = eng.step(x.cuda())
+    np.testing.assert_allclose(float(stats[0]), lo.item(), rtol=1e-4)
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    opt.step()
+    new = m2.state_dict()
+    for k, p in params.items():
+        if k.endswith(("tcn.0.bias", "residual.0.bias", "btlnk.net.0.bias")) or (k.startswith("btlnk.net.") and k.endswith("bias")
+                                                                                 and k[:-4] + "weight" in st and st[k[:-4] + "weight"].dim() == 2
+                                                                                 and k != max((q for q in st if q.startswith("btlnk.net.") and q.endswith(".bias") and st[q[:-4] + "weight"].dim() == 2))):
+            continue   # Linear biases in front of a train-mode BatchNorm: analytically zero gradient (autograd noise moves torch's Adam)
+        np.testing.assert_allclose(new[k].cpu().numpy(), p.detach().numpy(), rtol=2e-3, atol=3e-4, err_msg=k)
