@@ -2,10 +2,11 @@
 models/graph_layers/learnable_gcn.py:9-113 and gcn.py:8-99).
 
 A layer is `ReLU(A' . (X W) + b)` on X [B, T*V, C] with one dense (T*V x T*V) adjacency: learnable `softmax(Adj)` or the
-fixed row-normalised skeleton-in-time graph.  These are two plain GEMMs per layer (K = C and K = T*V = 204), so on
-MI355X they go to the GEMM library through torch.matmul (rocBLAS / hipBLASLt); the hand-written kernels of this repo
-are reserved for the fused STS-GCN path.  state_dict keys equal the reference's (`gcns.{i}.gcn.{weight,bias,Adj}`,
-buffer `Adj`)."""
+fixed row-normalised skeleton-in-time graph.  Here the activations stay in the [B, C, T*V] layout of the rest of the
+library (the reference's permutes at alternative_components.py:173-175 become strides), and both products, their
+gradients, the bias + ReLU epilogue and the adjacency softmax run on this repo's fp32 MFMA GEMM / elementwise kernels
+(csrc/gemm.hip) -- `_PlainGCNLayerFn` below.  The (T V x T V) mixing is applied on the narrower side of the layer
+(A'.(X W) = (A'.X) W).  state_dict keys equal the reference's (`gcns.{i}.gcn.{weight,bias,Adj}`, buffer `Adj`)."""
 from __future__ import annotations
 
 import math
@@ -15,7 +16,82 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import ops
+
 Tensor = torch.Tensor
+
+
+class _SoftmaxRowsFn(torch.autograd.Function):
+    """softmax over dim 1 of the learnable adjacency (learnable_gcn.py:36,66) on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, adj):
+        y = ops.softmax_rows(adj.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.softmax_rows_bwd(y, dy.contiguous())
+
+
+class _PlainGCNLayerFn(torch.autograd.Function):
+    """O[b] = relu(W^T . X[b] . A'^T + bias) on X [B, Ci, P] -> [B, Co, P]   (learnable_gcn.py:65-72 / gcn.py:48-54 + ReLU).
+
+    Forward and backward are strided GEMMs on csrc/gemm.hip: the channel product per clip (K = C), the position mixing as
+    ONE GEMM over all (clip, channel) rows (K = N = P), weight gradients as chunked reductions with fixed-order sums."""
+
+    @staticmethod
+    def forward(ctx, X, W, Ap, bias):
+        X = X.contiguous()
+        B, Ci, P = X.shape
+        Co = W.shape[1]
+        mix_first = Ci <= Co
+        if mix_first:       # Y = X . A'^T on Ci channels, then the channel product with bias + ReLU in its epilogue
+            Y = ops.gemm(X.view(B * Ci, P), Ap.t()).view(B, Ci, P)
+            O = ops.gemm(W.t(), Y, bias=bias, bias_mode=1 if bias is not None else 0, bias_mod=Co, relu=True)
+            ctx.save_for_backward(X, W, Ap, Y, O)
+        else:               # H = W^T . X on Co channels, then the mixing with bias (row % Co) + ReLU in its epilogue
+            H = ops.gemm(W.t(), X)
+            O = ops.gemm(H.view(B * Co, P), Ap.t(), bias=bias, bias_mode=1 if bias is not None else 0, bias_mod=Co,
+                         relu=True).view(B, Co, P)
+            ctx.save_for_backward(X, W, Ap, H, O)
+        ctx.mix_first, ctx.has_bias = mix_first, bias is not None
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        X, W, Ap, S, O = ctx.saved_tensors
+        B, Ci, P = X.shape
+        Co = W.shape[1]
+        need_x, need_w, need_a, need_b = ctx.needs_input_grad
+        db = torch.empty(Co, device=X.device, dtype=torch.float32) if (ctx.has_bias and need_b) else None
+        G = ops.relu_bwd(O, dO.contiguous(), db)                       # dO * (O > 0), bias gradient
+        dX = dW = dA = None
+
+        def adj_grad(Grows, Srows):      # dA'[p', p] = sum_r Grows[r, p'] * Srows[r, p] over all (clip, channel) rows
+            return ops.gemm_rows_outer(Grows, Srows, torch.empty(P, P, device=X.device, dtype=torch.float32))
+
+        if ctx.mix_first:
+            Y = S
+            if need_w:       # dW[c, o] = sum_b Y[b] . G[b]^T
+                dW = ops.gemm_reduce(Y, G.transpose(1, 2), torch.empty_like(W))
+            dY = ops.gemm(W, G)                                           # [B, Ci, P]
+            if need_a:
+                dA = adj_grad(dY.view(B * Ci, P), X.view(B * Ci, P))
+            if need_x:
+                dX = ops.gemm(dY.view(B * Ci, P), Ap).view(B, Ci, P)
+        else:
+            H = S
+            if need_a:
+                dA = adj_grad(G.view(B * Co, P), H.view(B * Co, P))
+            dH = ops.gemm(G.view(B * Co, P), Ap).view(B, Co, P)
+            if need_w:
+                dW = ops.gemm_reduce(X, dH.transpose(1, 2), torch.empty_like(W))
+            if need_x:
+                dX = ops.gemm(W, dH)
+        return dX, dW, dA, db
 
 
 class LearnableGraphConvBlock(nn.Module):
@@ -37,11 +113,8 @@ class LearnableGraphConvBlock(nn.Module):
             self.bias.data.uniform_(-stdv, stdv)
         self.Adj.data.uniform_(0.0, 1.0)
 
-    def forward(self, X: Tensor) -> Tensor:
-        X = torch.matmul(X, self.weight)                             # 'bij,jk->bik'
-        adj = torch.softmax(self.Adj, dim=1)                         # nn.Softmax() on a 2-D tensor: implicit dim=1 (:36,66)
-        X = torch.matmul(adj, X)                                     # 'ij,bjk->bik'
-        return X if self.bias is None else X + self.bias
+    def adjacency(self) -> Tensor:
+        return _SoftmaxRowsFn.apply(self.Adj)                        # nn.Softmax() on a 2-D tensor: implicit dim=1 (:36,66)
 
 
 class LearnablePlain_GCNN_Layer(nn.Module):
@@ -52,7 +125,8 @@ class LearnablePlain_GCNN_Layer(nn.Module):
         self.act = nn.ReLU()
 
     def forward(self, X: Tensor) -> Tensor:
-        return self.act(self.gcn(X))
+        """X [B, Ci, T*V] -> [B, Co, T*V] (bias + ReLU fused into the second GEMM's epilogue)."""
+        return _PlainGCNLayerFn.apply(X, self.gcn.weight, self.gcn.adjacency(), self.gcn.bias)
 
 
 class GraphConvBlock(nn.Module):
@@ -68,9 +142,6 @@ class GraphConvBlock(nn.Module):
         else:
             self.register_parameter('bias', None)
 
-    def forward(self, X: Tensor, Adj: Tensor) -> Tensor:
-        X = torch.matmul(Adj, torch.matmul(X, self.weight))
-        return X if self.bias is None else X + self.bias
 
 
 class StaticPlain_GCNN_Layer(nn.Module):
@@ -81,7 +152,7 @@ class StaticPlain_GCNN_Layer(nn.Module):
         self.act = nn.ReLU()
 
     def forward(self, X: Tensor, Adj: Tensor) -> Tensor:
-        return self.act(self.gcn(X, Adj))
+        return _PlainGCNLayerFn.apply(X, self.gcn.weight, Adj, self.gcn.bias)
 
 
 class _PlainGCNEncoder(nn.Module):
@@ -99,10 +170,10 @@ class _PlainGCNEncoder(nn.Module):
 
     def _run(self, X: Tensor, *extra) -> Tensor:
         B, C, T, V = X.size()
-        X = X.permute(0, 2, 3, 1).reshape(B, T * V, C)               # alternative_components.py:173-175
+        X = X.reshape(B, C, T * V)              # the reference's [B, T*V, C] (alternative_components.py:173-175) as strides
         for gcn in self.gcns:
             X = gcn(X, *extra)
-        return X.view(B, T, V, X.size(-1)).permute(0, 3, 1, 2).contiguous()
+        return X.view(B, X.size(1), T, V)
 
 
 class EncoderLearnablePlainGCN(_PlainGCNEncoder):

@@ -308,6 +308,120 @@ def btlnk_bwd(U, W, dz, slope, dW, db, dslope, ws, dU=None, accumulate=False):
     return dU
 
 
+def _cuda_f32(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.CoskadHipError(f"{name}: expected a CUDA (ROCm) tensor, got device {t.device}; no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+
+
+def _b3(t: Tensor):
+    """(tensor viewed as [batch, rows, cols], element strides) -- 2-D operands broadcast over the batch (stride 0)."""
+    if t.dim() == 2:
+        return 1, t.shape[0], t.shape[1], 0, t.stride(0), t.stride(1)
+    if t.dim() == 3:
+        return t.shape[0], t.shape[1], t.shape[2], t.stride(0), t.stride(1), t.stride(2)
+    raise ValueError("gemm operands are 2-D or 3-D")
+
+
+def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, bias: Optional[Tensor] = None, bias_mode: int = 0,
+         bias_mod: int = 1, relu: bool = False) -> Tensor:
+    """C[b] = act(A[b] @ B[b] + bias) on the fp32 MFMA GEMM kernel; A [.., M, K], B [.., K, N] may be ANY strided views
+    (transposes, broadcast batch): nothing is copied."""
+    _cuda_f32(A, "A"); _cuda_f32(B, "B")
+    ba, M, K, sab, sam, sak = _b3(A)
+    bb, K2, N, sbb, sbk, sbn = _b3(B)
+    if K != K2:
+        raise ValueError(f"gemm: inner sizes differ ({K} vs {K2})")
+    batch = max(ba, bb)
+    if ba not in (1, batch) or bb not in (1, batch):
+        raise ValueError("gemm: batch sizes do not broadcast")
+    if ba == 1:
+        sab = 0
+    if bb == 1:
+        sbb = 0
+    if out is None:
+        out = torch.empty((batch, M, N) if (A.dim() == 3 or B.dim() == 3) else (M, N), device=A.device, dtype=torch.float32)
+    _cuda_f32(out, "out")
+    bc, Mc, Nc, scb, scm, scn = _b3(out)
+    if (Mc, Nc) != (M, N) or bc != batch:
+        raise ValueError(f"gemm: out has shape {tuple(out.shape)}, expected batch {batch} x {M} x {N}")
+    _chk(bias, "bias", optional=True)
+    ll = ctypes.c_longlong
+    call("coskad_gemm_f32", ptr(A), ptr(B), ptr(out), ptr(bias), ll(sab), ll(sam), ll(sak), ll(sbb), ll(sbk), ll(sbn),
+         ll(scb), ll(scm), ll(scn), i32(M), i32(N), i32(K), i32(batch), i32(bias_mode), i32(bias_mod), i32(1 if relu else 0),
+         i32(0), i32(0), ll(0), _stream())
+    return out
+
+
+def gemm_reduce(A: Tensor, B: Tensor, out: Tensor, target_chunks: int = 64, ktotal: int = 0, accumulate: bool = False) -> Tensor:
+    """out (+)= sum_b A[b] @ B[b] (weight gradients): partial sums per batch chunk on the GEMM kernel, then a fixed-order
+    fp64 sum.  ktotal > 0: the reduction axis is one long axis cut into `batch` pieces of K (the last one partial)."""
+    _cuda_f32(A, "A"); _cuda_f32(B, "B"); _chk(out, "out")
+    ba, M, K, sab, sam, sak = _b3(A)
+    bb, K2, N, sbb, sbk, sbn = _b3(B)
+    if K != K2 or ba != bb or tuple(out.shape) != (M, N):
+        raise ValueError("gemm_reduce: shape mismatch")
+    chunk = max(1, (ba + target_chunks - 1) // target_chunks)
+    chunks = (ba + chunk - 1) // chunk
+    part = torch.empty(chunks, M, N, device=A.device, dtype=torch.float32)
+    ll = ctypes.c_longlong
+    call("coskad_gemm_f32", ptr(A), ptr(B), ptr(part), ptr(None), ll(sab), ll(sam), ll(sak), ll(sbb), ll(sbk), ll(sbn),
+         ll(0), ll(0), ll(0), i32(M), i32(N), i32(K), i32(ba), i32(0), i32(1), i32(0), i32(1), i32(chunk), ll(ktotal), _stream())
+    call("coskad_gemm_sum_f32", ptr(part), i32(chunks), ctypes.c_size_t(M * N), ptr(out), i32(1 if accumulate else 0), _stream())
+    return out
+
+
+def gemm_rows_outer(G: Tensor, S: Tensor, out: Tensor, rows_per_piece: int = 256, target_chunks: int = 64,
+                    accumulate: bool = False) -> Tensor:
+    """out[m, n] (+)= sum_r G[r, m] * S[r, n] for row-major G [R, M], S [R, N]: the long reduction axis r is cut into pieces
+    of `rows_per_piece` (the kernel's batch axis, the last piece guarded by ktotal = R), pieces are summed per chunk."""
+    R, M = G.shape
+    R2, N = S.shape
+    _chk(G, "G"); _chk(S, "S"); _chk(out, "out", (M, N))
+    if R != R2:
+        raise ValueError("gemm_rows_outer: row counts differ")
+    nb = (R + rows_per_piece - 1) // rows_per_piece
+    chunk = max(1, (nb + target_chunks - 1) // target_chunks)
+    chunks = (nb + chunk - 1) // chunk
+    part = torch.empty(chunks, M, N, device=G.device, dtype=torch.float32)
+    ll = ctypes.c_longlong
+    call("coskad_gemm_f32", ptr(G), ptr(S), ptr(part), ptr(None), ll(rows_per_piece * M), ll(1), ll(M),
+         ll(rows_per_piece * N), ll(N), ll(1), ll(0), ll(0), ll(0), i32(M), i32(N), i32(rows_per_piece), i32(nb), i32(0), i32(1),
+         i32(0), i32(1), i32(chunk), ll(R), _stream())
+    call("coskad_gemm_sum_f32", ptr(part), i32(chunks), ctypes.c_size_t(M * N), ptr(out), i32(1 if accumulate else 0), _stream())
+    return out
+
+
+def relu_bwd(out: Tensor, dout: Tensor, dbias: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """g = dout * (out > 0) on [N, C, P]; dbias[c] (+)= sum of g over (n, p)."""
+    Nb, C, P = out.shape
+    _chk(out, "out"); _chk(dout, "dout", (Nb, C, P)); _chk(dbias, "dbias", (C,), optional=True)
+    g = torch.empty_like(out)
+    slices = min(Nb, 64)
+    part = torch.empty(slices, C, device=out.device, dtype=torch.float32)
+    call("coskad_relu_bwd_f32", ptr(out), ptr(dout), ptr(g), ptr(part), i32(Nb), i32(C), i32(P), i32(slices), _stream())
+    if dbias is not None:
+        call("coskad_gemm_sum_f32", ptr(part), i32(slices), ctypes.c_size_t(C), ptr(dbias), i32(1 if accumulate else 0), _stream())
+    return g
+
+
+def softmax_rows(x: Tensor) -> Tensor:
+    n = x.shape[0]
+    _chk(x, "x", (n, n))
+    y = torch.empty_like(x)
+    call("coskad_softmax_rows_f32", ptr(x), ptr(y), i32(n), _stream())
+    return y
+
+
+def softmax_rows_bwd(y: Tensor, dy: Tensor) -> Tensor:
+    n = y.shape[0]
+    _chk(y, "y", (n, n)); _chk(dy, "dy", (n, n))
+    dx = torch.empty_like(y)
+    call("coskad_softmax_rows_bwd_f32", ptr(y), ptr(dy), ptr(dx), i32(n), _stream())
+    return dx
+
+
 def mlp_head_fwd(y1, gamma, beta, running_mean, running_var, nbt, W2, b2, training: bool, momentum: float = 0.1,
                  eps: float = 1e-5):
     """z = W2 . relu(BatchNorm1d(y1)) + b2 (the `mlp` projector behind its first Linear, components.py:209-226).

@@ -107,6 +107,23 @@ int coskad_fused_encoder_out_floats(void);
 int coskad_fused_encoder_f32(const float* x, float* out, const float* tab, const float* wreg, const float* slopes, int B,
                              int T, int V, hipStream_t stream);
 
+/* ---- strided batched fp32 GEMM (plain-GCN encoders: learnable_gcn.py:65-72, gcn.py:48-54; 1x1 convs of wide layers) ----
+ * C[b][m][n] = act(sum_k A[b][m][k] B[b][k][n] + bias), every operand addressed by element strides (s?_b may be 0).
+ * bias_mode: 0 none, 1 bias[m % bias_mod], 2 bias[n];  relu != 0: max(., 0).
+ * reduce != 0: C receives partial sums [ceil(batch / chunk)][M][N] (contiguous) over the batches of each chunk -- sum them
+ *              with coskad_gemm_sum_f32 (fp64, fixed order).  ktotal > 0: element (b, k) exists iff b*K + k < ktotal. */
+int coskad_gemm_f32(const float* A, const float* B, float* C, const float* bias, long long sa_b, long long sa_m,
+                    long long sa_k, long long sb_b, long long sb_k, long long sb_n, long long sc_b, long long sc_m,
+                    long long sc_n, int M, int N, int K, int batch, int bias_mode, int bias_mod, int relu, int reduce,
+                    int chunk, long long ktotal, hipStream_t stream);
+int coskad_gemm_sum_f32(const float* partials, int chunks, size_t E, float* out, int accumulate, hipStream_t stream);
+/* g = dout * (out > 0) on [Nb, C, P]; part [slices][C]: per-slice channel sums of g (bias gradient partials) */
+int coskad_relu_bwd_f32(const float* out, const float* dout, float* g, float* part, int Nb, int C, int P, int slices,
+                        hipStream_t stream);
+/* row softmax of an n x n matrix (nn.Softmax() on the 2-D learnable adjacency, learnable_gcn.py:36,66) and its backward */
+int coskad_softmax_rows_f32(const float* x, float* y, int n, hipStream_t stream);
+int coskad_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, int n, hipStream_t stream);
+
 /* ---- `mlp` projector tail (models/common/components.py:209-226 behind its first Linear, which runs on the bottleneck
  * kernels): z = W2 . relu(BatchNorm1d(y1)) + b2 on y1 [B, H]; H, L <= 64.
  * forward : training != 0 -> batch statistics (biased variance normalises, running_mean / running_var (unbiased) and

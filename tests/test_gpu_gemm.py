@@ -1,0 +1,81 @@
+"""The strided fp32 MFMA GEMM (csrc/gemm.hip) and its companions against float64 torch on the CPU: ragged sizes, transposed
+/ broadcast / non-contiguous operand views, bias modes, ReLU, chunked reductions (weight gradients) with a partial last
+piece, ReLU backward with channel sums, row softmax forward / backward."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(A, B):
+    return torch.matmul(A.double().cpu(), B.double().cpu())
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(64, 64, 16, 1), (37, 204, 204, 1), (16, 204, 2, 5), (130, 70, 33, 3), (1, 1, 1, 2)])
+def test_gemm_shapes_and_views(M, N, K, batch):
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    A = torch.randn(batch, M, K, generator=g).cuda()
+    B = torch.randn(batch, K, N, generator=g).cuda()
+    tol = dict(rtol=1e-5, atol=1e-5 * K ** 0.5)
+    np.testing.assert_allclose(ops.gemm(A, B).cpu().numpy(), _ref(A, B).numpy(), **tol)
+    # transposed views (k not contiguous in A, n not contiguous in B), broadcast 2-D operands
+    At = torch.randn(batch, K, M, generator=g).cuda()
+    Bt = torch.randn(batch, N, K, generator=g).cuda()
+    np.testing.assert_allclose(ops.gemm(At.transpose(1, 2), Bt.transpose(1, 2)).cpu().numpy(),
+                               _ref(At.transpose(1, 2), Bt.transpose(1, 2)).numpy(), **tol)
+    W = torch.randn(M, K, generator=g).cuda()
+    np.testing.assert_allclose(ops.gemm(W, B).cpu().numpy(), _ref(W, B).numpy(), **tol)
+    W2 = torch.randn(K, N, generator=g).cuda()
+    np.testing.assert_allclose(ops.gemm(A, W2).cpu().numpy(), _ref(A, W2).numpy(), **tol)
+    # epilogues: bias per row (modulo), per column, ReLU
+    bm = torch.randn(max(1, M // 2 if M % 2 == 0 else M), generator=g).cuda()
+    mod = bm.numel()
+    got = ops.gemm(A, B, bias=bm, bias_mode=1, bias_mod=mod, relu=True).cpu()
+    want = torch.relu(_ref(A, B) + bm.double().cpu()[torch.arange(M) % mod][:, None])
+    np.testing.assert_allclose(got.numpy(), want.numpy(), **tol)
+    bn = torch.randn(N, generator=g).cuda()
+    np.testing.assert_allclose(ops.gemm(A, B, bias=bn, bias_mode=2).cpu().numpy(), (_ref(A, B) + bn.double().cpu()).numpy(), **tol)
+    # strided output view
+    out = torch.zeros(batch, M, 2 * N, device="cuda")
+    ops.gemm(A, B, out=out[:, :, ::2])
+    np.testing.assert_allclose(out[:, :, ::2].cpu().numpy(), _ref(A, B).numpy(), **tol)
+    assert float(out[:, :, 1::2].abs().max()) == 0.0
+
+
+def test_gemm_reductions():
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(7)
+    Bn, Ci, Co, P = 150, 8, 20, 204
+    Y = torch.randn(Bn, Ci, P, generator=g).cuda()
+    G = torch.randn(Bn, Co, P, generator=g).cuda()
+    dW = ops.gemm_reduce(Y, G.transpose(1, 2), torch.empty(Ci, Co, device="cuda"))
+    want = torch.matmul(Y.double().cpu(), G.double().cpu().transpose(1, 2)).sum(0)
+    np.testing.assert_allclose(dW.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-3)
+    acc = ops.gemm_reduce(Y, G.transpose(1, 2), dW.clone(), accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), 2 * want.numpy(), rtol=1e-5, atol=2e-3)
+    # one long reduction axis cut into pieces of 256 rows, the last one partial (1200 = 4 * 256 + 176)
+    R = Bn * Ci
+    Gr, Sr = torch.randn(R, P, generator=g).cuda(), torch.randn(R, P, generator=g).cuda()
+    dA = ops.gemm_rows_outer(Gr, Sr, torch.empty(P, P, device="cuda"))
+    np.testing.assert_allclose(dA.cpu().numpy(), (Gr.double().cpu().t() @ Sr.double().cpu()).numpy(), rtol=1e-5, atol=2e-3)
+
+
+def test_relu_bwd_and_softmax():
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(3)
+    O = torch.randn(70, 12, 204, generator=g).cuda()
+    dO = torch.randn(70, 12, 204, generator=g).cuda()
+    db = torch.empty(12, device="cuda")
+    G = ops.relu_bwd(O, dO, db)
+    want = dO.cpu() * (O.cpu() > 0)
+    assert torch.equal(G.cpu(), want)
+    np.testing.assert_allclose(db.cpu().numpy(), want.double().sum((0, 2)).numpy(), rtol=1e-5, atol=1e-4)
+    x = torch.rand(204, 204, generator=g).cuda()
+    y = ops.softmax_rows(x)
+    np.testing.assert_allclose(y.cpu().numpy(), torch.softmax(x.cpu().double(), 1).numpy(), rtol=1e-5, atol=1e-8)
+    dy = torch.randn(204, 204, generator=g).cuda()
+    xr = x.cpu().double().requires_grad_(True)
+    (torch.softmax(xr, 1) * dy.cpu().double()).sum().backward()
+    np.testing.assert_allclose(ops.softmax_rows_bwd(y, dy).cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-7)
