@@ -31,6 +31,7 @@ struct Args {
   int reduce;         // != 0: sum over the batches of a chunk, C = partials [chunks][M][N] (contiguous)
   int chunk;          // batches per chunk (reduce mode)
   long long ktotal;   // > 0: element (b, k) exists iff b * K + k < ktotal  (a long reduction axis cut into `batch` pieces)
+  int accum;          // != 0 (non-reduce): C += result
 };
 
 __global__ __launch_bounds__(256) void k_gemm(Args a) {
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void k_gemm(Args a) {
             if (a.bias_mode == 1) v += a.bias[m % a.bias_mod];
             else if (a.bias_mode == 2) v += a.bias[n];
             if (a.relu) v = v > 0.f ? v : 0.f;
+            if (a.accum) v += Cb[(long long)m * scm + (long long)n * scn];
           }
           Cb[(long long)m * scm + (long long)n * scn] = v;
         }
@@ -209,14 +211,14 @@ extern "C" {
 int coskad_gemm_f32(const float* A, const float* B, float* C, const float* bias, long long sa_b, long long sa_m,
                     long long sa_k, long long sb_b, long long sb_k, long long sb_n, long long sc_b, long long sc_m,
                     long long sc_n, int M, int N, int K, int batch, int bias_mode, int bias_mod, int relu, int reduce,
-                    int chunk, long long ktotal, hipStream_t stream) {
+                    int chunk, long long ktotal, int accum, hipStream_t stream) {
   if (!A || !B || !C) return fail(COSKAD_ERR_ARG, "gemm: null pointer");
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return fail(COSKAD_ERR_ARG, "gemm: M=%d N=%d K=%d batch=%d", M, N, K, batch);
   if (bias_mode && !bias) return fail(COSKAD_ERR_ARG, "gemm: bias_mode %d without bias", bias_mode);
   if (bias_mode == 1 && bias_mod <= 0) return fail(COSKAD_ERR_ARG, "gemm: bias_mod=%d", bias_mod);
   if (reduce && chunk <= 0) return fail(COSKAD_ERR_ARG, "gemm: reduce mode needs chunk > 0");
   gemm::Args a{A, B, C, bias, sa_b, sa_m, sa_k, sb_b, sb_k, sb_n, sc_b, sc_m, sc_n, M, N, K, batch, bias_mode, bias_mod, relu,
-               reduce, chunk, ktotal};
+               reduce, chunk, ktotal, accum};
   const int gz = reduce ? ceil_div(batch, chunk) : batch;
   if (gz > 65535) return fail(COSKAD_ERR_SHAPE, "gemm: %d batches/chunks exceed the grid limit", gz);
   hipLaunchKernelGGL(gemm::k_gemm, dim3(ceil_div(N, gemm::BN), ceil_div(M, gemm::BM), gz), dim3(256), 0, stream, a);

@@ -139,6 +139,56 @@ class _PReLUFn(torch.autograd.Function):
         return du, dslope
 
 
+class _WideLayerFn(torch.autograd.Function):
+    """out = PReLU(BN_t(Wt . gcn(X) + bt) + BN_r(Wr . X + br))  (identity residual when Wr is None) for one wide layer."""
+
+    @staticmethod
+    def forward(ctx, X, A, T, Wt, bt, gt, bet, Wr, br, gr, ber, slope, bn_t, bn_r, training):
+        X = X.contiguous()
+        B, Ci, Tn, V = X.shape
+        Co, P = Wt.shape[0], Tn * V
+        Z = ops.gcn(X, A.contiguous(), T.contiguous(), adjoint=False)
+        Wt2 = Wt.view(Co, Ci)
+        Ct = ops.gemm(Wt2, Z.view(B, Ci, P), bias=bt, bias_mode=1 if bt is not None else 0, bias_mod=Co)
+        st_t = ops.bn2_stats(Ct, bn_t, training)
+        if Wr is not None:
+            Cr = ops.gemm(Wr.view(Co, Ci), X.view(B, Ci, P), bias=br, bias_mode=1 if br is not None else 0, bias_mod=Co)
+            st_r = ops.bn2_stats(Cr, bn_r, training)
+        else:
+            Cr, st_r = X.view(B, Ci, P), None
+        out = ops.bn2_apply_prelu(Ct, Cr, st_t, gt, bet, st_r, gr, ber, slope)
+        ctx.save_for_backward(X, Z, A, T, Wt, gt, bet, Wr, gr, ber, slope, Ct, Cr if Wr is not None else None, st_t, st_r)
+        ctx.training, ctx.has_bt, ctx.has_br = training, bt is not None, br is not None
+        return out.view(B, Co, Tn, V)
+
+    @staticmethod
+    def backward(ctx, dOut):
+        X, Z, A, T, Wt, gt, bet, Wr, gr, ber, slope, Ct, Cr, st_t, st_r = ctx.saved_tensors
+        B, Ci, Tn, V = X.shape
+        Co, P = Wt.shape[0], Tn * V
+        Xv = X.view(B, Ci, P)
+        Crv = Cr if Cr is not None else Xv
+        dCt, dCr, dgt, dbet, dgr, dber, dslope = ops.bn2_bwd(Ct, Crv, dOut.contiguous().view(B, Co, P), st_t, gt, bet, st_r, gr, ber,
+                                                             slope, ctx.training)
+        Wt2 = Wt.view(Co, Ci)
+        dWt = ops.gemm_reduce(dCt, Z.view(B, Ci, P).transpose(1, 2), torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
+        dZ = ops.gemm(Wt2.t(), dCt).view(B, Ci, Tn, V)
+        dX = ops.gcn(dZ, A, T, adjoint=True)
+        dA, dT = ops.gcn_bwd_params(X, dZ, A, T)
+        dWr = dbr = None
+        if Wr is not None:
+            dWr = ops.gemm_reduce(dCr, Xv.transpose(1, 2), torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
+            ops.gemm(Wr.view(Co, Ci).t(), dCr, out=dX.view(B, Ci, P), accumulate=True)
+            if ctx.has_br:      # a bias in front of a BatchNorm: its gradient is the sum of a mean-free tensor (exactly 0 in training)
+                dbr = dCr.sum((0, 2)) if not ctx.training else torch.zeros(Co, device=X.device, dtype=torch.float32)
+        else:
+            dX = dX + dCr.view(B, Ci, Tn, V)
+        dbt = None
+        if ctx.has_bt:
+            dbt = dCt.sum((0, 2)) if not ctx.training else torch.zeros(Co, device=X.device, dtype=torch.float32)
+        return (dX, dA, dT, dWt.view_as(Wt), dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope.view_as(slope), None, None, None)
+
+
 class ST_GCNN_layer(nn.Module):
     """Space-Time-Separable graph-conv block (reference stsgcn.py:9-116):
     out = PReLU( BN(Conv1x1(gcn(X))) + residual(X) ),  residual = BN(Conv1x1(X)) or identity."""
@@ -189,14 +239,18 @@ class ST_GCNN_layer(nn.Module):
         return not _FITS[key]
 
     def forward_wide(self, X: Tensor) -> Tensor:
-        """Wide layers (the C = 2 -> 256 stack of BASELINE.json's north_star): the block is GEMM-dominated, so it runs
-        as the HIP mixing kernel (with its adjoint / parameter-gradient kernels) + the 1x1 convolutions on the GEMM /
-        convolution library + torch's BatchNorm / PReLU kernels -- the reference's own composition (stsgcn.py:106-110)
-        with its einsums replaced.  X is the post-activation input."""
-        Z = self.gcn(X)
-        out = self.tcn[1](self.tcn[0](Z))      # nn.Conv2d 1x1 (its weight-gradient GEMM beats a batched matmul + sum here)
-        res = X if isinstance(self.residual, nn.Identity) else self.residual(X)
-        return self.prelu(out + res)
+        """Layers beyond the LDS-resident tile kernels (the C = 2 -> 256 stack of BASELINE.json's north_star; 64 input
+        channels on the 25-joint layout): the reference's composition (stsgcn.py:106-110) on this repo's kernels in the
+        native NCHW layout -- mixing (coskad_gcn_f32 + adjoint + dA/dT), both 1x1 convolutions and their gradients on the
+        strided MFMA GEMM (csrc/gemm.hip), BatchNorm statistics / normalise + residual add + PReLU and their backward on
+        csrc/wide.hip.  X is the post-activation input; returns the activated output."""
+        has_res = not isinstance(self.residual, nn.Identity)
+        tc, tb = self.tcn[0], self.tcn[1]
+        rc, rb = (self.residual[0], self.residual[1]) if has_res else (None, None)
+        return _WideLayerFn.apply(X, self.gcn.A, self.gcn.T, tc.weight, tc.bias, tb.weight, tb.bias,
+                                  rc.weight if has_res else None, rc.bias if has_res else None,
+                                  rb.weight if has_res else None, rb.bias if has_res else None, self.prelu.weight,
+                                  tb, rb, self.training)
 
     def forward(self, X: Tensor, t: Tensor = None) -> Tensor:
         if self.is_wide:

@@ -325,7 +325,7 @@ def _b3(t: Tensor):
 
 
 def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, bias: Optional[Tensor] = None, bias_mode: int = 0,
-         bias_mod: int = 1, relu: bool = False) -> Tensor:
+         bias_mod: int = 1, relu: bool = False, accumulate: bool = False) -> Tensor:
     """C[b] = act(A[b] @ B[b] + bias) on the fp32 MFMA GEMM kernel; A [.., M, K], B [.., K, N] may be ANY strided views
     (transposes, broadcast batch): nothing is copied."""
     _cuda_f32(A, "A"); _cuda_f32(B, "B")
@@ -350,7 +350,7 @@ def gemm(A: Tensor, B: Tensor, out: Optional[Tensor] = None, bias: Optional[Tens
     ll = ctypes.c_longlong
     call("coskad_gemm_f32", ptr(A), ptr(B), ptr(out), ptr(bias), ll(sab), ll(sam), ll(sak), ll(sbb), ll(sbk), ll(sbn),
          ll(scb), ll(scm), ll(scn), i32(M), i32(N), i32(K), i32(batch), i32(bias_mode), i32(bias_mod), i32(1 if relu else 0),
-         i32(0), i32(0), ll(0), _stream())
+         i32(0), i32(0), ll(0), i32(1 if accumulate else 0), _stream())
     return out
 
 
@@ -367,7 +367,7 @@ def gemm_reduce(A: Tensor, B: Tensor, out: Tensor, target_chunks: int = 64, ktot
     part = torch.empty(chunks, M, N, device=A.device, dtype=torch.float32)
     ll = ctypes.c_longlong
     call("coskad_gemm_f32", ptr(A), ptr(B), ptr(part), ptr(None), ll(sab), ll(sam), ll(sak), ll(sbb), ll(sbk), ll(sbn),
-         ll(0), ll(0), ll(0), i32(M), i32(N), i32(K), i32(ba), i32(0), i32(1), i32(0), i32(1), i32(chunk), ll(ktotal), _stream())
+         ll(0), ll(0), ll(0), i32(M), i32(N), i32(K), i32(ba), i32(0), i32(1), i32(0), i32(1), i32(chunk), ll(ktotal), i32(0), _stream())
     call("coskad_gemm_sum_f32", ptr(part), i32(chunks), ctypes.c_size_t(M * N), ptr(out), i32(1 if accumulate else 0), _stream())
     return out
 
@@ -388,7 +388,7 @@ def gemm_rows_outer(G: Tensor, S: Tensor, out: Tensor, rows_per_piece: int = 256
     ll = ctypes.c_longlong
     call("coskad_gemm_f32", ptr(G), ptr(S), ptr(part), ptr(None), ll(rows_per_piece * M), ll(1), ll(M),
          ll(rows_per_piece * N), ll(N), ll(1), ll(0), ll(0), ll(0), i32(M), i32(N), i32(rows_per_piece), i32(nb), i32(0), i32(1),
-         i32(0), i32(1), i32(chunk), ll(R), _stream())
+         i32(0), i32(1), i32(chunk), ll(R), i32(0), _stream())
     call("coskad_gemm_sum_f32", ptr(part), i32(chunks), ctypes.c_size_t(M * N), ptr(out), i32(1 if accumulate else 0), _stream())
     return out
 
@@ -420,6 +420,50 @@ def softmax_rows_bwd(y: Tensor, dy: Tensor) -> Tensor:
     dx = torch.empty_like(y)
     call("coskad_softmax_rows_bwd_f32", ptr(y), ptr(dy), ptr(dx), i32(n), _stream())
     return dx
+
+
+def _bn2_ws(Nb: int, C: int, device, bwd: bool = False) -> Tensor:
+    fn = getattr(_lib.lib(), "coskad_bn2_bwd_ws_bytes" if bwd else "coskad_bn2_ws_bytes")
+    fn.restype = ctypes.c_size_t
+    return torch.empty(fn(i32(Nb), i32(C)), dtype=torch.uint8, device=device)
+
+
+def bn2_stats(x: Tensor, bn, training: bool) -> Tensor:
+    """Per-channel (mean, invstd) of x [N, C, P] for nn.BatchNorm2d `bn`: batch statistics (+ running update) in training
+    mode, the running statistics otherwise."""
+    Nb, C, P = x.shape
+    _chk(x, "x")
+    stat = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    ws = _bn2_ws(Nb, C, x.device)
+    call("coskad_bn2_stats_f32", ptr(x), ptr(stat), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+         ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps), i32(1 if training else 0),
+         ptr(ws), ctypes.c_size_t(ws.numel()), i32(Nb), i32(C), i32(P), _stream())
+    return stat
+
+
+def bn2_apply_prelu(Ct, Cr, stat_t, gt, bt, stat_r, gr, br, slope) -> Tensor:
+    Nb, C, P = Ct.shape
+    _chk(Ct, "Ct"); _chk(Cr, "Cr", (Nb, C, P)); _chk(stat_t, "stat_t", (2 * C,)); _chk(stat_r, "stat_r", (2 * C,), optional=True)
+    out = torch.empty_like(Ct)
+    call("coskad_bn2_apply_prelu_f32", ptr(Ct), ptr(Cr), ptr(stat_t), ptr(gt), ptr(bt), ptr(stat_r), ptr(gr), ptr(br), ptr(slope),
+         ptr(out), i32(Nb), i32(C), i32(P), _stream())
+    return out
+
+
+def bn2_bwd(Ct, Cr, dOut, stat_t, gt, bt, stat_r, gr, br, slope, training: bool):
+    """-> (dCt, dCr, dgt, dbt, dgr, dbr, dslope) (residual gradients None for an identity residual)."""
+    Nb, C, P = Ct.shape
+    _chk(dOut, "dOut", (Nb, C, P))
+    dCt, dCr = torch.empty_like(Ct), torch.empty_like(Ct)
+    dgt, dbt = torch.empty_like(gt), torch.empty_like(bt)
+    dgr = torch.empty_like(gr) if stat_r is not None else None
+    dbr = torch.empty_like(br) if stat_r is not None else None
+    dslope = torch.empty(1, device=Ct.device, dtype=torch.float32)
+    ws = _bn2_ws(Nb, C, Ct.device, bwd=True)
+    call("coskad_bn2_bwd_f32", ptr(Ct), ptr(Cr), ptr(dOut), ptr(stat_t), ptr(gt), ptr(bt), ptr(stat_r), ptr(gr), ptr(br), ptr(slope),
+         ptr(dCt), ptr(dCr), ptr(dgt), ptr(dbt), ptr(dgr), ptr(dbr), ptr(dslope), i32(1 if training else 0), ptr(ws),
+         ctypes.c_size_t(ws.numel()), i32(Nb), i32(C), i32(P), _stream())
+    return dCt, dCr, dgt, dbt, dgr, dbr, dslope
 
 
 def mlp_head_fwd(y1, gamma, beta, running_mean, running_var, nbt, W2, b2, training: bool, momentum: float = 0.1,

@@ -111,11 +111,12 @@ int coskad_fused_encoder_f32(const float* x, float* out, const float* tab, const
  * C[b][m][n] = act(sum_k A[b][m][k] B[b][k][n] + bias), every operand addressed by element strides (s?_b may be 0).
  * bias_mode: 0 none, 1 bias[m % bias_mod], 2 bias[n];  relu != 0: max(., 0).
  * reduce != 0: C receives partial sums [ceil(batch / chunk)][M][N] (contiguous) over the batches of each chunk -- sum them
- *              with coskad_gemm_sum_f32 (fp64, fixed order).  ktotal > 0: element (b, k) exists iff b*K + k < ktotal. */
+ *              with coskad_gemm_sum_f32 (fp64, fixed order).  ktotal > 0: element (b, k) exists iff b*K + k < ktotal.
+ * accum != 0 (reduce == 0): C += the product (after bias / ReLU). */
 int coskad_gemm_f32(const float* A, const float* B, float* C, const float* bias, long long sa_b, long long sa_m,
                     long long sa_k, long long sb_b, long long sb_k, long long sb_n, long long sc_b, long long sc_m,
                     long long sc_n, int M, int N, int K, int batch, int bias_mode, int bias_mod, int relu, int reduce,
-                    int chunk, long long ktotal, hipStream_t stream);
+                    int chunk, long long ktotal, int accum, hipStream_t stream);
 int coskad_gemm_sum_f32(const float* partials, int chunks, size_t E, float* out, int accumulate, hipStream_t stream);
 /* g = dout * (out > 0) on [Nb, C, P]; part [slices][C]: per-slice channel sums of g (bias gradient partials) */
 int coskad_relu_bwd_f32(const float* out, const float* dout, float* g, float* part, int Nb, int C, int P, int slices,
@@ -123,6 +124,22 @@ int coskad_relu_bwd_f32(const float* out, const float* dout, float* g, float* pa
 /* row softmax of an n x n matrix (nn.Softmax() on the 2-D learnable adjacency, learnable_gcn.py:36,66) and its backward */
 int coskad_softmax_rows_f32(const float* x, float* y, int n, hipStream_t stream);
 int coskad_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, int n, hipStream_t stream);
+
+/* ---- BatchNorm2d + residual add + PReLU of an ST_GCNN layer on [Nb, C, P] tensors (stsgcn.py:56-80,106-110), for layers
+ * beyond the LDS-resident tile kernels (their 1x1 convolutions are coskad_gemm_f32, their mixing coskad_gcn_f32).
+ * stat [2C] = (mean, 1/sqrt(var + eps)); stat_r == NULL: identity residual.  ws: coskad_bn2_ws_bytes / _bwd_ws_bytes. */
+size_t coskad_bn2_ws_bytes(int Nb, int C);
+size_t coskad_bn2_bwd_ws_bytes(int Nb, int C);
+int coskad_bn2_stats_f32(const float* x, float* stat, float* running_mean, float* running_var, long long* num_batches_tracked,
+                         float momentum, float eps, int training, void* ws, size_t ws_bytes, int Nb, int C, int P,
+                         hipStream_t stream);
+int coskad_bn2_apply_prelu_f32(const float* Ct, const float* Cr, const float* stat_t, const float* gamma_t, const float* beta_t,
+                               const float* stat_r, const float* gamma_r, const float* beta_r, const float* slope, float* out,
+                               int Nb, int C, int P, hipStream_t stream);
+int coskad_bn2_bwd_f32(const float* Ct, const float* Cr, const float* dOut, const float* stat_t, const float* gamma_t,
+                       const float* beta_t, const float* stat_r, const float* gamma_r, const float* beta_r, const float* slope,
+                       float* dCt, float* dCr, float* dgamma_t, float* dbeta_t, float* dgamma_r, float* dbeta_r, float* dslope,
+                       int training, void* ws, size_t ws_bytes, int Nb, int C, int P, hipStream_t stream);
 
 /* ---- `mlp` projector tail (models/common/components.py:209-226 behind its first Linear, which runs on the bottleneck
  * kernels): z = W2 . relu(BatchNorm1d(y1)) + b2 on y1 [B, H]; H, L <= 64.

@@ -199,7 +199,8 @@ def test_split_backward_on_side_stream_is_bit_identical(golden):
 
 def test_wide_stack_c256_vs_oracle():
     """The C = 2 -> 256 stack of the north_star wording (channels [64, 128, 256], h_dim 256): layer 1 on the fused
-    kernels, the wider layers on the HIP mixing kernel + library GEMMs; outputs and gradients against the oracle."""
+    kernels, the wider layers on the mixing kernels + the strided MFMA GEMM (1x1 convolutions and their gradients) + the
+    BatchNorm / residual / PReLU kernels of csrc/wide.hip; outputs, every gradient and the running statistics against the oracle."""
     from coskad_amd.models.sts.ae import STSE
     from oracle import ref_cpu as R
     st = R.init_stse_state(2, (64, 128, 256), 256, 16, 12, 17, seed=2)
@@ -231,6 +232,9 @@ def test_wide_stack_c256_vs_oracle():
             continue
         ref = params[k].grad.numpy()
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-3, atol=1e-3 * np.abs(ref).max() + 1e-9, err_msg=k)
+    for k, v in sto.items():
+        if "running" in k or "num_batches" in k:
+            np.testing.assert_allclose(m.state_dict()[k].cpu().numpy(), v.detach().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 
 
 def test_autograd_train_step_matches_fast_path_and_handles_mlp():

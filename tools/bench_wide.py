@@ -1,6 +1,6 @@
 """Throughput of the wide stack of the north_star wording (C = 2 -> 256: channels [64, 128, 256], h_dim 256, latent 16)
 on one GPU: train step = forward + MSE-to-centre + backward + Adam through the module surface (autograd).  Layer 1 runs on
-the fused kernels, the wider layers on the HIP mixing kernel + library GEMMs (coskad_amd ST_GCNN_layer.forward_wide).
+the fused kernels, the wider layers on the mixing kernels + the strided MFMA GEMM + csrc/wide.hip (ST_GCNN_layer.forward_wide).
 Not the judged bench (bench.py keeps BASELINE.json's configs[1]); prints one JSON line.
 usage: python tools/bench_wide.py [--batch 1024] [--steps 10]"""
 import argparse
