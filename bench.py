@@ -205,15 +205,18 @@ def main():
         lib.coskad_probe_end(ctypes.byref(lbw_ms), ctypes.byref(lbw_n))
     # forward-only (eval-mode encoder + bottleneck; SURVEY 8d's forward roofline target), outside the timed region
     model.eval()
+    fz_ms, fz_n = ctypes.c_float(0), ctypes.c_int(0)
     with torch.no_grad():
-        for _ in range(3):
+        for _ in range(5):
             model(x)
         sync()
+        lib.coskad_probe_begin(7, C_IN, HID)      # the fused encoder kernel's own launches (HIP events on its stream)
         tf0 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(50):
             model(x)
         sync()
-        fwd_dt = (time.perf_counter() - tf0) / 10
+        fwd_dt = (time.perf_counter() - tf0) / 50
+        lib.coskad_probe_end(ctypes.byref(fz_ms), ctypes.byref(fz_n))
     model.train()
     if world > 1:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -279,7 +282,16 @@ def main():
             "final_loss": round(loss, 6),
             "forward_only": {"value": round(B / fwd_dt, 1), "unit": "clips/s per GPU", "ms": round(fwd_dt * 1e3, 4),
                              "hbm_frac": round(B / fwd_dt * fwd_b / (HBM_PEAK_GBS * 1e9), 4),
-                             "what": "eval-mode STSE forward (4 layer kernels + bottleneck), BN folded from running stats"},
+                             "what": "eval-mode STSE forward: ONE fused encoder kernel (activations resident in LDS / registers) + "
+                                     "the split-K bottleneck, BN folded from running stats; hbm_frac prices SURVEY 8d's "
+                                     "layer-materialised 236 704 B/clip against 8 TB/s (north_star target: 0.50)",
+                             "fused_encoder_kernel_us": round(fz_ms.value * 1e3, 2) if fz_n.value else None,
+                             # the fully fused path's own lower bound is input + latent only (1 696 B/clip): it is
+                             # FMA-bound, so it is priced against the fp32 matrix peak (3 946 992 FLOP per clip)
+                             "fused_inference": {"hbm_bytes_per_clip": 4 * C_IN * T * V + 4 * LATENT,
+                                                 "hbm_frac": round(B / fwd_dt * (4 * C_IN * T * V + 4 * LATENT) / (HBM_PEAK_GBS * 1e9), 5),
+                                                 "flops_per_clip": 3946992,
+                                                 "mfma_f32_frac": round(B / fwd_dt * 3946992 / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)}},
             "roofline": roof,
             "roofline_fwd_layer4": roof_fwd,
             "roofline_layer4_backward": roof_lbw,

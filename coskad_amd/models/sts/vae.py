@@ -102,16 +102,26 @@ class STSVAE(STSAE):
         assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
         B = X.shape[0]
         U, slope = self.encoder.forward_preact(X)
-        if isinstance(self.btlnk, MLP) and self.btlnk.hip_ok:      # wide Linear + BN/ReLU/Linear tail on the HIP kernels
-            from .ae import _BottleneckFn
-            Z = self.btlnk.forward_preact(U, slope, self._ws, _BottleneckFn.apply)
-        else:
-            Z = self.btlnk((U if slope is None else _PReLUFn.apply(U, slope)).reshape(B, -1))
         X_shape = (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)
-        Z_mean = self.fc_mean(Z)
+        n_var = self.fc_var.out_features
+        if isinstance(self.btlnk, nn.Identity) and self.latent_dim + n_var <= 16:
+            # `linear` projector (vae.py:147-150): both heads read the flattened encoder output -- ONE pass of the
+            # bottleneck kernel over U (PReLU fused into the load) with the two weights stacked
+            from .ae import _BottleneckFn
+            Wc = torch.cat([self.fc_mean.weight, self.fc_var.weight], 0)
+            bc = torch.cat([self.fc_mean.bias, self.fc_var.bias], 0)
+            H = _BottleneckFn.apply(U, slope, Wc, bc, self._ws)
+            Z_mean, var_raw = H[:, :self.latent_dim], H[:, self.latent_dim:]
+        else:
+            if isinstance(self.btlnk, MLP) and self.btlnk.hip_ok:      # wide Linear + BN/ReLU/Linear tail on the HIP kernels
+                from .ae import _BottleneckFn
+                Z = self.btlnk.forward_preact(U, slope, self._ws, _BottleneckFn.apply)
+            else:
+                Z = self.btlnk((U if slope is None else _PReLUFn.apply(U, slope)).reshape(B, -1))
+            Z_mean, var_raw = self.fc_mean(Z), self.fc_var(Z)
         if self.distribution == 'ps':
             Z_mean = Z_mean / torch.norm(Z_mean, dim=-1, keepdim=True)
-        Z_var = F.softplus(self.fc_var(Z)) + 1          # the `+ 1` prevents collapse (vae.py:85)
+        Z_var = F.softplus(var_raw) + 1          # the `+ 1` prevents collapse (vae.py:85)
         if return_shape:
             return Z_mean, Z_var, X_shape
         return Z_mean, Z_var
