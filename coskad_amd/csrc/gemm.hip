@@ -16,7 +16,7 @@ namespace coskad {
 namespace gemm {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;   // LDS row stride (floats): 64 + 4 keeps 16-float operand reads aligned and conflict-free
+constexpr int BK = 16;
 
 struct Args {
   const float* A;
@@ -34,12 +34,18 @@ struct Args {
   int accum;          // != 0 (non-reduce): C += result
 };
 
+// TM x TN MFMA tiles per wave: block tile = (32 TM) x (32 TN).  2 x 2 for small / skinny products, 4 x 4 (128 x 128 per
+// block, 0.5 LDS operand reads per MFMA) when both M and N are large.
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm(Args a) {
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  constexpr int LDA = BM + 4, LDB = BN + 4;      // LDS row strides: + 4 keeps 16-float operand reads aligned and conflict-free
+  constexpr int EA = BM / 16, EB = BN / 16;      // elements per thread and K-tile
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int wm = (wave >> 1) * 16 * TM, wn = (wave & 1) * 16 * TN;
   const int j = lane & 15, q = lane >> 4;
   int b_first, b_last;
   if (a.reduce) {
@@ -52,33 +58,39 @@ __global__ __launch_bounds__(256) void k_gemm(Args a) {
   // global -> register mapping: 4 elements per thread and operand, consecutive threads along the contiguous dimension
   const bool a_kc = a.sa_k == 1;                 // A contiguous along k (else along m or generic)
   const bool b_nc = a.sb_n == 1;                 // B contiguous along n
-  int am[4], ak[4], bk[4], bn[4];
+  int am[EA], ak[EA], bk[EB], bn[EB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < EA; ++i) {
     if (a_kc) { am[i] = (tid >> 4) + 16 * i; ak[i] = tid & 15; }
-    else { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; }
-    if (b_nc) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; }
+    else { am[i] = tid % BM; ak[i] = tid / BM + (256 / BM) * i; }
+  }
+#pragma unroll
+  for (int i = 0; i < EB; ++i) {
+    if (b_nc) { bn[i] = tid % BN; bk[i] = tid / BN + (256 / BN) * i; }
     else { bn[i] = (tid >> 4) + 16 * i; bk[i] = tid & 15; }
   }
-  f32x4 acc[2][2];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < TM; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int y = 0; y < TN; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int ktiles = (a.K + BK - 1) / BK;
   const int total = (b_last - b_first) * ktiles;
-  float ra[4], rb[4];
+  float ra[EA], rb[EB];
   auto gload = [&](int it) {
     const int b = b_first + it / ktiles, k0 = (it % ktiles) * BK;
     const float* Ab = a.A + (long long)b * a.sa_b;
     const float* Bb = a.B + (long long)b * a.sb_b;
     const long long kbase = (long long)b * a.K;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < EA; ++i) {
       const int m = m0 + am[i], k = k0 + ak[i];
       const bool ok = m < a.M && k < a.K && (a.ktotal <= 0 || kbase + k < a.ktotal);
       ra[i] = ok ? Ab[(long long)m * a.sa_m + (long long)k * a.sa_k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
       const int n = n0 + bn[i], kb = k0 + bk[i];
       const bool okb = n < a.N && kb < a.K && (a.ktotal <= 0 || kbase + kb < a.ktotal);
       rb[i] = okb ? Bb[(long long)kb * a.sb_k + (long long)n * a.sb_n] : 0.f;
@@ -86,10 +98,9 @@ __global__ __launch_bounds__(256) void k_gemm(Args a) {
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      As[buf][ak[i]][am[i]] = ra[i];
-      Bs[buf][bk[i]][bn[i]] = rb[i];
-    }
+    for (int i = 0; i < EA; ++i) As[buf][ak[i]][am[i]] = ra[i];
+#pragma unroll
+    for (int i = 0; i < EB; ++i) Bs[buf][bk[i]][bn[i]] = rb[i];
   };
   if (total > 0) {
     gload(0);
@@ -101,12 +112,15 @@ __global__ __launch_bounds__(256) void k_gemm(Args a) {
     if (it + 1 < total) gload(it + 1);
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
-      const float a0 = As[buf][4 * s + q][wm + j], a1 = As[buf][4 * s + q][wm + 16 + j];
-      const float b0 = Bs[buf][4 * s + q][wn + j], b1 = Bs[buf][4 * s + q][wn + 16 + j];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int x = 0; x < TM; ++x) av[x] = As[buf][4 * s + q][wm + 16 * x + j];
+#pragma unroll
+      for (int y = 0; y < TN; ++y) bv[y] = Bs[buf][4 * s + q][wn + 16 * y + j];
+#pragma unroll
+      for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[y], acc[x][y], 0, 0, 0);
     }
     if (it + 1 < total) sstore(buf ^ 1);
     __syncthreads();
@@ -117,9 +131,9 @@ __global__ __launch_bounds__(256) void k_gemm(Args a) {
   if (a.reduce) { Cb = a.C + (long long)blockIdx.z * a.M * a.N; scm = a.N; scn = 1; }
   else { Cb = a.C + (long long)b_first * a.sc_b; scm = a.sc_m; scn = a.sc_n; }
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < TM; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y)
+    for (int y = 0; y < TN; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + 16 * x + 4 * q + r, n = n0 + wn + 16 * y + j;
@@ -221,7 +235,10 @@ int coskad_gemm_f32(const float* A, const float* B, float* C, const float* bias,
                reduce, chunk, ktotal, accum};
   const int gz = reduce ? ceil_div(batch, chunk) : batch;
   if (gz > 65535) return fail(COSKAD_ERR_SHAPE, "gemm: %d batches/chunks exceed the grid limit", gz);
-  hipLaunchKernelGGL(gemm::k_gemm, dim3(ceil_div(N, gemm::BN), ceil_div(M, gemm::BM), gz), dim3(256), 0, stream, a);
+  if (M >= 128 && N >= 128)      // 128 x 128 block tiles: half the LDS operand traffic per MFMA
+    hipLaunchKernelGGL((gemm::k_gemm<4, 4>), dim3(ceil_div(N, 128), ceil_div(M, 128), gz), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((gemm::k_gemm<2, 2>), dim3(ceil_div(N, 64), ceil_div(M, 64), gz), dim3(256), 0, stream, a);
   return check_launch("gemm");
 }
 
