@@ -136,34 +136,43 @@ template <int ROWS, int NRT>
 __device__ __forceinline__ void temporal_phase(float* img, const TTab& tt, const Lane& L) {
   constexpr int GV = NRT == 2 ? 2 : 4;          // joints per group: 4 independent chains in flight either way
   constexpr int NG = (V + GV - 1) / GV;
+  // three stages in flight: operand reads of group g+1, MFMAs of group g, result writes of group g-1 -- a result is
+  // written one group after its MFMA chain was issued, so the wave never idles on the MFMA -> LDS-store hazard
   TOp cur[GV][NRT], nxt[GV][NRT];
+  f32x4 d[GV][NRT], dp[GV][NRT];
 #pragma unroll
   for (int u = 0; u < GV; ++u)
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) cur[u][rt] = temporal_read<ROWS>(img, rt, u, L);
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
+  for (int g = 0; g <= NG; ++g) {
     const int v0 = g * GV;
+    if (g < NG) {
+#pragma unroll
+      for (int u = 0; u < GV; ++u)
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          if (v0 + GV + u < V) nxt[u][rt] = temporal_read<ROWS>(img, rt, v0 + GV + u, L);
+#pragma unroll
+      for (int u = 0; u < GV; ++u)
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          if (v0 + u < V) d[u][rt] = temporal_mm(cur[u][rt], tt.r[v0 + u < V ? v0 + u : V - 1]);
+    }
+    if (g > 0) {
+#pragma unroll
+      for (int u = 0; u < GV; ++u)
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          if (v0 - GV + u < V) temporal_store<ROWS>(img, rt, v0 - GV + u, dp[u][rt], L);
+    }
 #pragma unroll
     for (int u = 0; u < GV; ++u)
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-        if (v0 + GV + u < V) nxt[u][rt] = temporal_read<ROWS>(img, rt, v0 + GV + u, L);
-    f32x4 d[GV][NRT];
-#pragma unroll
-    for (int u = 0; u < GV; ++u)
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-        if (v0 + u < V) d[u][rt] = temporal_mm(cur[u][rt], tt.r[v0 + u < V ? v0 + u : V - 1]);
-#pragma unroll
-    for (int u = 0; u < GV; ++u)
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-        if (v0 + u < V) temporal_store<ROWS>(img, rt, v0 + u, d[u][rt], L);
-#pragma unroll
-    for (int u = 0; u < GV; ++u)
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) cur[u][rt] = nxt[u][rt];
+      for (int rt = 0; rt < NRT; ++rt) {
+        cur[u][rt] = nxt[u][rt];
+        dp[u][rt] = d[u][rt];
+      }
   }
 }
 
@@ -317,6 +326,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
       spatial_extra<2>(r2, 0, 0, op1, rec1, L);
       rec1 = load_spat(tabres, 0, 1, l16);
       op1 = spatial_read<2>(r2, 0, 1, L);
+      f32x4 Pp = {0.f, 0.f, 0.f, 0.f}, Rp = Pp;      // results of the previous tile: stored one tile later (see temporal_phase)
+      int posp = PADCOL;
+      bool okp = false;
       FF_AB_UNROLL
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
@@ -351,10 +363,15 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
           P = mfma(w[WP + 4 + r], x21[r], P);
           Rr = mfma(w[WR + 4 + r], x21[r], Rr);
         }
-        tile_store(r1, 0, pos, ok, P, L);
-        tile_store(r1, 16, pos, ok, Rr, L);
+        if (tile > 0) {
+          tile_store(r1, 0, posp, okp, Pp, L);
+          tile_store(r1, 16, posp, okp, Rp, L);
+        }
+        Pp = P; Rp = Rr; posp = pos; okp = ok;
         zc = zn; rec1 = rec2; op1 = op2;
       }
+      tile_store(r1, 0, posp, okp, Pp, L);
+      tile_store(r1, 16, posp, okp, Rp, L);
     }
 
     // ================= layer 2 mixing on P; U2 = gcn(P) + R; X3 -> R2; residual conv of layer 3 -> R1 (in place) ======
@@ -370,6 +387,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
       spatial_extra<16>(r1, 0, 0, op1, rec1, L);
       rec1 = load_spat(tabres, tb, 1, l16);
       op1 = spatial_read<16>(r1, 0, 1, L);
+      f32x4 a0p = {0.f, 0.f, 0.f, 0.f}, a1p = a0p;
+      int posp = PADCOL;
+      bool okp = false;
       FF_AB_UNROLL
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
@@ -392,10 +412,15 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
           a0 = mfma(w[WX3 + r], x3[r], a0);
           a1 = mfma(w[WX3 + 4 + r], x3[r], a1);
         }
-        tile_store(r1, 0, pos, ok, a0, L);
-        tile_store(r1, 16, pos, ok, a1, L);
+        if (tile > 0) {
+          tile_store(r1, 0, posp, okp, a0p, L);
+          tile_store(r1, 16, posp, okp, a1p, L);
+        }
+        a0p = a0; a1p = a1; posp = pos; okp = ok;
         zc = zn; rec1 = rec2; op1 = op2;
       }
+      tile_store(r1, 0, posp, okp, a0p, L);
+      tile_store(r1, 16, posp, okp, a1p, L);
     }
 
     // ================= layer 3 mixing on X3; conv3 on top of the stored residual part; X4 -> R1 and registers =========
@@ -414,6 +439,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
       spatial_extra<16>(r2, 0, 0, op1, rec1, L);
       rec1 = load_spat(tabres, tb, 1, l16);
       op1 = spatial_read<16>(r2, 0, 1, L);
+      f32x4 a0p = {0.f, 0.f, 0.f, 0.f}, a1p = a0p;
+      int posp = PADCOL;
+      bool okp = false;
 #pragma unroll
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
@@ -433,18 +461,23 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
           a0 = mfma(w[WZ3 + r], zc[r], a0);
           a1 = mfma(w[WZ3 + 4 + r], zc[r], a1);
         }
-        if (!(FF_CABL & 16)) {
-          a0 = prelu4(a0, s3);
-          a1 = prelu4(a1, s3);
+        if (tile > 0) {                                   // epilogue of the previous tile, behind this tile's MFMAs
+          const f32x4 e0 = prelu4(a0p, s3), e1 = prelu4(a1p, s3);
+          tile_store(r1, 0, posp, okp, e0, L);
+          tile_store(r1, 16, posp, okp, e1, L);
+          x4[tile > 0 ? tile - 1 : 0][0] = e0;
+          x4[tile > 0 ? tile - 1 : 0][1] = e1;
         }
-        if (!(FF_CABL & 4)) {
-          tile_store(r1, 0, pos, ok, a0, L);
-          tile_store(r1, 16, pos, ok, a1, L);
-        }
-        x4[tile][0] = a0;
-        x4[tile][1] = a1;
+        a0p = a0; a1p = a1; posp = pos; okp = ok;
         zc = zn; rec1 = rec2; op1 = op2;
         FF_TILE_FENCE;
+      }
+      {
+        const f32x4 e0 = prelu4(a0p, s3), e1 = prelu4(a1p, s3);
+        tile_store(r1, 0, posp, okp, e0, L);
+        tile_store(r1, 16, posp, okp, e1, L);
+        x4[NTILE - 1][0] = e0;
+        x4[NTILE - 1][1] = e1;
       }
     }
 
@@ -464,6 +497,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
       rec1 = load_spat(tabres, tb, 1, l16);
       op10 = spatial_read<16>(r1, 0, 1, L);
       op11 = spatial_read<16>(r1, 1, 1, L);
+      f32x4 ap[4];
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot) ap[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tile = 0; tile < NTILE; ++tile) {
         TILE_GEO(tile);
@@ -500,13 +536,25 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int ot = 0; ot < 4; ++ot) a[ot] = mfma(w[WZ4 + 8 * ot + 4 + r], zc1[r], a[ot]);
+        if (tile > 0) {                                   // epilogue of the previous tile, behind this tile's MFMAs
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-          const f32x4 v = prelu4(a[ot], s4);
-          buf_store4(ores, l16, (tile * 4 + ot) * 1024, ok ? float4{v[0], v[1], v[2], v[3]} : float4{0.f, 0.f, 0.f, 0.f});
+          for (int ot = 0; ot < 4; ++ot) {
+            const f32x4 v = prelu4(ap[ot], s4);
+            buf_store4(ores, l16, ((tile > 0 ? tile - 1 : 0) * 4 + ot) * 1024, float4{v[0], v[1], v[2], v[3]});   // frame tiles: every column valid
+          }
         }
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) ap[ot] = a[ot];
         zc0 = zn0; zc1 = zn1; rec1 = rec2; op10 = op20; op11 = op21;
         FF_TILE_FENCE;
+      }
+      {
+        const bool ok = L.j < T;                          // the 17th-joint tile: columns 12..15 are padding
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+          const f32x4 v = prelu4(ap[ot], s4);
+          buf_store4(ores, l16, ((NTILE - 1) * 4 + ot) * 1024, ok ? float4{v[0], v[1], v[2], v[3]} : float4{0.f, 0.f, 0.f, 0.f});
+        }
       }
     }
     load_ttab(tt, tabres, 0, l16);   // layer 1's table for the next clip
