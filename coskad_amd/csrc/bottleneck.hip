@@ -73,7 +73,13 @@ __global__ __launch_bounds__(64 * kBtlFwdWaves) void k_btlnk_fwd(const float* __
 // Split-K variant for large batches: a block = 64 clips (four MFMA row tiles per wave, which share every W operand:
 // the L2 traffic of W drops to a quarter of the HBM traffic of U) x one of KS slices of K; the four waves split the
 // slice again.  Partials [KS][B][16] are summed in a fixed order by k_btlnk_fwd_sum (deterministic, no atomics).
-constexpr int kBtlKS = 8;
+#ifndef BTL_KS
+#define BTL_KS 8
+#endif
+#ifndef BTL_UB
+#define BTL_UB 2
+#endif
+constexpr int kBtlKS = BTL_KS;
 __global__ __launch_bounds__(256) void k_btlnk_fwd_t(const float* __restrict__ U, const float* __restrict__ W,
                                                      const float* __restrict__ slope, float* __restrict__ part,
                                                      int B, int K, int L) {
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void k_btlnk_fwd_t(const float* __restrict__ U
   f32x4 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int UB = 2;
+  constexpr int UB = BTL_UB;
   for (int sb = s0; sb < s1; sb += UB) {
     float4 x[4][UB], w[UB];
 #pragma unroll
