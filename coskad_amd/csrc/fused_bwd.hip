@@ -1,0 +1,368 @@
+// Backward of one ST_GCNN layer (autograd of models/graph_layers/stsgcn.py:94-116 in training mode) behind the batch
+// reductions and the fp64 fold (stsgcn_bwd.hip stages 1-2): the data path AND the mixing-parameter gradients in ONE
+// kernel, one clip per wavefront, for the stored-Z training path at n_frames 12 / n_joints 17, 16 or 32 input channels.
+//
+//   dZ      = Bt.dU + Kt.Z + kt                          (coefficient matrices from k_bwd_fold)
+//   dX      = gcn^T(dZ) + Br.dU + Kr.X + kr ;  dU_prev = dX * PReLU'(U_prev) ;  dslope_prev = sum dX * U_prev [U_prev < 0]
+//   dA[t]   = Y_t^T dZ_t   (Y = temporal mix of X)     dT[v] = X_v^T dY_v   (dY = spatial adjoint of dZ)
+//
+// Replaces k_bwd_data_f + k_bwd_gcn_params (round 1: 229 + 110 us at layer 4, B = 4096) and their HBM round trips: dZ
+// is never written (107 MB + re-read), X is staged once for both, the PReLU mask is the only re-read.  Same toolkit as
+// fused_fwd.hip: no workgroup barrier, 39.6 KB of LDS per wave, accumulator tiles as the next product's operand
+// (dZ tile -> B operand of dA), coefficient matrices as A operands in registers, buffer-addressed streams, hand-written
+// software pipeline.  One 32-row LDS image carries X -> Y -> dZ (frame by frame, as soon as dA has consumed Y's frame)
+// -> dY -> gcn^T(dZ) in place; Br.dU + Kr.X waits in 104 registers; X is re-staged 16 rows at a time for dT.
+// Per-wave partial sums of dA / dT live in the workspace (summed in a fixed order by k_reduce_gcn: deterministic).
+#include "fused_ops.h"
+
+namespace coskad {
+namespace fb {
+
+using namespace ff;
+
+constexpr int NA = T * V * V, NTT = V * T * T, EROW = NA + NTT;
+constexpr int SPAT_F4 = T * 3 * 64;                  // float4 records of one spatial section
+constexpr int BTAB_F4 = 2 * TEMP_F4 + SPAT_F4;       // [forward temporal][adjoint spatial][adjoint temporal]
+
+// operand streams of one layer from its A [T,V,V] and T [V,T,T] (lane l: j = l & 15, q = l >> 4):
+//   forward temporal  rec[v][l][s]      = T[v][4s+q][j]          (j < 12)
+//   adjoint spatial   rec[t][l][0..4]   = A[t][j][4s+q]          (4s+q < 17),  [5..9] = A[t][16][4s+q]
+//   adjoint temporal  rec[v][l][s]      = T[v][j][4s+q]          (j < 12)
+__global__ void k_build_btab(const float* __restrict__ Aw, const float* __restrict__ Tw, float* __restrict__ tab) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= BTAB_F4 * 4) return;
+  float val = 0.f;
+  if (e < TEMP_F4 * 4 || e >= (TEMP_F4 + SPAT_F4) * 4) {
+    const bool adj = e >= TEMP_F4 * 4;
+    const int r = adj ? e - (TEMP_F4 + SPAT_F4) * 4 : e;
+    const int v = r / 256, l = (r >> 2) & 63, s = r & 3, j = l & 15, q = l >> 4;
+    if (s < 3 && j < T) val = adj ? Tw[v * T * T + j * T + 4 * s + q] : Tw[v * T * T + (4 * s + q) * T + j];
+  } else {
+    const int r = e - TEMP_F4 * 4;
+    const int t = r / (3 * 256), c = (r / 256) % 3, l = (r >> 2) & 63, k = 4 * c + (r & 3), j = l & 15, q = l >> 4;
+    if (k < 10) {
+      const int s = k < 5 ? k : k - 5, w = 4 * s + q;
+      if (w < V) val = Aw[t * V * V + (k < 5 ? j : 16) * V + w];
+    }
+  }
+  tab[e] = val;
+}
+
+__device__ __forceinline__ void rmw(float* p, float v, bool first) { *p = first ? v : *p + v; }
+
+template <int CT, int OT>
+__global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restrict__ in, const float* __restrict__ Zg,
+                                                           const float* __restrict__ dU, const float* __restrict__ coef,
+                                                           const float* __restrict__ btab, const float* __restrict__ in_slope,
+                                                           float* __restrict__ dIn, float* __restrict__ partials,
+                                                           float* __restrict__ dap, int B) {
+  constexpr int Ci = 16 * CT, Co = 16 * OT, CiP = Ci;
+  constexpr int KU = OT * 4, KC = CT * 4, NOP = KU + 2 * KC;      // k-steps of dU, Z, X per position tile
+  constexpr int KT0 = (Co + Ci) * CiP, DX0 = KT0 + CiP, KR0 = DX0 + (Co + Ci) * CiP;
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* lds = lds_all + wave * WAVE_LDS;
+  float* r1 = lds + R1;
+  float* r2 = lds + R2;
+  auto geo = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return Lane{l & 15, l >> 4};
+  };
+  Lane L = geo();
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const int l16 = lane * 16;
+  const BufRes tabres = make_res(btab, BTAB_F4 * 16u);
+  const BufRes cres = make_res(coef, (KR0 + CiP) * 4u);
+  float* prow = partials + (size_t)(blockIdx.x * 4 + wave) * EROW;
+  const int nwaves = gridDim.x * 4;
+  float da = 0.f;
+  bool first = true;
+  int clip = blockIdx.x * 4 + wave;
+  if (clip >= B) {                                   // a wave without clips still owns a partial row: zero it
+    for (int e = lane; e < EROW; e += 64) prow[e] = 0.f;
+  }
+
+  for (; clip < B; clip += nwaves) {
+    const BufRes xres = make_res(in + (size_t)clip * Ci * TV, Ci * TV * 4u);
+    const BufRes zres = make_res(Zg + (size_t)clip * Ci * TV, Ci * TV * 4u);
+    const BufRes dures = make_res(dU + (size_t)clip * Co * TV, Co * TV * 4u);
+    const BufRes ores = make_res(dIn + (size_t)clip * Ci * TV, Ci * TV * 4u);
+
+    // ---- stage X = PReLU(U_prev) rows [row0, row0 + nrows) into an image (float4 loads: a row is 51 float4) ----------
+    auto stage = [&](float* img, int row0, int nrows) {
+      const int n4 = nrows * (TV / 4);
+#pragma unroll
+      for (int i = 0; i < (16 * CT * (TV / 4) + 63) / 64; ++i) {
+        if (i * 64 < n4) {
+          const int e4 = lane + 64 * i;
+          float4 v = buf_load4(xres, l16, (row0 * (TV / 4) + 64 * i) * 16);
+          if (pre) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+          const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
+          const bool ok = e4 < n4;
+          float* d0 = img + (ok ? row * LD + col : PADCOL);
+          float* d1 = img + (ok ? row * LD + col + 2 : PADCOL);
+          *reinterpret_cast<float2*>(d0) = float2{v.x, v.y};
+          *reinterpret_cast<float2*>(d1) = float2{v.z, v.w};
+        }
+      }
+    };
+    L = geo();
+    TTab tt;
+    load_ttab(tt, tabres, 0, l16);
+    stage(r1, 0, Ci);
+
+    // ---- Y = temporal mix of X, in place -----------------------------------------------------------------------------
+    L = geo();
+    temporal_phase<16, CT>(r1, tt, L);
+
+    // ---- coefficient matrices as A operands (lane: output channel 16 ct + j, k slot q) and bias quads ------------------
+    L = geo();
+    float wbt[KU][CT], wbr[KU][CT], wkt[KC][CT], wkr[KC][CT];
+    f32x4 ktq[CT], krq[CT];
+    {
+      const int lq = (L.q * CiP + L.j) * 4;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int s = 0; s < KU; ++s) {
+          wbt[s][ct] = buf_load1(cres, lq, (4 * s * CiP + 16 * ct) * 4);
+          wbr[s][ct] = buf_load1(cres, lq, (DX0 + 4 * s * CiP + 16 * ct) * 4);
+        }
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          wkt[s][ct] = buf_load1(cres, lq, ((Co + 4 * s) * CiP + 16 * ct) * 4);
+          wkr[s][ct] = buf_load1(cres, lq, (DX0 + (Co + 4 * s) * CiP + 16 * ct) * 4);
+        }
+        const float4 a = buf_load4(cres, L.q * 16, (KT0 + 16 * ct) * 4), b = buf_load4(cres, L.q * 16, (KR0 + 16 * ct) * 4);
+        ktq[ct] = f32x4{a.x, a.y, a.z, a.w};
+        krq[ct] = f32x4{b.x, b.y, b.z, b.w};
+      }
+    }
+
+    // ---- position tiles: dZ = Bt.dU + Kt.Z + kt,  dXres = Br.dU + Kr.X + kr,  dA ----------------------------------------
+    // B operands straight from HBM: row 4s + q of dU / Z / X at this lane's position (16 consecutive floats per row)
+    const int jc = L.j < T ? L.j : T - 1;
+    float bop[2][NOP];
+    auto load_ops = [&](float (&o)[NOP], int tile) {
+      const int pos = tile < T ? tile * V + L.j : jc * V + 16;
+      const int vo = (L.q * TV + pos) * 4;
+#pragma unroll
+      for (int s = 0; s < KU; ++s) o[s] = buf_load1(dures, vo, s * 4 * TV * 4);
+#pragma unroll
+      for (int s = 0; s < KC; ++s) o[KU + s] = buf_load1(zres, vo, s * 4 * TV * 4);
+#pragma unroll
+      for (int s = 0; s < KC; ++s) o[KU + KC + s] = buf_load1(xres, vo, s * 4 * TV * 4);
+    };
+    auto tile_mm = [&](const float (&o)[NOP], f32x4 (&az)[CT], f32x4 (&ax)[CT]) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) { az[ct] = ktq[ct]; ax[ct] = krq[ct]; }
+#pragma unroll
+      for (int s = 0; s < KU; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          az[ct] = mfma(wbt[s][ct], o[s], az[ct]);
+          ax[ct] = mfma(wbr[s][ct], o[s], ax[ct]);
+        }
+#pragma unroll
+      for (int s = 0; s < KC; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          az[ct] = mfma(wkt[s][ct], o[KU + s], az[ct]);
+          const float xv = pre ? prelu(o[KU + KC + s], a_in) : o[KU + KC + s];
+          ax[ct] = mfma(wkr[s][ct], xv, ax[ct]);
+        }
+    };
+    f32x4 xr[NTILE][CT];
+    f32x4 az17[CT];
+    float exB[V];
+    load_ops(bop[0], T);            // the 17th-joint tile first: dA's column 16 needs Y intact
+    load_ops(bop[1], 0);
+    {
+      f32x4 ax[CT];
+      tile_mm(bop[0], az17, ax);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) xr[T][ct] = ax[ct];
+      // dA[t = j][v][16] = sum_c Y[c][t, v] dZ[c][t, 16]
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float s = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const f32x4 y = tile_load(r1, 16 * ct, jc * V + v, L);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s = fmaf(y[r], az17[ct][r], s);
+        }
+        exB[v] = quad_sum(s);
+      }
+    }
+    f32x4 dAacc[T];
+    float exA[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) load_ops(bop[(t + 1) & 1 ? 0 : 1], t + 1);
+      f32x4 az[CT], ax[CT];
+      tile_mm(bop[t & 1 ? 0 : 1], az, ax);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      float s16 = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        xr[t][ct] = ax[ct];
+        const f32x4 y = tile_load(r1, 16 * ct, t * V + L.j, L);          // A operand: Y[16 ct + 4q + r][t, v = j]
+        const f32x4 y16 = tile_load(r1, 16 * ct, t * V + 16, L);        // Y[..][t, 16] (same address in every column)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc = mfma(y[r], az[ct][r], acc);
+          s16 = fmaf(y16[r], az[ct][r], s16);
+        }
+      }
+      dAacc[t] = acc;
+      exA[t] = quad_sum(s16);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, t * V + L.j, true, az[ct], L);   // dZ over Y's frame t
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, jc * V + 16, L.j < T, az17[ct], L);
+    // dA partial sums of this wave (its own row of the workspace: read-modify-write, first clip writes)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rmw(prow + t * V * V + (4 * L.q + r) * V + L.j, dAacc[t][r], first);
+      if (L.q == 0) rmw(prow + t * V * V + 16 * V + L.j, exA[t], first);
+    }
+    if (L.q == 0 && L.j < T) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) rmw(prow + L.j * V * V + v * V + 16, exB[v], first);
+    }
+
+    // ---- dY = spatial adjoint of dZ, in place (operand reads of frame t+1 before the stores of frame t) ----------------
+    L = geo();
+    {
+      SpatRec rec = load_spat(tabres, 0, 0, l16);
+      SOp op[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) op[ct] = spatial_read<16>(r1, ct, 0, L);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int tn = t + 1 < T ? t + 1 : T - 1;
+        const SpatRec nxt = load_spat(tabres, 0, tn, l16);
+        SOp opn[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) opn[ct] = spatial_read<16>(r1, ct, tn, L);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const f32x4 d = spatial_mm(op[ct], rec);
+          spatial_extra<16>(r1, ct, t, op[ct], rec, L);
+          tile_store(r1, 16 * ct, t * V + L.j, true, d, L);
+        }
+        rec = nxt;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) op[ct] = opn[ct];
+      }
+    }
+
+    // ---- dT[v] = X_v^T dY_v: X re-staged 16 rows at a time beside the image --------------------------------------------
+    L = geo();
+    {
+      f32x4 dTacc[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) dTacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int ic = L.j < T ? L.j : T - 1;
+#pragma unroll
+      for (int h = 0; h < CT; ++h) {
+        stage(r2, 16 * h, 16);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            float a = r2[(4 * s + L.q) * LD + ic * V + v];
+            float b = r1[(16 * h + 4 * s + L.q) * LD + ic * V + v];
+            a = L.j < T ? a : 0.f;
+            b = L.j < T ? b : 0.f;
+            dTacc[v] = mfma(a, b, dTacc[v]);
+          }
+        }
+      }
+      // D[row t = 4q + r][col q' = j]
+#pragma unroll
+      for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * L.q + r < T && L.j < T) rmw(prow + NA + v * T * T + (4 * L.q + r) * T + L.j, dTacc[v][r], first);
+    }
+
+    // ---- gcn^T: temporal adjoint in place --------------------------------------------------------------------------------
+    L = geo();
+    load_ttab(tt, tabres, TEMP_F4 + SPAT_F4, l16);
+    temporal_phase<16, CT>(r1, tt, L);
+
+    // ---- dU_prev = (gcn^T(dZ) + dXres) * PReLU'(U_prev), slope gradient ---------------------------------------------------
+    L = geo();
+#pragma unroll
+    for (int tile = 0; tile < NTILE; ++tile) {
+      const bool fr = tile < T;
+      const int pos = fr ? tile * V + L.j : jc * V + 16;
+      const bool ok = fr || L.j < T;
+      const int vo = ok ? (4 * L.q * TV + pos) * 4 : 0x7fffff00;       // masked lanes: out of the buffer's range (dropped)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        f32x4 g = tile_load(r1, 16 * ct, pos, L) + xr[tile][ct];
+        if (pre) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float u = buf_load1(xres, vo, (16 * ct + r) * TV * 4);   // the pre-activation itself (0 for masked lanes)
+            if (u < 0.f) da = fmaf(g[r], u, da);
+            g[r] = u > 0.f ? g[r] : a_in * g[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g[r]), ores, vo, (16 * ct + r) * TV * 4, 0);
+      }
+    }
+    first = false;
+  }
+  da = wave_sum(da);
+  if (lane == 0 && dap) dap[blockIdx.x * 4 + wave] = da;
+}
+
+}  // namespace fb
+
+// stage 3 + 4 of launch_layer_bwd for the shapes this kernel is built for; partials: >= 4 * grid rows of T*V*V + V*T*T floats
+int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
+                           const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
+                           int B, int Ci, int Co, hipStream_t st, int* rows_out) {
+  hipLaunchKernelGGL(fb::k_build_btab, dim3(ceil_div(fb::BTAB_F4 * 4, 256)), dim3(256), 0, st, Aw, Tw, btab);
+  int rc;
+  if ((rc = check_launch("bwd_build_btab"))) return rc;
+  const size_t lds = (size_t)4 * ff::WAVE_LDS * sizeof(float);
+  const int nblk = (B + 3) / 4;
+  const int grid = nblk < 256 ? nblk : 256;
+  *rows_out = grid * 4;
+#define LAUNCH_FB(CT, OT)                                                                                              \
+  do {                                                                                                                 \
+    auto k = fb::k_layer_bwd_fused<CT, OT>;                                                                            \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, B);    \
+  } while (0)
+  {
+    ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
+    if (Ci == 16 && Co == 16) LAUNCH_FB(1, 1);
+    else if (Ci == 16 && Co == 32) LAUNCH_FB(1, 2);
+    else if (Ci == 16 && Co == 64) LAUNCH_FB(1, 4);
+    else if (Ci == 32 && Co == 16) LAUNCH_FB(2, 1);
+    else if (Ci == 32 && Co == 32) LAUNCH_FB(2, 2);
+    else if (Ci == 32 && Co == 64) LAUNCH_FB(2, 4);
+    else return fail(COSKAD_ERR_SHAPE, "bwd_fused: unsupported channels (%d, %d)", Ci, Co);
+  }
+#undef LAUNCH_FB
+  return check_launch("bwd_fused");
+}
+
+bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co) {
+  return T_ == ff::T && V_ == ff::V && (Ci == 16 || Ci == 32) && (Co == 16 || Co == 32 || Co == 64);
+}
+
+}  // namespace coskad

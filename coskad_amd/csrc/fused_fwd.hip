@@ -19,227 +19,10 @@
 //   * the mixing matrices stream from L2 as ready-made B operands (16-byte records per lane), prefetched one item ahead.
 //
 // tests/test_fused_plan.py replays exactly this schedule in numpy from the same operand streams.
-#include "common.h"
+#include "fused_ops.h"
 
 namespace coskad {
 namespace ff {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int T = 12, V = 17, TV = T * V;
-constexpr int LD = 206;                 // row stride: = 2 (mod 4) -> (row, k) operand reads of the mixing phases are conflict-free
-constexpr int R1 = 0, R2 = 32 * LD;     // float offsets inside the wave's LDS image
-constexpr int PADCOL = TV;              // columns 204, 205 of every row are padding: masked lanes store there (no divergent branches)
-constexpr int WAVE_LDS = 48 * LD;       // floats per wave
-constexpr int NTILE = T + 1;
-#ifndef FF_AB_UNROLL
-#define FF_AB_UNROLL _Pragma("unroll")     // tile loops of layers 1-2: fully unrolled like layers 3-4 (rolled: 213 vs 199 us at B = 4096 --
-                                           // the register rotation of the hand-written pipeline costs ~20 v_mov per iteration)
-#endif
-#ifndef FF_ABLATE
-#define FF_ABLATE 0   // timing-only builds (tools/ab_fused.sh): bit 0 skips the temporal phases, bits 1..4 the chains of layers 1..4
-#endif
-#ifndef FF_CABL
-#define FF_CABL 0     // timing-only: pieces of the layer-3 chain (1 table loads, 2 accumulator loads, 4 stores, 8 joint 16, 16 PReLU)
-#endif
-#ifndef FF_TILE_FENCE
-#define FF_TILE_FENCE   // (A/B hook: -DFF_TILE_FENCE="__builtin_amdgcn_sched_barrier(0)" keeps the scheduler inside one tile)
-#endif
-constexpr int KP = NTILE * 4 * 64 * 4;  // tile-major output floats per clip (13 312)
-constexpr int TEMP_F4 = V * 64;         // float4 records of the temporal part of one layer
-constexpr int LAYER_F4 = TEMP_F4 + T * 3 * 64;
-enum { W1A = 0, W1B = 2, WP = 4, WR = 12, WX3 = 20, WZ3 = 28, WZ4 = 36, WX4 = 68, B1 = 100, B2 = 108, B3 = 112, B4 = 120, NWREG = 136 };
-
-__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ float prelu(float x, float a) { return x > 0.f ? x : a * x; }
-__device__ __forceinline__ f32x4 prelu4(f32x4 v, float a) {
-  return f32x4{prelu(v[0], a), prelu(v[1], a), prelu(v[2], a), prelu(v[3], a)};
-}
-
-struct Lane {
-  int j, q;
-};
-
-// Buffer-addressed global memory (a 128-bit descriptor in SGPRs + ONE 32-bit lane offset + a wave-uniform SGPR/immediate
-// offset): with flat addressing hipcc precomputes a 64-bit VGPR address pair per 4 KB window of every stream and holds
-// ~70 of them across the clip loop.  Out-of-range lanes read 0 / do not store (hardware bounds check).
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-using BufRes = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ BufRes make_res(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(BufRes r, int voff, int soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  return float4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-}
-__device__ __forceinline__ float buf_load1(BufRes r, int voff, int soff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_store4(BufRes r, int voff, int soff, const float4& v) {
-  const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
-}
-
-// ---- temporal mixing (stsgcn.py:154), in place -----------------------------------------------------------------------
-// One item = one joint column v of one row tile: D[row][q] = sum_t X[row][t,v] T[v][t][q].  The phase is software-
-// pipelined by hand: the operands of group g+1 are read BEFORE the results of group g are written (the compiler cannot
-// prove that those LDS accesses never alias, so program order is what it executes), which keeps several independent
-// MFMA chains and LDS round trips in flight from one wave.
-struct TOp {
-  float a0, a1, a2;
-};
-template <int ROWS>
-__device__ __forceinline__ TOp temporal_read(const float* img, int rt, int v, const Lane& L) {
-  const float* p = img + (16 * rt + L.j) * LD + L.q * V + v;
-  TOp o{p[0], p[4 * V], p[8 * V]};
-  if (ROWS < 16) {
-    const bool ok = L.j < ROWS;
-    o.a0 = ok ? o.a0 : 0.f; o.a1 = ok ? o.a1 : 0.f; o.a2 = ok ? o.a2 : 0.f;
-  }
-  return o;
-}
-__device__ __forceinline__ f32x4 temporal_mm(const TOp& o, const float4& rec) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = mfma(o.a0, rec.x, acc);
-  acc = mfma(o.a1, rec.y, acc);
-  acc = mfma(o.a2, rec.z, acc);
-  return acc;
-}
-template <int ROWS>
-__device__ __forceinline__ void temporal_store(float* img, int rt, int v, const f32x4& acc, const Lane& L) {
-  float* rowp = img + (16 * rt + 4 * L.q) * LD;
-  float* p;
-  if (ROWS >= 16) {
-    p = rowp + (L.j < T ? L.j * V + v : PADCOL);      // masked lanes (columns 12..15 of the tile): the rows' padding column
-    p[0] = acc[0]; p[LD] = acc[1]; p[2 * LD] = acc[2]; p[3 * LD] = acc[3];
-  } else {
-    p = rowp + ((L.j < T && L.q == 0) ? L.j * V + v : PADCOL);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (r < ROWS) p[r * LD] = acc[r];
-  }
-}
-
-// the table of one layer's temporal mixing as B operands: 17 records per lane
-struct TTab {
-  float4 r[V];
-};
-// tabres: the whole tab stream; `base4`: float4 index of the layer's first record; l16 = lane * 16 bytes
-__device__ __forceinline__ void load_ttab(TTab& t, BufRes tabres, int base4, int l16) {
-#pragma unroll
-  for (int v = 0; v < V; ++v) t.r[v] = buf_load4(tabres, l16, (base4 + v * 64) * 16);
-}
-
-template <int ROWS, int NRT>
-__device__ __forceinline__ void temporal_phase(float* img, const TTab& tt, const Lane& L) {
-  constexpr int GV = NRT == 2 ? 2 : 4;          // joints per group: 4 independent chains in flight either way
-  constexpr int NG = (V + GV - 1) / GV;
-  // three stages in flight: operand reads of group g+1, MFMAs of group g, result writes of group g-1 -- a result is
-  // written one group after its MFMA chain was issued, so the wave never idles on the MFMA -> LDS-store hazard
-  TOp cur[GV][NRT], nxt[GV][NRT];
-  f32x4 d[GV][NRT], dp[GV][NRT];
-#pragma unroll
-  for (int u = 0; u < GV; ++u)
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) cur[u][rt] = temporal_read<ROWS>(img, rt, u, L);
-#pragma unroll
-  for (int g = 0; g <= NG; ++g) {
-    const int v0 = g * GV;
-    if (g < NG) {
-#pragma unroll
-      for (int u = 0; u < GV; ++u)
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
-          if (v0 + GV + u < V) nxt[u][rt] = temporal_read<ROWS>(img, rt, v0 + GV + u, L);
-#pragma unroll
-      for (int u = 0; u < GV; ++u)
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
-          if (v0 + u < V) d[u][rt] = temporal_mm(cur[u][rt], tt.r[v0 + u < V ? v0 + u : V - 1]);
-    }
-    if (g > 0) {
-#pragma unroll
-      for (int u = 0; u < GV; ++u)
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
-          if (v0 - GV + u < V) temporal_store<ROWS>(img, rt, v0 - GV + u, dp[u][rt], L);
-    }
-#pragma unroll
-    for (int u = 0; u < GV; ++u)
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        cur[u][rt] = nxt[u][rt];
-        dp[u][rt] = d[u][rt];
-      }
-  }
-}
-
-// ---- spatial mixing of one frame (stsgcn.py:155) -> accumulator tile; joint 16 goes back to the image in place -------
-struct SpatRec {
-  float4 c0, c1, c2;   // b[0..3] | b[4], bw[0..2] | bw[3], bw[4], -, -
-};
-__device__ __forceinline__ SpatRec load_spat(BufRes tabres, int base4, int t, int l16) {
-  const int o = (base4 + TEMP_F4 + t * 3 * 64) * 16;
-  return SpatRec{buf_load4(tabres, l16, o), buf_load4(tabres, l16, o + 1024), buf_load4(tabres, l16, o + 2048)};
-}
-struct SOp {
-  float a0, a1, a2, a3, a4;
-};
-template <int ROWS>
-__device__ __forceinline__ SOp spatial_read(const float* img, int rt, int t, const Lane& L) {
-  const float* row = img + (16 * rt + L.j) * LD + t * V;
-  const float* p = row + L.q;
-  SOp o{p[0], p[4], p[8], p[12], row[16]};
-  o.a4 = L.q == 0 ? o.a4 : 0.f;                        // joint 16: k slot 0 of the fifth step only
-  if (ROWS < 16) {
-    const bool ok = L.j < ROWS;
-    o.a0 = ok ? o.a0 : 0.f; o.a1 = ok ? o.a1 : 0.f; o.a2 = ok ? o.a2 : 0.f; o.a3 = ok ? o.a3 : 0.f; o.a4 = ok ? o.a4 : 0.f;
-  }
-  return o;
-}
-__device__ __forceinline__ f32x4 spatial_mm(const SOp& o, const SpatRec& R) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  acc = mfma(o.a0, R.c0.x, acc);
-  acc = mfma(o.a1, R.c0.y, acc);
-  acc = mfma(o.a2, R.c0.z, acc);
-  acc = mfma(o.a3, R.c0.w, acc);
-  acc = mfma(o.a4, R.c1.x, acc);
-  return acc;
-}
-// sum over the four k slots (lanes l, l^16, l^32, l^48) without leaving the VALU: v_permlane16_swap / v_permlane32_swap
-__device__ __forceinline__ float quad_sum(float x) {
-  unsigned u = __float_as_uint(x);
-  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  unsigned u2 = __float_as_uint(s);
-  auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-// joint 16 of the frame: Z[row][t,16] = sum_v Y[row][t,v] A[t][v][16], written over Y[row][t,16] (dead by now)
-template <int ROWS>
-__device__ __forceinline__ void spatial_extra(float* img, int rt, int t, const SOp& o, const SpatRec& R, const Lane& L) {
-  float ex = o.a0 * R.c1.y;
-  ex = fmaf(o.a1, R.c1.z, ex);
-  ex = fmaf(o.a2, R.c1.w, ex);
-  ex = fmaf(o.a3, R.c2.x, ex);
-  ex = fmaf(o.a4, R.c2.y, ex);
-  ex = quad_sum(ex);
-  float* e = img + (16 * rt + L.j) * LD + ((L.q == 0 && (ROWS >= 16 || L.j < ROWS)) ? t * V + 16 : PADCOL);
-  *e = ex;
-}
-
-// ---- accumulator-layout tiles in LDS -------------------------------------------------------------------------------
-// lane (j, q), register r  <->  row row0 + 4q + r, position `pos` (lane-dependent; `ok` masks the padding columns)
-__device__ __forceinline__ void tile_store(float* img, int row0, int pos, bool ok, const f32x4& a, const Lane& L) {
-  float* p = img + (row0 + 4 * L.q) * LD + (ok ? pos : PADCOL);
-  p[0] = a[0]; p[LD] = a[1]; p[2 * LD] = a[2]; p[3 * LD] = a[3];
-}
-__device__ __forceinline__ f32x4 tile_load(const float* img, int row0, int pos, const Lane& L) {
-  const float* p = img + (row0 + 4 * L.q) * LD + pos;
-  return f32x4{p[0], p[LD], p[2 * LD], p[3 * LD]};
-}
 
 __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restrict__ x, float* __restrict__ out,
                                                          const float4* __restrict__ tab, const float* __restrict__ wreg,

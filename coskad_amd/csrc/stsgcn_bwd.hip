@@ -26,7 +26,8 @@
 
 namespace coskad {
 
-constexpr int kMaxGridBwd = 768;   // persistent blocks: up to three 512-thread blocks per CU
+constexpr int kMaxGridBwd = 1024;  // partial rows: up to three 512-thread blocks per CU, or 4 waves x 256 blocks of the fused kernel
+constexpr int kBtabFloats = (2 * 17 * 64 + 12 * 3 * 64) * 4;   // operand streams of fused_bwd.hip (T = 12, V = 17)
 
 // ---------------------------------------------------------------------------------------
 // 1. reductions.  LDS: X image (nb*Ci rows) then dU image (nb*Co rows) then 1024 scratch.
@@ -1104,8 +1105,15 @@ struct BwdWs {
   double* red;
   float* coef;
   float* dap;
+  float* btab;
   float* dz;
 };
+
+// fused_bwd.hip
+int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
+                           const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
+                           int B, int Ci, int Co, hipStream_t st, int* rows_out);
+bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
 
 static size_t bwd_emax(int Ci, int Co, int T, int V) {
   const size_t e1 = 2 * (size_t)Co * Ci + Co;
@@ -1117,8 +1125,8 @@ size_t layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V) {
   const size_t E = bwd_emax(Ci, Co, T, V);
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   return al(kMaxGridBwd * E * sizeof(float)) + al(E * sizeof(double)) +
-         al(coef_floats(Ci, Co) * sizeof(float)) + al((size_t)(B + 1) * sizeof(float)) +
-         al((size_t)B * Ci * T * V * sizeof(float));
+         al(coef_floats(Ci, Co) * sizeof(float)) + al((size_t)((B > kMaxGridBwd ? B : kMaxGridBwd) + 1) * sizeof(float)) +
+         al((size_t)kBtabFloats * sizeof(float)) + al((size_t)B * Ci * T * V * sizeof(float));
 }
 
 static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
@@ -1129,7 +1137,8 @@ static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
   w.partials = reinterpret_cast<float*>(p); p += al(kMaxGridBwd * E * sizeof(float));
   w.red = reinterpret_cast<double*>(p);     p += al(E * sizeof(double));
   w.coef = reinterpret_cast<float*>(p);     p += al(coef_floats(Ci, Co) * sizeof(float));
-  w.dap = reinterpret_cast<float*>(p);      p += al((size_t)(B + 1) * sizeof(float));
+  w.dap = reinterpret_cast<float*>(p);      p += al((size_t)((B > kMaxGridBwd ? B : kMaxGridBwd) + 1) * sizeof(float));
+  w.btab = reinterpret_cast<float*>(p);     p += al((size_t)kBtabFloats * sizeof(float));
   w.dz = reinterpret_cast<float*>(p);
   return w;
 }
@@ -1289,6 +1298,16 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(1024), fold_lds, st, w.red, (double)B * TV, stat,
                      Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate);
   if ((rc = check_launch("bwd_fold"))) return rc;
+  // 3 + 4 in one kernel (fused_bwd.hip) for the stored-Z path at the shapes it is built for: dZ never leaves the CU
+  if (Zg && dIn && !dz_ext && layer_bwd_fused_ok(T, V, Ci, Co)) {
+    int rows = 0;
+    float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
+    if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, B, Ci, Co, st, &rows)))
+      return rc;
+    hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(T * V * V + V * T * T, 64) + (dap ? 1 : 0)), dim3(1024), 0, st, w.partials,
+                       rows, T * V * V, V * T * T, dA, dT, dap, rows, dslope_in, accumulate);
+    return check_launch("bwd_gcn_reduce");
+  }
   // 3. data path
   int grid_d;
   const float* dap_sum = nullptr;   // block partials of the producer's slope gradient (summed by stage 4's reduce)
