@@ -177,8 +177,10 @@ def test_plain_gcn_encoders_vs_reference(enc):
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=1e-6 + 1e-4 * np.abs(ref).max(), err_msg=k)
 
 
-def test_split_backward_on_side_stream_is_bit_identical(golden):
-    """coskad_layer_bwd_data_f32 + coskad_layer_gcn_params_f32 on a second stream == the single-call backward."""
+def test_split_backward_on_side_stream_matches(golden):
+    """coskad_layer_bwd_data_f32 + coskad_layer_gcn_params_f32 on a second stream (the split, per-kernel backward) against
+    the single-call backward, which runs the fused wave-per-clip kernel (csrc/fused_bwd.hip) for 16 / 32-channel layers:
+    two implementations of the same arithmetic, equal up to fp32 summation order (three Adam steps apart)."""
     from coskad_amd.models.sts.ae import STSE
     from coskad_amd.trainer import STSETrainStep
     from oracle import ref_cpu as R
@@ -194,7 +196,7 @@ def test_split_backward_on_side_stream_is_bit_identical(golden):
             eng.step(x)
         torch.cuda.synchronize()
         flats.append(eng.fp.flat.clone())
-    assert torch.equal(flats[0], flats[1])
+    np.testing.assert_allclose(flats[0].cpu().numpy(), flats[1].cpu().numpy(), rtol=2e-3, atol=2e-5)
 
 
 def test_wide_stack_c256_vs_oracle():
