@@ -50,6 +50,10 @@ __global__ void k_build_btab(const float* __restrict__ Aw, const float* __restri
 
 __device__ __forceinline__ void rmw(float* p, float v, bool first) { *p = first ? v : *p + v; }
 
+#ifndef FB_ABLATE
+#define FB_ABLATE 0   // timing-only builds (tools/ab_fused.sh): 1 staging + forward temporal, 2 position tiles, 4 dA extras + flush,
+#endif                //   8 spatial adjoint, 16 dT, 32 temporal adjoint, 64 epilogue
+
 template <int CT, int OT>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restrict__ in, const float* __restrict__ Zg,
                                                            const float* __restrict__ dU, const float* __restrict__ coef,
@@ -57,7 +61,6 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
                                                            float* __restrict__ dIn, float* __restrict__ partials,
                                                            float* __restrict__ dap, int B) {
   constexpr int Ci = 16 * CT, Co = 16 * OT, CiP = Ci;
-  constexpr int KU = OT * 4, KC = CT * 4, NOP = KU + 2 * KC;      // k-steps of dU, Z, X per position tile
   constexpr int KT0 = (Co + Ci) * CiP, DX0 = KT0 + CiP, KR0 = DX0 + (Co + Ci) * CiP;
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = threadIdx.x & 63;
@@ -112,80 +115,109 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     L = geo();
     TTab tt;
     load_ttab(tt, tabres, 0, l16);
-    stage(r1, 0, Ci);
+    if (!(FB_ABLATE & 1)) stage(r1, 0, Ci);
 
     // ---- Y = temporal mix of X, in place -----------------------------------------------------------------------------
     L = geo();
-    temporal_phase<16, CT>(r1, tt, L);
+    if (!(FB_ABLATE & 1)) temporal_phase<16, CT>(r1, tt, L);
 
     // ---- coefficient matrices as A operands (lane: output channel 16 ct + j, k slot q) and bias quads ------------------
     L = geo();
-    float wbt[KU][CT], wbr[KU][CT], wkt[KC][CT], wkr[KC][CT];
     f32x4 ktq[CT], krq[CT];
-    {
-      const int lq = (L.q * CiP + L.j) * 4;
+    const int lq = (L.q * CiP + L.j) * 4;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
+      const float4 a = buf_load4(cres, L.q * 16, (KT0 + 16 * ct) * 4), b = buf_load4(cres, L.q * 16, (KR0 + 16 * ct) * 4);
+      ktq[ct] = f32x4{a.x, a.y, a.z, a.w};
+      krq[ct] = f32x4{b.x, b.y, b.z, b.w};
+    }
+    // coefficient A operands of one 16-row group (lane: output channel 16 ct + j, k slot q), fetched one group ahead:
+    // wz multiplies into dZ, wx into dXres (dU groups feed both, Z groups only dZ, X groups only dXres)
+    float wz[2][4][CT], wx[2][4][CT];
+    auto cload = [&](int buf, int g) {
+      constexpr int OTc = OT, CTc = CT;
 #pragma unroll
-        for (int s = 0; s < KU; ++s) {
-          wbt[s][ct] = buf_load1(cres, lq, (4 * s * CiP + 16 * ct) * 4);
-          wbr[s][ct] = buf_load1(cres, lq, (DX0 + 4 * s * CiP + 16 * ct) * 4);
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          if (g < OTc) {
+            wz[buf][s][ct] = buf_load1(cres, lq, ((16 * g + 4 * s) * CiP + 16 * ct) * 4);
+            wx[buf][s][ct] = buf_load1(cres, lq, (DX0 + (16 * g + 4 * s) * CiP + 16 * ct) * 4);
+          } else if (g < OTc + CTc) {
+            wz[buf][s][ct] = buf_load1(cres, lq, ((Co + 16 * (g - OTc) + 4 * s) * CiP + 16 * ct) * 4);
+          } else {
+            wx[buf][s][ct] = buf_load1(cres, lq, (DX0 + (Co + 16 * (g - OTc - CTc) + 4 * s) * CiP + 16 * ct) * 4);
+          }
+        }
+    };
+
+    // ---- dZ = Bt.dU + Kt.Z + kt,  dXres = Br.dU + Kr.X + kr for ALL position tiles at once --------------------------------
+    // The K axis (rows of dU, Z, X) is walked in groups of 16 rows: a group is staged into R2 by full-line float4 loads
+    // (every byte of dU / Z / X is read once, aligned), then feeds 4 k-steps x 13 tiles x CT (x 2) independent MFMA
+    // chains from LDS.  The next group's loads are in flight while the current one is multiplied.
+    const int jc = L.j < T ? L.j : T - 1;
+    f32x4 az[NTILE][CT], xr[NTILE][CT];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) { az[t][ct] = ktq[ct]; xr[t][ct] = krq[ct]; }
+    constexpr int G4 = 16 * (TV / 4);                    // float4 of a 16-row group (816)
+    constexpr int GL = (G4 + 63) / 64;                   // per lane (13)
+    float4 gbuf[GL];
+    auto gload = [&](BufRes res, int row0) {
+#pragma unroll
+      for (int i = 0; i < GL; ++i) gbuf[i] = buf_load4(res, l16, (row0 * (TV / 4) + 64 * i) * 16);
+    };
+    auto gstore = [&](bool act) {
+#pragma unroll
+      for (int i = 0; i < GL; ++i) {
+        const int e4 = lane + 64 * i;
+        float4 v = gbuf[i];
+        if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+        const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
+        const bool ok = e4 < G4;
+        *reinterpret_cast<float2*>(r2 + (ok ? row * LD + col : PADCOL)) = float2{v.x, v.y};
+        *reinterpret_cast<float2*>(r2 + (ok ? row * LD + col + 2 : PADCOL)) = float2{v.z, v.w};
+      }
+    };
+    if (!(FB_ABLATE & 2)) {
+      constexpr int NG = OT + 2 * CT;                    // groups: dU (OT), Z (CT), X (CT)
+      gload(dures, 0);
+      cload(0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        gstore(g >= OT + CT && pre);
+        if (g + 1 < NG) {
+          if (g + 1 < OT) gload(dures, 16 * (g + 1));
+          else if (g + 1 < OT + CT) gload(zres, 16 * (g + 1 - OT));
+          else gload(xres, 16 * (g + 1 - OT - CT));
+          cload((g + 1) & 1, g + 1);
         }
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          wkt[s][ct] = buf_load1(cres, lq, ((Co + 4 * s) * CiP + 16 * ct) * 4);
-          wkr[s][ct] = buf_load1(cres, lq, (DX0 + (Co + 4 * s) * CiP + 16 * ct) * 4);
+        for (int s = 0; s < 4; ++s) {
+          float b[NTILE];
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) b[t] = r2[(4 * s + L.q) * LD + (t < T ? t * V + L.j : jc * V + 16)];
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              if (g < OT) {
+                az[t][ct] = mfma(wz[g & 1][s][ct], b[t], az[t][ct]);
+                xr[t][ct] = mfma(wx[g & 1][s][ct], b[t], xr[t][ct]);
+              } else if (g < OT + CT) {
+                az[t][ct] = mfma(wz[g & 1][s][ct], b[t], az[t][ct]);
+              } else {
+                xr[t][ct] = mfma(wx[g & 1][s][ct], b[t], xr[t][ct]);
+              }
+            }
         }
-        const float4 a = buf_load4(cres, L.q * 16, (KT0 + 16 * ct) * 4), b = buf_load4(cres, L.q * 16, (KR0 + 16 * ct) * 4);
-        ktq[ct] = f32x4{a.x, a.y, a.z, a.w};
-        krq[ct] = f32x4{b.x, b.y, b.z, b.w};
       }
     }
-
-    // ---- position tiles: dZ = Bt.dU + Kt.Z + kt,  dXres = Br.dU + Kr.X + kr,  dA ----------------------------------------
-    // B operands straight from HBM: row 4s + q of dU / Z / X at this lane's position (16 consecutive floats per row)
-    const int jc = L.j < T ? L.j : T - 1;
-    float bop[2][NOP];
-    auto load_ops = [&](float (&o)[NOP], int tile) {
-      const int pos = tile < T ? tile * V + L.j : jc * V + 16;
-      const int vo = (L.q * TV + pos) * 4;
-#pragma unroll
-      for (int s = 0; s < KU; ++s) o[s] = buf_load1(dures, vo, s * 4 * TV * 4);
-#pragma unroll
-      for (int s = 0; s < KC; ++s) o[KU + s] = buf_load1(zres, vo, s * 4 * TV * 4);
-#pragma unroll
-      for (int s = 0; s < KC; ++s) o[KU + KC + s] = buf_load1(xres, vo, s * 4 * TV * 4);
-    };
-    auto tile_mm = [&](const float (&o)[NOP], f32x4 (&az)[CT], f32x4 (&ax)[CT]) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) { az[ct] = ktq[ct]; ax[ct] = krq[ct]; }
-#pragma unroll
-      for (int s = 0; s < KU; ++s)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          az[ct] = mfma(wbt[s][ct], o[s], az[ct]);
-          ax[ct] = mfma(wbr[s][ct], o[s], ax[ct]);
-        }
-#pragma unroll
-      for (int s = 0; s < KC; ++s)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          az[ct] = mfma(wkt[s][ct], o[KU + s], az[ct]);
-          const float xv = pre ? prelu(o[KU + KC + s], a_in) : o[KU + KC + s];
-          ax[ct] = mfma(wkr[s][ct], xv, ax[ct]);
-        }
-    };
-    f32x4 xr[NTILE][CT];
-    f32x4 az17[CT];
     float exB[V];
-    load_ops(bop[0], T);            // the 17th-joint tile first: dA's column 16 needs Y intact
-    load_ops(bop[1], 0);
+    if (!(FB_ABLATE & 2)) {
     {
-      f32x4 ax[CT];
-      tile_mm(bop[0], az17, ax);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) xr[T][ct] = ax[ct];
-      // dA[t = j][v][16] = sum_c Y[c][t, v] dZ[c][t, 16]
+      // the 17th-joint tile first: dA[t = j][v][16] = sum_c Y[c][t, v] dZ[c][t, 16] needs Y intact
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         float s = 0.f;
@@ -193,53 +225,51 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         for (int ct = 0; ct < CT; ++ct) {
           const f32x4 y = tile_load(r1, 16 * ct, jc * V + v, L);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s = fmaf(y[r], az17[ct][r], s);
+          for (int r = 0; r < 4; ++r) s = fmaf(y[r], az[T][ct][r], s);
         }
-        exB[v] = quad_sum(s);
+        exB[v] = (FB_ABLATE & 4) ? s : quad_sum(s);
       }
     }
     f32x4 dAacc[T];
     float exA[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) load_ops(bop[(t + 1) & 1 ? 0 : 1], t + 1);
-      f32x4 az[CT], ax[CT];
-      tile_mm(bop[t & 1 ? 0 : 1], az, ax);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       float s16 = 0.f;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        xr[t][ct] = ax[ct];
         const f32x4 y = tile_load(r1, 16 * ct, t * V + L.j, L);          // A operand: Y[16 ct + 4q + r][t, v = j]
         const f32x4 y16 = tile_load(r1, 16 * ct, t * V + 16, L);        // Y[..][t, 16] (same address in every column)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          acc = mfma(y[r], az[ct][r], acc);
-          s16 = fmaf(y16[r], az[ct][r], s16);
+          acc = mfma(y[r], az[t][ct][r], acc);
+          s16 = fmaf(y16[r], az[t][ct][r], s16);
         }
       }
       dAacc[t] = acc;
       exA[t] = quad_sum(s16);
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, t * V + L.j, true, az[ct], L);   // dZ over Y's frame t
+      for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, t * V + L.j, true, az[t][ct], L);   // dZ over Y's frame t
     }
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, jc * V + 16, L.j < T, az17[ct], L);
+    for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, jc * V + 16, L.j < T, az[T][ct], L);
     // dA partial sums of this wave (its own row of the workspace: read-modify-write, first clip writes)
+    if (!(FB_ABLATE & 4))
 #pragma unroll
     for (int t = 0; t < T; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) rmw(prow + t * V * V + (4 * L.q + r) * V + L.j, dAacc[t][r], first);
       if (L.q == 0) rmw(prow + t * V * V + 16 * V + L.j, exA[t], first);
     }
-    if (L.q == 0 && L.j < T) {
+    if (L.q == 0 && L.j < T && !(FB_ABLATE & 4)) {
 #pragma unroll
       for (int v = 0; v < V; ++v) rmw(prow + L.j * V * V + v * V + 16, exB[v], first);
     }
+    }   // FB_ABLATE & 2
 
     // ---- dY = spatial adjoint of dZ, in place (operand reads of frame t+1 before the stores of frame t) ----------------
     L = geo();
-    {
+    if (!(FB_ABLATE & 8)) {
       SpatRec rec = load_spat(tabres, 0, 0, l16);
       SOp op[CT];
 #pragma unroll
@@ -265,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
 
     // ---- dT[v] = X_v^T dY_v: X re-staged 16 rows at a time beside the image --------------------------------------------
     L = geo();
-    {
+    if (!(FB_ABLATE & 16)) {
       f32x4 dTacc[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) dTacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -296,30 +326,49 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     // ---- gcn^T: temporal adjoint in place --------------------------------------------------------------------------------
     L = geo();
     load_ttab(tt, tabres, TEMP_F4 + SPAT_F4, l16);
-    temporal_phase<16, CT>(r1, tt, L);
+    if (!(FB_ABLATE & 32)) temporal_phase<16, CT>(r1, tt, L);
 
     // ---- dU_prev = (gcn^T(dZ) + dXres) * PReLU'(U_prev), slope gradient ---------------------------------------------------
+    // dXres joins the image tile by tile (LDS only); the image then leaves row-wise: float4 loads of the pre-activations
+    // (the PReLU mask) and float4 stores of dU_prev, full lines both ways.
     L = geo();
+    if (!(FB_ABLATE & 64)) {
 #pragma unroll
-    for (int tile = 0; tile < NTILE; ++tile) {
-      const bool fr = tile < T;
-      const int pos = fr ? tile * V + L.j : jc * V + 16;
-      const bool ok = fr || L.j < T;
-      const int vo = ok ? (4 * L.q * TV + pos) * 4 : 0x7fffff00;       // masked lanes: out of the buffer's range (dropped)
+      for (int tile = 0; tile < NTILE; ++tile) {
+        const bool fr = tile < T;
+        const int pos = fr ? tile * V + L.j : jc * V + 16;
+        const bool ok = fr || L.j < T;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        f32x4 g = tile_load(r1, 16 * ct, pos, L) + xr[tile][ct];
-        if (pre) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float u = buf_load1(xres, vo, (16 * ct + r) * TV * 4);   // the pre-activation itself (0 for masked lanes)
-            if (u < 0.f) da = fmaf(g[r], u, da);
-            g[r] = u > 0.f ? g[r] : a_in * g[r];
-          }
+        for (int ct = 0; ct < CT; ++ct) {
+          const f32x4 g = tile_load(r1, 16 * ct, pos, L) + xr[tile][ct];
+          tile_store(r1, 16 * ct, pos, ok, g, L);
         }
+      }
+      constexpr int N4 = Ci * (TV / 4), NL = (N4 + 63) / 64;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g[r]), ores, vo, (16 * ct + r) * TV * 4, 0);
+      for (int i0 = 0; i0 < NL; i0 += 7) {
+        float4 u[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+          if (i0 + k < NL) u[k] = pre ? buf_load4(xres, l16, 64 * (i0 + k) * 16) : float4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+          if (i0 + k < NL) {
+            const int e4 = lane + 64 * (i0 + k);
+            const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
+            const float* p = r1 + (e4 < N4 ? row * LD + col : PADCOL);
+            const float2 g0 = *reinterpret_cast<const float2*>(p), g1 = *reinterpret_cast<const float2*>(p + 2);
+            float g[4] = {g0.x, g0.y, g1.x, g1.y};
+            const float uu[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+            if (pre && e4 < N4) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if (uu[c] < 0.f) da = fmaf(g[c], uu[c], da);
+                g[c] = uu[c] > 0.f ? g[c] : a_in * g[c];
+              }
+            }
+            buf_store4(ores, l16, 64 * (i0 + k) * 16, float4{g[0], g[1], g[2], g[3]});    // beyond the clip: dropped (bounds check)
+          }
       }
     }
     first = false;

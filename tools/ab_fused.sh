@@ -5,9 +5,10 @@
 cmd=$1; shift
 if [ "$cmd" = build ]; then
   name=$1; shift
+  src=${AB_SRC:-fused_fwd}     # AB_SRC=fused_bwd tools/ab_fused.sh build ...
   cd coskad_amd/csrc
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-variable "$@" -c fused_fwd.hip -o /tmp/ff_$name.o || exit 1
-  objs=$(ls *.o | grep -v fused_fwd.o)
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-variable "$@" -c $src.hip -o /tmp/ff_$name.o || exit 1
+  objs=$(ls *.o | grep -v $src.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/ff_$name.o -o ../../tools/libf_$name.so
 else
   cp coskad_amd/libcoskad_hip.so /tmp/lib_orig.so
@@ -15,7 +16,7 @@ else
     for v in "$@"; do
       cp tools/libf_$v.so coskad_amd/libcoskad_hip.so
       echo -n "$v: "
-      timeout -k 10 120 python tools/bench_fused.py 2>&1 | tail -1
+      timeout -k 10 120 python ${AB_BENCH:-tools/bench_fused.py} 2>&1 | tail -1
     done
   done
   cp /tmp/lib_orig.so coskad_amd/libcoskad_hip.so
