@@ -52,7 +52,7 @@ __device__ __forceinline__ void rmw(float* p, float v, bool first) { *p = first 
 
 #ifndef FB_ABLATE
 #define FB_ABLATE 0   // timing-only builds (tools/ab_fused.sh): 1 staging + forward temporal, 2 position tiles, 4 dA extras + flush,
-#endif                //   8 spatial adjoint, 16 dT, 32 temporal adjoint, 64 epilogue
+#endif                //   8 spatial adjoint, 16 dT, 32 temporal adjoint, 64 epilogue, 128 K-group GEMM only, 256 dA column 16, 512 dA main
 
 template <int CT, int OT>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restrict__ in, const float* __restrict__ Zg,
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         *reinterpret_cast<float2*>(r2 + (ok ? row * LD + col + 2 : PADCOL)) = float2{v.z, v.w};
       }
     };
-    if (!(FB_ABLATE & 2)) {
+    if (!(FB_ABLATE & (2 | 128))) {
       constexpr int NG = OT + 2 * CT;                    // groups: dU (OT), Z (CT), X (CT)
       gload(dures, 0);
       cload(0, 0);
@@ -214,12 +214,18 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         }
       }
     }
-    float exB[V];
+    float exB[V] = {};
+    f32x4 dAacc[T];
+    float exA[T], pa[T][5], pb[V];
+    if (FB_ABLATE) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) { dAacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; exA[t] = 0.f; }
+    }
     if (!(FB_ABLATE & 2)) {
     {
       // the 17th-joint tile first: dA[t = j][v][16] = sum_c Y[c][t, v] dZ[c][t, 16] needs Y intact
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
+      for (int v = 0; v < ((FB_ABLATE & 256) ? 0 : V); ++v) {
         float s = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -230,14 +236,12 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         exB[v] = (FB_ABLATE & 4) ? s : quad_sum(s);
       }
     }
-    f32x4 dAacc[T];
-    float exA[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       float s16 = 0.f;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
+      for (int ct = 0; ct < ((FB_ABLATE & 512) ? 0 : CT); ++ct) {
         const f32x4 y = tile_load(r1, 16 * ct, t * V + L.j, L);          // A operand: Y[16 ct + 4q + r][t, v = j]
         const f32x4 y16 = tile_load(r1, 16 * ct, t * V + 16, L);        // Y[..][t, 16] (same address in every column)
 #pragma unroll
@@ -253,21 +257,22 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, jc * V + 16, L.j < T, az[T][ct], L);
-    // dA partial sums of this wave (its own row of the workspace: read-modify-write, first clip writes)
-    if (!(FB_ABLATE & 4))
+    // dA partial sums of this wave live in its own row of the workspace (read-modify-write; the first clip writes).  The
+    // loads are issued here and consumed behind the spatial adjoint, so their L2 round trips cost nothing.
+    if (!(FB_ABLATE & 4) && !first) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
+      for (int t = 0; t < T; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rmw(prow + t * V * V + (4 * L.q + r) * V + L.j, dAacc[t][r], first);
-      if (L.q == 0) rmw(prow + t * V * V + 16 * V + L.j, exA[t], first);
-    }
-    if (L.q == 0 && L.j < T && !(FB_ABLATE & 4)) {
+        for (int r = 0; r < 4; ++r) pa[t][r] = prow[t * V * V + (4 * L.q + r) * V + L.j];
+        pa[t][4] = prow[t * V * V + 16 * V + L.j];
+      }
 #pragma unroll
-      for (int v = 0; v < V; ++v) rmw(prow + L.j * V * V + v * V + 16, exB[v], first);
+      for (int v = 0; v < V; ++v) pb[v] = prow[jc * V * V + v * V + 16];
     }
     }   // FB_ABLATE & 2
 
     // ---- dY = spatial adjoint of dZ, in place (operand reads of frame t+1 before the stores of frame t) ----------------
+    if (!(FB_ABLATE & 16)) gload(xres, 0);             // X rows 0..15 for dT: in flight during the adjoint
     L = geo();
     if (!(FB_ABLATE & 8)) {
       SpatRec rec = load_spat(tabres, 0, 0, l16);
@@ -293,40 +298,64 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
       }
     }
 
+    if (!(FB_ABLATE & (2 | 4))) {                      // complete the dA read-modify-write
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prow[t * V * V + (4 * L.q + r) * V + L.j] = first ? dAacc[t][r] : pa[t][r] + dAacc[t][r];
+        if (L.q == 0) prow[t * V * V + 16 * V + L.j] = first ? exA[t] : pa[t][4] + exA[t];
+      }
+      if (L.q == 0 && L.j < T) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) prow[L.j * V * V + v * V + 16] = first ? exB[v] : pb[v] + exB[v];
+      }
+    }
+
     // ---- dT[v] = X_v^T dY_v: X re-staged 16 rows at a time beside the image --------------------------------------------
     L = geo();
-    if (!(FB_ABLATE & 16)) {
-      f32x4 dTacc[V];
+    f32x4 dTacc[V];
 #pragma unroll
-      for (int v = 0; v < V; ++v) dTacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < V; ++v) dTacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(FB_ABLATE & 16)) {
       const int ic = L.j < T ? L.j : T - 1;
 #pragma unroll
       for (int h = 0; h < CT; ++h) {
-        stage(r2, 16 * h, 16);
+        gstore(pre);                                   // X rows 16h .. 16h+15 (fetched before the spatial adjoint / the previous half)
+        if (h + 1 < CT) gload(xres, 16 * (h + 1));
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
+        for (int s = 0; s < 4; ++s) {                  // 17 independent chains per k-step
+          float a[V], b[V];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            float a = r2[(4 * s + L.q) * LD + ic * V + v];
-            float b = r1[(16 * h + 4 * s + L.q) * LD + ic * V + v];
-            a = L.j < T ? a : 0.f;
-            b = L.j < T ? b : 0.f;
-            dTacc[v] = mfma(a, b, dTacc[v]);
+          for (int v = 0; v < V; ++v) {
+            a[v] = r2[(4 * s + L.q) * LD + ic * V + v];
+            b[v] = r1[(16 * h + 4 * s + L.q) * LD + ic * V + v];
           }
+#pragma unroll
+          for (int v = 0; v < V; ++v) dTacc[v] = mfma(L.j < T ? a[v] : 0.f, L.j < T ? b[v] : 0.f, dTacc[v]);
         }
       }
-      // D[row t = 4q + r][col q' = j]
+    }
+    // dT partial sums: the read half of the read-modify-write before the temporal adjoint, the write half behind it
+    float pt[V][4];
+    if (!(FB_ABLATE & 16) && !first) {
 #pragma unroll
       for (int v = 0; v < V; ++v)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (4 * L.q + r < T && L.j < T) rmw(prow + NA + v * T * T + (4 * L.q + r) * T + L.j, dTacc[v][r], first);
+        for (int r = 0; r < 4; ++r) pt[v][r] = prow[NA + v * T * T + (4 * L.q + r < T ? 4 * L.q + r : 0) * T + jc];
     }
 
     // ---- gcn^T: temporal adjoint in place --------------------------------------------------------------------------------
     L = geo();
     load_ttab(tt, tabres, TEMP_F4 + SPAT_F4, l16);
     if (!(FB_ABLATE & 32)) temporal_phase<16, CT>(r1, tt, L);
+    if (!(FB_ABLATE & 16)) {                           // D[row t = 4q + r][col q' = j] of dT[v]
+#pragma unroll
+      for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * L.q + r < T && L.j < T)
+            prow[NA + v * T * T + (4 * L.q + r) * T + L.j] = first ? dTacc[v][r] : pt[v][r] + dTacc[v][r];
+    }
 
     // ---- dU_prev = (gcn^T(dZ) + dXres) * PReLU'(U_prev), slope gradient ---------------------------------------------------
     // dXres joins the image tile by tile (LDS only); the image then leaves row-wise: float4 loads of the pre-activations
