@@ -20,7 +20,13 @@ namespace fb {
 
 using namespace ff;
 
-constexpr int NA = T * V * V, NTT = V * T * T, EROW = NA + NTT;
+
+// A wave's partial sums of dA / dT in the workspace, lane-major (one float4 per lane and record: 1 KB per load / store):
+//   records [0, 12)   dA[t][4q + r][j]            (t = record)
+//           [12, 15)  dA[t = 4c + r][16][j]       (q == 0 lanes)
+//           [15, 20)  dA[t = j][v = 4c + r][16]   (q == 0, j < 12 lanes; v < 17)
+//           [20, 37)  dT[v][4q + r][j]            (v = record - 20; 4q + r < 12, j < 12)
+constexpr int PR_A = 0, PR_XA = 12, PR_XB = 15, PR_T = 20, PR_N = 37, EROW = PR_N * 256;
 constexpr int SPAT_F4 = T * 3 * 64;                  // float4 records of one spatial section
 constexpr int BTAB_F4 = 2 * TEMP_F4 + SPAT_F4;       // [forward temporal][adjoint spatial][adjoint temporal]
 
@@ -48,7 +54,42 @@ __global__ void k_build_btab(const float* __restrict__ Aw, const float* __restri
   tab[e] = val;
 }
 
-__device__ __forceinline__ void rmw(float* p, float v, bool first) { *p = first ? v : *p + v; }
+// dA, dT (+)= sum over the P lane-major partial rows (fp64, fixed order); one extra block sums the slope partials
+__global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__ partials, int P, float* __restrict__ dA,
+                                                       float* __restrict__ dT, const float* __restrict__ dap, int ndap,
+                                                       float* __restrict__ dslope, int accumulate) {
+  __shared__ double sh[1024];
+  constexpr int NB = EROW / 64;
+  if ((int)blockIdx.x == NB) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < ndap; i += 1024) s += (double)dap[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dslope[0] = accumulate ? dslope[0] + (float)sh[0] : (float)sh[0];
+    return;
+  }
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  double s = 0.0;
+  for (int p = slice; p < P; p += 16) s += (double)partials[(size_t)p * EROW + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (slice == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+    const int rec = e >> 8, l = (e >> 2) & 63, r = e & 3, j = l & 15, q = l >> 4;
+    float* out = nullptr;
+    if (rec < PR_XA) out = dA + rec * V * V + (4 * q + r) * V + j;
+    else if (rec < PR_XB) { if (q == 0) out = dA + (4 * (rec - PR_XA) + r) * V * V + 16 * V + j; }
+    else if (rec < PR_T) { const int v = 4 * (rec - PR_XB) + r; if (q == 0 && j < T && v < V) out = dA + j * V * V + v * V + 16; }
+    else if (4 * q + r < T && j < T) out = dT + (rec - PR_T) * T * T + (4 * q + r) * T + j;
+    if (out) *out = accumulate ? *out + (float)t : (float)t;
+  }
+}
 
 #ifndef FB_ABLATE
 #define FB_ABLATE 0   // timing-only builds (tools/ab_fused.sh): 1 staging + forward temporal, 2 position tiles, 4 dA extras + flush,
@@ -59,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
                                                            const float* __restrict__ dU, const float* __restrict__ coef,
                                                            const float* __restrict__ btab, const float* __restrict__ in_slope,
                                                            float* __restrict__ dIn, float* __restrict__ partials,
-                                                           float* __restrict__ dap, int B) {
+                                                           float* __restrict__ dap, float* __restrict__ xscr, int B) {
   constexpr int Ci = 16 * CT, Co = 16 * OT, CiP = Ci;
   constexpr int KT0 = (Co + Ci) * CiP, DX0 = KT0 + CiP, KR0 = DX0 + (Co + Ci) * CiP;
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -79,14 +120,15 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
   const int l16 = lane * 16;
   const BufRes tabres = make_res(btab, BTAB_F4 * 16u);
   const BufRes cres = make_res(coef, (KR0 + CiP) * 4u);
-  float* prow = partials + (size_t)(blockIdx.x * 4 + wave) * EROW;
+  const BufRes pres = make_res(partials + (size_t)(blockIdx.x * 4 + wave) * EROW, EROW * 4u);
+  // dXres = Br.dU + Kr.X + kr waits for the adjoint mixing outside the register file: a tile-major slab of this wave in the
+  // workspace (26 KB, L2-resident; 1 KB per store / load), which frees 104 registers across three phases
+  const BufRes sres = make_res(xscr + (size_t)(blockIdx.x * 4 + wave) * (NTILE * 2 * 256), NTILE * 2 * 256 * 4u);
   const int nwaves = gridDim.x * 4;
   float da = 0.f;
-  bool first = true;
   int clip = blockIdx.x * 4 + wave;
-  if (clip >= B) {                                   // a wave without clips still owns a partial row: zero it
-    for (int e = lane; e < EROW; e += 64) prow[e] = 0.f;
-  }
+#pragma unroll
+  for (int k = 0; k < PR_N; ++k) buf_store4(pres, l16, k * 1024, float4{0.f, 0.f, 0.f, 0.f});   // this wave's partial row starts at 0
 
   for (; clip < B; clip += nwaves) {
     const BufRes xres = make_res(in + (size_t)clip * Ci * TV, Ci * TV * 4u);
@@ -214,9 +256,16 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         }
       }
     }
+    if (!(FB_ABLATE & 2)) {
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          buf_store4(sres, l16, (t * 2 + ct) * 1024, float4{xr[t][ct][0], xr[t][ct][1], xr[t][ct][2], xr[t][ct][3]});
+    }
     float exB[V] = {};
     f32x4 dAacc[T];
-    float exA[T], pa[T][5], pb[V];
+    float exA[T];
     if (FB_ABLATE) {
 #pragma unroll
       for (int t = 0; t < T; ++t) { dAacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; exA[t] = 0.f; }
@@ -257,22 +306,29 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, jc * V + 16, L.j < T, az[T][ct], L);
-    // dA partial sums of this wave live in its own row of the workspace (read-modify-write; the first clip writes).  The
-    // loads are issued here and consumed behind the spatial adjoint, so their L2 round trips cost nothing.
-    if (!(FB_ABLATE & 4) && !first) {
+    // dA partial sums of this wave: read-modify-write of its lane-major row (20 x 1 KB each way, loads batched)
+    if (!(FB_ABLATE & 4)) {
+      float4 pv[PR_T];
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
+      for (int k = 0; k < PR_T; ++k) pv[k] = buf_load4(pres, l16, k * 1024);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pa[t][r] = prow[t * V * V + (4 * L.q + r) * V + L.j];
-        pa[t][4] = prow[t * V * V + 16 * V + L.j];
-      }
+      for (int t = 0; t < T; ++t)
+        buf_store4(pres, l16, (PR_A + t) * 1024,
+                   float4{pv[t].x + dAacc[t][0], pv[t].y + dAacc[t][1], pv[t].z + dAacc[t][2], pv[t].w + dAacc[t][3]});
 #pragma unroll
-      for (int v = 0; v < V; ++v) pb[v] = prow[jc * V * V + v * V + 16];
+      for (int c = 0; c < 3; ++c)
+        buf_store4(pres, l16, (PR_XA + c) * 1024, float4{pv[PR_XA + c].x + exA[4 * c], pv[PR_XA + c].y + exA[4 * c + 1],
+                                                         pv[PR_XA + c].z + exA[4 * c + 2], pv[PR_XA + c].w + exA[4 * c + 3]});
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+        buf_store4(pres, l16, (PR_XB + c) * 1024,
+                   float4{pv[PR_XB + c].x + exB[4 * c], pv[PR_XB + c].y + (4 * c + 1 < V ? exB[4 * c + 1 < V ? 4 * c + 1 : 0] : 0.f),
+                          pv[PR_XB + c].z + (4 * c + 2 < V ? exB[4 * c + 2 < V ? 4 * c + 2 : 0] : 0.f),
+                          pv[PR_XB + c].w + (4 * c + 3 < V ? exB[4 * c + 3 < V ? 4 * c + 3 : 0] : 0.f)});
     }
     }   // FB_ABLATE & 2
 
     // ---- dY = spatial adjoint of dZ, in place (operand reads of frame t+1 before the stores of frame t) ----------------
-    if (!(FB_ABLATE & 16)) gload(xres, 0);             // X rows 0..15 for dT: in flight during the adjoint
     L = geo();
     if (!(FB_ABLATE & 8)) {
       SpatRec rec = load_spat(tabres, 0, 0, l16);
@@ -298,19 +354,6 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
       }
     }
 
-    if (!(FB_ABLATE & (2 | 4))) {                      // complete the dA read-modify-write
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) prow[t * V * V + (4 * L.q + r) * V + L.j] = first ? dAacc[t][r] : pa[t][r] + dAacc[t][r];
-        if (L.q == 0) prow[t * V * V + 16 * V + L.j] = first ? exA[t] : pa[t][4] + exA[t];
-      }
-      if (L.q == 0 && L.j < T) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) prow[L.j * V * V + v * V + 16] = first ? exB[v] : pb[v] + exB[v];
-      }
-    }
-
     // ---- dT[v] = X_v^T dY_v: X re-staged 16 rows at a time beside the image --------------------------------------------
     L = geo();
     f32x4 dTacc[V];
@@ -318,6 +361,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     for (int v = 0; v < V; ++v) dTacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!(FB_ABLATE & 16)) {
       const int ic = L.j < T ? L.j : T - 1;
+      gload(xres, 0);
 #pragma unroll
       for (int h = 0; h < CT; ++h) {
         gstore(pre);                                   // X rows 16h .. 16h+15 (fetched before the spatial adjoint / the previous half)
@@ -335,33 +379,34 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         }
       }
     }
-    // dT partial sums: the read half of the read-modify-write before the temporal adjoint, the write half behind it
-    float pt[V][4];
-    if (!(FB_ABLATE & 16) && !first) {
+    if (!(FB_ABLATE & 16)) {                           // dT partial sums: 17 x 1 KB each way
+      float4 pv[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) pv[v] = buf_load4(pres, l16, (PR_T + v) * 1024);
 #pragma unroll
       for (int v = 0; v < V; ++v)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pt[v][r] = prow[NA + v * T * T + (4 * L.q + r < T ? 4 * L.q + r : 0) * T + jc];
+        buf_store4(pres, l16, (PR_T + v) * 1024,
+                   float4{pv[v].x + dTacc[v][0], pv[v].y + dTacc[v][1], pv[v].z + dTacc[v][2], pv[v].w + dTacc[v][3]});
     }
 
     // ---- gcn^T: temporal adjoint in place --------------------------------------------------------------------------------
     L = geo();
     load_ttab(tt, tabres, TEMP_F4 + SPAT_F4, l16);
     if (!(FB_ABLATE & 32)) temporal_phase<16, CT>(r1, tt, L);
-    if (!(FB_ABLATE & 16)) {                           // D[row t = 4q + r][col q' = j] of dT[v]
-#pragma unroll
-      for (int v = 0; v < V; ++v)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (4 * L.q + r < T && L.j < T)
-            prow[NA + v * T * T + (4 * L.q + r) * T + L.j] = first ? dTacc[v][r] : pt[v][r] + dTacc[v][r];
-    }
 
     // ---- dU_prev = (gcn^T(dZ) + dXres) * PReLU'(U_prev), slope gradient ---------------------------------------------------
     // dXres joins the image tile by tile (LDS only); the image then leaves row-wise: float4 loads of the pre-activations
     // (the PReLU mask) and float4 stores of dU_prev, full lines both ways.
     L = geo();
     if (!(FB_ABLATE & 64)) {
+      f32x4 xq[NTILE][CT];
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const float4 v = buf_load4(sres, l16, (t * 2 + ct) * 1024);
+          xq[t][ct] = f32x4{v.x, v.y, v.z, v.w};
+        }
 #pragma unroll
       for (int tile = 0; tile < NTILE; ++tile) {
         const bool fr = tile < T;
@@ -369,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         const bool ok = fr || L.j < T;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          const f32x4 g = tile_load(r1, 16 * ct, pos, L) + xr[tile][ct];
+          const f32x4 g = tile_load(r1, 16 * ct, pos, L) + xq[tile][ct];
           tile_store(r1, 16 * ct, pos, ok, g, L);
         }
       }
@@ -400,7 +445,6 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
           }
       }
     }
-    first = false;
   }
   da = wave_sum(da);
   if (lane == 0 && dap) dap[blockIdx.x * 4 + wave] = da;
@@ -411,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
 // stage 3 + 4 of launch_layer_bwd for the shapes this kernel is built for; partials: >= 4 * grid rows of T*V*V + V*T*T floats
 int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
                            const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
-                           int B, int Ci, int Co, hipStream_t st, int* rows_out) {
+                           float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out) {
   hipLaunchKernelGGL(fb::k_build_btab, dim3(ceil_div(fb::BTAB_F4 * 4, 256)), dim3(256), 0, st, Aw, Tw, btab);
   int rc;
   if ((rc = check_launch("bwd_build_btab"))) return rc;
@@ -423,7 +467,7 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
   do {                                                                                                                 \
     auto k = fb::k_layer_bwd_fused<CT, OT>;                                                                            \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, B);    \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, xscr, B); \
   } while (0)
   {
     ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
@@ -437,6 +481,13 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
   }
 #undef LAUNCH_FB
   return check_launch("bwd_fused");
+}
+
+int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, const float* dap, float* dslope, int accumulate,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(fb::k_reduce_fused, dim3(fb::EROW / 64 + (dap ? 1 : 0)), dim3(1024), 0, st, partials, rows, dA, dT, dap, rows,
+                     dslope, accumulate);
+  return check_launch("bwd_reduce_fused");
 }
 
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co) {

@@ -1106,18 +1106,24 @@ struct BwdWs {
   float* coef;
   float* dap;
   float* btab;
+  float* xscr;
   float* dz;
 };
 
 // fused_bwd.hip
 int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
                            const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
-                           int B, int Ci, int Co, hipStream_t st, int* rows_out);
+                           float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out);
+constexpr size_t kXscrFloats = (size_t)kMaxGridBwd * 13 * 2 * 256;   // fused_bwd.hip: one tile-major dXres slab per wave
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
+int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, const float* dap, float* dslope, int accumulate,
+                        hipStream_t st);
+constexpr size_t kFusedRowFloats = 37 * 256;   // lane-major partial row of fused_bwd.hip
 
 static size_t bwd_emax(int Ci, int Co, int T, int V) {
   const size_t e1 = 2 * (size_t)Co * Ci + Co;
-  const size_t e2 = (size_t)T * V * V + (size_t)V * T * T;
+  size_t e2 = (size_t)T * V * V + (size_t)V * T * T;
+  if (e2 < kFusedRowFloats) e2 = kFusedRowFloats;
   return e1 > e2 ? e1 : e2;
 }
 
@@ -1126,7 +1132,7 @@ size_t layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V) {
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   return al(kMaxGridBwd * E * sizeof(float)) + al(E * sizeof(double)) +
          al(coef_floats(Ci, Co) * sizeof(float)) + al((size_t)((B > kMaxGridBwd ? B : kMaxGridBwd) + 1) * sizeof(float)) +
-         al((size_t)kBtabFloats * sizeof(float)) + al((size_t)B * Ci * T * V * sizeof(float));
+         al((size_t)kBtabFloats * sizeof(float)) + al(kXscrFloats * sizeof(float)) + al((size_t)B * Ci * T * V * sizeof(float));
 }
 
 static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
@@ -1139,6 +1145,7 @@ static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
   w.coef = reinterpret_cast<float*>(p);     p += al(coef_floats(Ci, Co) * sizeof(float));
   w.dap = reinterpret_cast<float*>(p);      p += al((size_t)((B > kMaxGridBwd ? B : kMaxGridBwd) + 1) * sizeof(float));
   w.btab = reinterpret_cast<float*>(p);     p += al((size_t)kBtabFloats * sizeof(float));
+  w.xscr = reinterpret_cast<float*>(p);     p += al(kXscrFloats * sizeof(float));
   w.dz = reinterpret_cast<float*>(p);
   return w;
 }
@@ -1302,11 +1309,9 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   if (Zg && dIn && !dz_ext && layer_bwd_fused_ok(T, V, Ci, Co)) {
     int rows = 0;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
-    if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, B, Ci, Co, st, &rows)))
+    if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows)))
       return rc;
-    hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(T * V * V + V * T * T, 64) + (dap ? 1 : 0)), dim3(1024), 0, st, w.partials,
-                       rows, T * V * V, V * T * T, dA, dT, dap, rows, dslope_in, accumulate);
-    return check_launch("bwd_gcn_reduce");
+    return launch_reduce_fused(w.partials, rows, dA, dT, dap, dslope_in, accumulate, st);
   }
   // 3. data path
   int grid_d;
