@@ -23,10 +23,11 @@ using namespace ff;
 
 // A wave's partial sums of dA / dT in the workspace, lane-major (one float4 per lane and record: 1 KB per load / store):
 //   records [0, 12)   dA[t][4q + r][j]            (t = record)
-//           [12, 15)  dA[t = 4c + r][16][j]       (q == 0 lanes)
-//           [15, 20)  dA[t = j][v = 4c + r][16]   (q == 0, j < 12 lanes; v < 17)
-//           [20, 37)  dT[v][4q + r][j]            (v = record - 20; 4q + r < 12, j < 12)
-constexpr int PR_A = 0, PR_XA = 12, PR_XB = 15, PR_T = 20, PR_N = 37, EROW = PR_N * 256;
+//           12        dA[t = 4q + r][16][j]       (t < 12)
+//           13        dA[t = j][v = 4q + r][16]   (j < 12)
+//           14        dA[t = j][16][16]           (r == 0, q == 0, j < 12)
+//           [15, 32)  dT[v][4q + r][j]            (v = record - 15; 4q + r < 12, j < 12)
+constexpr int PR_A = 0, PR_XA = 12, PR_XB = 13, PR_C = 14, PR_T = 15, PR_N = 32, EROW = PR_N * 256;
 constexpr int SPAT_F4 = T * 3 * 64;                  // float4 records of one spatial section
 constexpr int BTAB_F4 = 2 * TEMP_F4 + SPAT_F4;       // [forward temporal][adjoint spatial][adjoint temporal]
 
@@ -84,25 +85,29 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
     const int rec = e >> 8, l = (e >> 2) & 63, r = e & 3, j = l & 15, q = l >> 4;
     float* out = nullptr;
     if (rec < PR_XA) out = dA + rec * V * V + (4 * q + r) * V + j;
-    else if (rec < PR_XB) { if (q == 0) out = dA + (4 * (rec - PR_XA) + r) * V * V + 16 * V + j; }
-    else if (rec < PR_T) { const int v = 4 * (rec - PR_XB) + r; if (q == 0 && j < T && v < V) out = dA + j * V * V + v * V + 16; }
+    else if (rec == PR_XA) { if (4 * q + r < T) out = dA + (4 * q + r) * V * V + 16 * V + j; }
+    else if (rec == PR_XB) { if (j < T) out = dA + j * V * V + (4 * q + r) * V + 16; }
+    else if (rec == PR_C) { if (r == 0 && q == 0 && j < T) out = dA + j * V * V + 16 * V + 16; }
     else if (4 * q + r < T && j < T) out = dT + (rec - PR_T) * T * T + (4 * q + r) * T + j;
     if (out) *out = accumulate ? *out + (float)t : (float)t;
   }
 }
 
-#ifndef FB_ABLATE
-#define FB_ABLATE 0   // timing-only builds (tools/ab_fused.sh): 1 staging + forward temporal, 2 position tiles, 4 dA extras + flush,
-#endif                //   8 spatial adjoint, 16 dT, 32 temporal adjoint, 64 epilogue, 128 K-group GEMM only, 256 dA column 16, 512 dA main
+#ifdef FB_TIMING   // timing-only builds: per-phase wall-clock (100 MHz) sums of wave 0, written over dIn[block * 16 + phase]
+#define FB_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = wall_clock64(); tacc[k] += (float)(now_ - tlast); tlast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FB_STAMP(k) do {} while (0)
+#endif
 
 template <int CT, int OT>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restrict__ in, const float* __restrict__ Zg,
                                                            const float* __restrict__ dU, const float* __restrict__ coef,
                                                            const float* __restrict__ btab, const float* __restrict__ in_slope,
                                                            float* __restrict__ dIn, float* __restrict__ partials,
-                                                           float* __restrict__ dap, float* __restrict__ xscr, int B) {
-  constexpr int Ci = 16 * CT, Co = 16 * OT, CiP = Ci;
+                                                           float* __restrict__ dap, int B) {
+  constexpr int Ci = 16 * CT, Co = 16 * OT, CiP = Ci, NG = OT + CT;
   constexpr int KT0 = (Co + Ci) * CiP, DX0 = KT0 + CiP, KR0 = DX0 + (Co + Ci) * CiP;
+  static_assert(CT <= 2, "dT stages one 16-row half of X at a time");
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -114,223 +119,215 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     asm volatile("" : "+v"(l));
     return Lane{l & 15, l >> 4};
   };
+  // the same for row-wise staging addresses: recomputed where they are used, never carried across the clip loop
+  auto olane = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
   Lane L = geo();
-  const bool pre = in_slope != nullptr;
-  const float a_in = pre ? in_slope[0] : 0.f;
+  constexpr bool pre = true;                             // every layer on this path reads PReLU(U_prev) (launcher checks the slope pointer)
+  const float a_in = in_slope[0];
   const int l16 = lane * 16;
   const BufRes tabres = make_res(btab, BTAB_F4 * 16u);
   const BufRes cres = make_res(coef, (KR0 + CiP) * 4u);
   const BufRes pres = make_res(partials + (size_t)(blockIdx.x * 4 + wave) * EROW, EROW * 4u);
-  // dXres = Br.dU + Kr.X + kr waits for the adjoint mixing outside the register file: a tile-major slab of this wave in the
-  // workspace (26 KB, L2-resident; 1 KB per store / load), which frees 104 registers across three phases
-  const BufRes sres = make_res(xscr + (size_t)(blockIdx.x * 4 + wave) * (NTILE * 2 * 256), NTILE * 2 * 256 * 4u);
   const int nwaves = gridDim.x * 4;
   float da = 0.f;
   int clip = blockIdx.x * 4 + wave;
+  // dA / dT sums of ALL this wave's clips stay in accumulator registers (124 of them) and leave once, at the end.  The
+  // 17th row / column of dA[t] ride on two more tiles: row t of exA collects dA[t][16][0..15] (A operand masked to row t),
+  // column t of exB collects dA[t][0..15][16] (B operand masked to column t); the corner element is a plain sum.
+  f32x4 dAacc[T], dTacc[V], exA = {0.f, 0.f, 0.f, 0.f}, exB = {0.f, 0.f, 0.f, 0.f};
+  float corner = 0.f;
 #pragma unroll
-  for (int k = 0; k < PR_N; ++k) buf_store4(pres, l16, k * 1024, float4{0.f, 0.f, 0.f, 0.f});   // this wave's partial row starts at 0
+  for (int t = 0; t < T; ++t) dAacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int v = 0; v < V; ++v) dTacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Streams are buffer resources per clip; beyond the batch they are empty (loads return 0 without traffic)
+  auto clip_res = [&](const float* base, int c, int rows) {
+    const bool in_range = c < B;
+    return make_res(base + (size_t)(in_range ? c : 0) * rows * TV, in_range ? rows * TV * 4u : 0u);
+  };
+  // X of the NEXT clip is fetched while this clip's epilogue runs and staged at the loop head
+  constexpr int XL = (Ci * (TV / 4) + 63) / 64;          // float4 per lane of a clip's input (26 / 13)
+  float4 xs[XL];
+  auto xload = [&](float4 (&dst)[XL], const BufRes& r) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) dst[i] = buf_load4(r, l16, 64 * i * 16);
+  };
+  // A 16-row group of dU / Z / X travels as four quarters of 4 rows (204 float4 = 3 full 64-lane pieces + one of 12 lanes)
+  // through ONE set of 16 registers per lane: a quarter is stored to R2 behind the k-step that consumed those rows, and
+  // its registers are refilled at once with the same quarter of the following group -- staging never stands between two
+  // groups' MFMAs and every load has a whole group of MFMAs to arrive.
+  constexpr int QTAIL = 4 * (TV / 4) - 192;              // lanes of the 4th piece (12)
+  const int l16t = lane < QTAIL ? l16 : 0x7ffffff0;      // lanes beyond the quarter: out of range
+  float4 gb[16];
+  auto qload = [&](const BufRes& res, int row0, int q) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gb[4 * q + c] = buf_load4(res, c < 3 ? l16 : l16t, ((row0 + 4 * q) * (TV / 4) + 64 * c) * 16);
+  };
+  auto qstore = [&](int q, bool act) {                   // rows 4q .. 4q+3 of R2
+    const int ln = olane();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e = ln + 64 * c;
+      float4 v = gb[4 * q + c];
+      if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+      const int row = e / (TV / 4), col = 4 * (e - row * (TV / 4));
+      float* d = r2 + (4 * q + row) * LD + col;
+      if (c < 3 || lane < QTAIL) {
+        *reinterpret_cast<float2*>(d) = float2{v.x, v.y};
+        *reinterpret_cast<float2*>(d + 2) = float2{v.z, v.w};
+      }
+    }
+  };
+  auto gload = [&](const BufRes& res, int row0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qload(res, row0, q);
+  };
+  {
+    const BufRes x0 = clip_res(in, clip, Ci), du0 = clip_res(dU, clip, Co);
+    xload(xs, x0);
+    gload(du0, 0);                                       // first K pass, group 0
+  }
+#ifdef FB_TIMING
+  float tacc[16] = {};
+  long long tlast = wall_clock64();
+#endif
 
   for (; clip < B; clip += nwaves) {
-    const BufRes xres = make_res(in + (size_t)clip * Ci * TV, Ci * TV * 4u);
-    const BufRes zres = make_res(Zg + (size_t)clip * Ci * TV, Ci * TV * 4u);
-    const BufRes dures = make_res(dU + (size_t)clip * Co * TV, Co * TV * 4u);
-    const BufRes ores = make_res(dIn + (size_t)clip * Ci * TV, Ci * TV * 4u);
-
-    // ---- stage X = PReLU(U_prev) rows [row0, row0 + nrows) into an image (float4 loads: a row is 51 float4) ----------
-    auto stage = [&](float* img, int row0, int nrows) {
-      const int n4 = nrows * (TV / 4);
-#pragma unroll
-      for (int i = 0; i < (16 * CT * (TV / 4) + 63) / 64; ++i) {
-        if (i * 64 < n4) {
-          const int e4 = lane + 64 * i;
-          float4 v = buf_load4(xres, l16, (row0 * (TV / 4) + 64 * i) * 16);
-          if (pre) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
-          const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
-          const bool ok = e4 < n4;
-          float* d0 = img + (ok ? row * LD + col : PADCOL);
-          float* d1 = img + (ok ? row * LD + col + 2 : PADCOL);
-          *reinterpret_cast<float2*>(d0) = float2{v.x, v.y};
-          *reinterpret_cast<float2*>(d1) = float2{v.z, v.w};
-        }
-      }
+    FB_STAMP(15);
+    const BufRes xres = clip_res(in, clip, Ci), zres = clip_res(Zg, clip, Ci), dures = clip_res(dU, clip, Co);
+    const BufRes ores = clip_res(dIn, clip, Ci);
+    // quarter q of group g of a K pass: dU rows first (OT groups), then the pass's second source
+    auto kq = [&](int g, int q, const BufRes& res2) {
+      if (g < OT) qload(dures, 16 * g, q);
+      else qload(res2, 16 * (g - OT), q);
     };
+    // group 0 (fetched a phase ago) goes to R2, group 1 takes its registers: a phase before the pass itself
+    auto kprime = [&](const BufRes& res2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { qstore(q, false); kq(1, q, res2); }
+    };
+
+    // ---- stage X = PReLU(U_prev) into the image (fetched during the previous clip) ----------------------------------------
+    // (register budget: at most 256 of a lane's registers can hold operands; X, the K group and the tables take turns)
     L = geo();
+    kprime(zres);
+    {
+      constexpr int n4 = Ci * (TV / 4);
+      const int ln = olane();
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        const int e4 = ln + 64 * i;
+        float4 v = xs[i];
+        if (pre) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+        const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
+        const bool ok = e4 < n4;
+        *reinterpret_cast<float2*>(r1 + (ok ? row * LD + col : PADCOL)) = float2{v.x, v.y};
+        *reinterpret_cast<float2*>(r1 + (ok ? row * LD + col + 2 : PADCOL)) = float2{v.z, v.w};
+      }
+    }
     TTab tt;
     load_ttab(tt, tabres, 0, l16);
-    if (!(FB_ABLATE & 1)) stage(r1, 0, Ci);
-
-    // ---- Y = temporal mix of X, in place -----------------------------------------------------------------------------
-    L = geo();
-    if (!(FB_ABLATE & 1)) temporal_phase<16, CT>(r1, tt, L);
-
-    // ---- coefficient matrices as A operands (lane: output channel 16 ct + j, k slot q) and bias quads ------------------
-    L = geo();
-    f32x4 ktq[CT], krq[CT];
-    const int lq = (L.q * CiP + L.j) * 4;
+    f32x4 ktq[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      const float4 a = buf_load4(cres, L.q * 16, (KT0 + 16 * ct) * 4), b = buf_load4(cres, L.q * 16, (KR0 + 16 * ct) * 4);
+      const float4 a = buf_load4(cres, L.q * 16, (KT0 + 16 * ct) * 4);
       ktq[ct] = f32x4{a.x, a.y, a.z, a.w};
-      krq[ct] = f32x4{b.x, b.y, b.z, b.w};
     }
-    // coefficient A operands of one 16-row group (lane: output channel 16 ct + j, k slot q), fetched one group ahead:
-    // wz multiplies into dZ, wx into dXres (dU groups feed both, Z groups only dZ, X groups only dXres)
-    float wz[2][4][CT], wx[2][4][CT];
-    auto cload = [&](int buf, int g) {
-      constexpr int OTc = OT, CTc = CT;
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          if (g < OTc) {
-            wz[buf][s][ct] = buf_load1(cres, lq, ((16 * g + 4 * s) * CiP + 16 * ct) * 4);
-            wx[buf][s][ct] = buf_load1(cres, lq, (DX0 + (16 * g + 4 * s) * CiP + 16 * ct) * 4);
-          } else if (g < OTc + CTc) {
-            wz[buf][s][ct] = buf_load1(cres, lq, ((Co + 16 * (g - OTc) + 4 * s) * CiP + 16 * ct) * 4);
-          } else {
-            wx[buf][s][ct] = buf_load1(cres, lq, (DX0 + (Co + 16 * (g - OTc - CTc) + 4 * s) * CiP + 16 * ct) * 4);
-          }
-        }
-    };
+    FB_STAMP(0);
 
-    // ---- dZ = Bt.dU + Kt.Z + kt,  dXres = Br.dU + Kr.X + kr for ALL position tiles at once --------------------------------
-    // The K axis (rows of dU, Z, X) is walked in groups of 16 rows: a group is staged into R2 by full-line float4 loads
-    // (every byte of dU / Z / X is read once, aligned), then feeds 4 k-steps x 13 tiles x CT (x 2) independent MFMA
-    // chains from LDS.  The next group's loads are in flight while the current one is multiplied.
+    // ---- Y = temporal mix of X, in place -------------------------------------------------------------------------------------
+    L = geo();
+    temporal_phase<16, CT>(r1, tt, L);
+    FB_STAMP(1);
+
+    // ---- K passes:  dZ = Bt.dU + Kt.Z + kt  now,  + dXres = Br.dU + Kr.X + kr  at the end ------------------------------------
+    // acc[tile][ct] += coefficient rows [c0 ..) x dU (OT groups) + rows [c1 ..) x the second source (CT groups), all 13
+    // position tiles at once: 4 k-steps x 13 x CT independent MFMA chains per group, B operands from R2 (fetched a k-step
+    // ahead), coefficient A operands a group ahead.  Two passes (104 accumulators each) instead of one with 208: that one
+    // left the register allocator no room to keep operand fetches ahead of the MFMAs; dU is read twice for it.
+    L = geo();
+    const int lq = (L.q * CiP + L.j) * 4;
     const int jc = L.j < T ? L.j : T - 1;
-    f32x4 az[NTILE][CT], xr[NTILE][CT];
+    auto kpass = [&](f32x4 (&acc)[NTILE][CT], const BufRes& res2, bool act2, int c0, int c1, auto&& last_group_hook) {
+      float wc[2][4][CT];
+      auto cload = [&](int buf, int g) {
+        const int krow = g < OT ? c0 + 16 * g : c1 + 16 * (g - OT);
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) { az[t][ct] = ktq[ct]; xr[t][ct] = krq[ct]; }
-    constexpr int G4 = 16 * (TV / 4);                    // float4 of a 16-row group (816)
-    constexpr int GL = (G4 + 63) / 64;                   // per lane (13)
-    float4 gbuf[GL];
-    auto gload = [&](BufRes res, int row0) {
-#pragma unroll
-      for (int i = 0; i < GL; ++i) gbuf[i] = buf_load4(res, l16, (row0 * (TV / 4) + 64 * i) * 16);
-    };
-    auto gstore = [&](bool act) {
-#pragma unroll
-      for (int i = 0; i < GL; ++i) {
-        const int e4 = lane + 64 * i;
-        float4 v = gbuf[i];
-        if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
-        const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
-        const bool ok = e4 < G4;
-        *reinterpret_cast<float2*>(r2 + (ok ? row * LD + col : PADCOL)) = float2{v.x, v.y};
-        *reinterpret_cast<float2*>(r2 + (ok ? row * LD + col + 2 : PADCOL)) = float2{v.z, v.w};
-      }
-    };
-    if (!(FB_ABLATE & (2 | 128))) {
-      constexpr int NG = OT + 2 * CT;                    // groups: dU (OT), Z (CT), X (CT)
-      gload(dures, 0);
+          for (int ct = 0; ct < CT; ++ct) wc[buf][s][ct] = buf_load1(cres, lq, ((krow + 4 * s) * CiP + 16 * ct) * 4);
+      };
+      // on entry group 0 is staged in R2 and group 1 is in the registers (kprime)
       cload(0, 0);
+      float b[2][NTILE];
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) b[0][t] = r2[L.q * LD + (t < T ? t * V + L.j : jc * V + 16)];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        gstore(g >= OT + CT && pre);
-        if (g + 1 < NG) {
-          if (g + 1 < OT) gload(dures, 16 * (g + 1));
-          else if (g + 1 < OT + CT) gload(zres, 16 * (g + 1 - OT));
-          else gload(xres, 16 * (g + 1 - OT - CT));
-          cload((g + 1) & 1, g + 1);
-        }
+        if (g + 1 < NG) cload((g + 1) & 1, g + 1);
+        else last_group_hook();                          // the group registers are free from here on
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          float b[NTILE];
+          if (s + 1 < 4 || g + 1 < NG) {                 // operands of the next k-step (the next group's first: stored at s = 0)
+            const int sn = (s + 1) & 3;
 #pragma unroll
-          for (int t = 0; t < NTILE; ++t) b[t] = r2[(4 * s + L.q) * LD + (t < T ? t * V + L.j : jc * V + 16)];
+            for (int t = 0; t < NTILE; ++t) b[(s + 1) & 1][t] = r2[(4 * sn + L.q) * LD + (t < T ? t * V + L.j : jc * V + 16)];
+          }
+          if (g + 1 < NG) {                              // this k-step's rows are free: the next group's quarter moves in
+            qstore(s, g + 1 >= OT && act2);
+            if (g + 2 < NG) kq(g + 2, s, res2);
+          }
 #pragma unroll
           for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              if (g < OT) {
-                az[t][ct] = mfma(wz[g & 1][s][ct], b[t], az[t][ct]);
-                xr[t][ct] = mfma(wx[g & 1][s][ct], b[t], xr[t][ct]);
-              } else if (g < OT + CT) {
-                az[t][ct] = mfma(wz[g & 1][s][ct], b[t], az[t][ct]);
-              } else {
-                xr[t][ct] = mfma(wx[g & 1][s][ct], b[t], xr[t][ct]);
-              }
-            }
+            for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma(wc[g & 1][s][ct], b[s & 1][t], acc[t][ct]);
         }
       }
-    }
-    if (!(FB_ABLATE & 2)) {
+    };
+    f32x4 az[NTILE][CT];
 #pragma unroll
-      for (int t = 0; t < NTILE; ++t)
+    for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-          buf_store4(sres, l16, (t * 2 + ct) * 1024, float4{xr[t][ct][0], xr[t][ct][1], xr[t][ct][2], xr[t][ct][3]});
-    }
-    float exB[V] = {};
-    f32x4 dAacc[T];
-    float exA[T];
-    if (FB_ABLATE) {
+      for (int ct = 0; ct < CT; ++ct) az[t][ct] = ktq[ct];
+    kpass(az, zres, false, 0, Co, [] {});                // Bt rows [0, Co), Kt rows [Co, Co + Ci)
+    FB_STAMP(2);
+    gload(xres, 0);                                      // dT's first X half takes off behind the dA products
+
+    // ---- dA += Y^T dZ per frame, dZ over Y ---------------------------------------------------------------------------------
 #pragma unroll
-      for (int t = 0; t < T; ++t) { dAacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; exA[t] = 0.f; }
-    }
-    if (!(FB_ABLATE & 2)) {
-    {
-      // the 17th-joint tile first: dA[t = j][v][16] = sum_c Y[c][t, v] dZ[c][t, 16] needs Y intact
+    for (int ct = 0; ct < CT; ++ct) {                    // dA[t = j][16][16]
+      const f32x4 y16 = tile_load(r1, 16 * ct, jc * V + 16, L);
 #pragma unroll
-      for (int v = 0; v < ((FB_ABLATE & 256) ? 0 : V); ++v) {
-        float s = 0.f;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const f32x4 y = tile_load(r1, 16 * ct, jc * V + v, L);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s = fmaf(y[r], az[T][ct][r], s);
-        }
-        exB[v] = (FB_ABLATE & 4) ? s : quad_sum(s);
-      }
+      for (int r = 0; r < 4; ++r) corner = fmaf(y16[r], az[T][ct][r], corner);
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      float s16 = 0.f;
 #pragma unroll
-      for (int ct = 0; ct < ((FB_ABLATE & 512) ? 0 : CT); ++ct) {
+      for (int ct = 0; ct < CT; ++ct) {
         const f32x4 y = tile_load(r1, 16 * ct, t * V + L.j, L);          // A operand: Y[16 ct + 4q + r][t, v = j]
         const f32x4 y16 = tile_load(r1, 16 * ct, t * V + 16, L);        // Y[..][t, 16] (same address in every column)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          acc = mfma(y[r], az[t][ct][r], acc);
-          s16 = fmaf(y16[r], az[t][ct][r], s16);
+          dAacc[t] = mfma(y[r], az[t][ct][r], dAacc[t]);
+          exA = mfma(L.j == t ? y16[r] : 0.f, az[t][ct][r], exA);
+          exB = mfma(y[r], L.j == t ? az[T][ct][r] : 0.f, exB);
         }
       }
-      dAacc[t] = acc;
-      exA[t] = quad_sum(s16);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, t * V + L.j, true, az[t][ct], L);   // dZ over Y's frame t
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, jc * V + 16, L.j < T, az[T][ct], L);
-    // dA partial sums of this wave: read-modify-write of its lane-major row (20 x 1 KB each way, loads batched)
-    if (!(FB_ABLATE & 4)) {
-      float4 pv[PR_T];
-#pragma unroll
-      for (int k = 0; k < PR_T; ++k) pv[k] = buf_load4(pres, l16, k * 1024);
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-        buf_store4(pres, l16, (PR_A + t) * 1024,
-                   float4{pv[t].x + dAacc[t][0], pv[t].y + dAacc[t][1], pv[t].z + dAacc[t][2], pv[t].w + dAacc[t][3]});
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        buf_store4(pres, l16, (PR_XA + c) * 1024, float4{pv[PR_XA + c].x + exA[4 * c], pv[PR_XA + c].y + exA[4 * c + 1],
-                                                         pv[PR_XA + c].z + exA[4 * c + 2], pv[PR_XA + c].w + exA[4 * c + 3]});
-#pragma unroll
-      for (int c = 0; c < 5; ++c)
-        buf_store4(pres, l16, (PR_XB + c) * 1024,
-                   float4{pv[PR_XB + c].x + exB[4 * c], pv[PR_XB + c].y + (4 * c + 1 < V ? exB[4 * c + 1 < V ? 4 * c + 1 : 0] : 0.f),
-                          pv[PR_XB + c].z + (4 * c + 2 < V ? exB[4 * c + 2 < V ? 4 * c + 2 : 0] : 0.f),
-                          pv[PR_XB + c].w + (4 * c + 3 < V ? exB[4 * c + 3 < V ? 4 * c + 3 : 0] : 0.f)});
-    }
-    }   // FB_ABLATE & 2
+    FB_STAMP(3);
 
-    // ---- dY = spatial adjoint of dZ, in place (operand reads of frame t+1 before the stores of frame t) ----------------
+    // ---- dY = spatial adjoint of dZ, in place (operand reads of frame t+1 before the stores of frame t) ----------------------
     L = geo();
-    if (!(FB_ABLATE & 8)) {
+    {
       SpatRec rec = load_spat(tabres, 0, 0, l16);
       SOp op[CT];
 #pragma unroll
@@ -353,21 +350,23 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         for (int ct = 0; ct < CT; ++ct) op[ct] = opn[ct];
       }
     }
+    FB_STAMP(5);
 
-    // ---- dT[v] = X_v^T dY_v: X re-staged 16 rows at a time beside the image --------------------------------------------
+    // ---- dT[v] += X_v^T dY_v: X re-staged 16 rows at a time beside the image; the second K pass's group 0 follows ------------
     L = geo();
-    f32x4 dTacc[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) dTacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(FB_ABLATE & 16)) {
+    load_ttab(tt, tabres, TEMP_F4 + SPAT_F4, l16);       // adjoint temporal operands, ahead of the far loads
+    {
       const int ic = L.j < T ? L.j : T - 1;
-      gload(xres, 0);
 #pragma unroll
       for (int h = 0; h < CT; ++h) {
-        gstore(pre);                                   // X rows 16h .. 16h+15 (fetched before the spatial adjoint / the previous half)
-        if (h + 1 < CT) gload(xres, 16 * (h + 1));
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {                  // 17 independent chains per k-step
+        for (int q = 0; q < 4; ++q) {                    // X rows 16h .. 16h+15 -> R2; the next half / dU group 0 -> registers
+          qstore(q, pre);
+          if (h + 1 < CT) qload(xres, 16 * (h + 1), q);
+          else qload(dures, 0, q);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                    // 17 independent chains per k-step
           float a[V], b[V];
 #pragma unroll
           for (int v = 0; v < V; ++v) {
@@ -379,73 +378,98 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         }
       }
     }
-    if (!(FB_ABLATE & 16)) {                           // dT partial sums: 17 x 1 KB each way
-      float4 pv[V];
-#pragma unroll
-      for (int v = 0; v < V; ++v) pv[v] = buf_load4(pres, l16, (PR_T + v) * 1024);
-#pragma unroll
-      for (int v = 0; v < V; ++v)
-        buf_store4(pres, l16, (PR_T + v) * 1024,
-                   float4{pv[v].x + dTacc[v][0], pv[v].y + dTacc[v][1], pv[v].z + dTacc[v][2], pv[v].w + dTacc[v][3]});
-    }
+    kprime(xres);                                        // second pass: dU group 0 -> R2, group 1 on its way across the adjoint
+    FB_STAMP(6);
 
-    // ---- gcn^T: temporal adjoint in place --------------------------------------------------------------------------------
+    // ---- gcn^T: temporal adjoint in place ----------------------------------------------------------------------------------
     L = geo();
-    load_ttab(tt, tabres, TEMP_F4 + SPAT_F4, l16);
-    if (!(FB_ABLATE & 32)) temporal_phase<16, CT>(r1, tt, L);
+    temporal_phase<16, CT>(r1, tt, L);
+    FB_STAMP(7);
 
-    // ---- dU_prev = (gcn^T(dZ) + dXres) * PReLU'(U_prev), slope gradient ---------------------------------------------------
-    // dXres joins the image tile by tile (LDS only); the image then leaves row-wise: float4 loads of the pre-activations
-    // (the PReLU mask) and float4 stores of dU_prev, full lines both ways.
+    // ---- + dXres: the second K pass starts from the image's own tiles and returns them in place -------------------------------
     L = geo();
-    if (!(FB_ABLATE & 64)) {
-      f32x4 xq[NTILE][CT];
+    float4 u[XL];
+    constexpr int UH = XL <= 13 ? XL : 13;               // pre-activation pieces fetched inside the pass (the rest: behind it)
+    {
+      f32x4 krq[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const float4 b = buf_load4(cres, L.q * 16, (KR0 + 16 * ct) * 4);
+        krq[ct] = f32x4{b.x, b.y, b.z, b.w};
+      }
+      f32x4 xr[NTILE][CT];
 #pragma unroll
       for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const float4 v = buf_load4(sres, l16, (t * 2 + ct) * 1024);
-          xq[t][ct] = f32x4{v.x, v.y, v.z, v.w};
-        }
+        for (int ct = 0; ct < CT; ++ct) xr[t][ct] = tile_load(r1, 16 * ct, t < T ? t * V + L.j : jc * V + 16, L) + krq[ct];
+      kpass(xr, xres, pre, DX0 / CiP, DX0 / CiP + Co, [&] {   // Br / Kr rows; the pre-activations come back (from L2) meanwhile
+        __builtin_amdgcn_sched_barrier(0);               // not earlier: the registers are taken until here
+        if (pre) {
 #pragma unroll
-      for (int tile = 0; tile < NTILE; ++tile) {
-        const bool fr = tile < T;
-        const int pos = fr ? tile * V + L.j : jc * V + 16;
-        const bool ok = fr || L.j < T;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const f32x4 g = tile_load(r1, 16 * ct, pos, L) + xq[tile][ct];
-          tile_store(r1, 16 * ct, pos, ok, g, L);
+          for (int i = 0; i < UH; ++i) u[i] = buf_load4(xres, l16, 64 * i * 16);
         }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, t < T ? t * V + L.j : jc * V + 16, t < T || L.j < T, xr[t][ct], L);
+    }
+    FB_STAMP(4);
+
+    // ---- dU_prev = image * PReLU'(U_prev), slope gradient: row-wise, full lines both ways.  The next clip's first dU group
+    // takes off first; its X follows piece by piece into the registers the pre-activations leave (loads return in order:
+    // nothing this pass waits for is queued behind a far fetch)
+    {
+      const BufRes xn = clip_res(in, clip + nwaves, Ci), dun = clip_res(dU, clip + nwaves, Co);
+      constexpr int N4 = Ci * (TV / 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (pre) {
+#pragma unroll
+        for (int i = UH; i < XL; ++i) u[i] = buf_load4(xres, l16, 64 * i * 16);
       }
-      constexpr int N4 = Ci * (TV / 4), NL = (N4 + 63) / 64;
+      gload(dun, 0);
+      const int ln = olane();
 #pragma unroll
-      for (int i0 = 0; i0 < NL; i0 += 7) {
-        float4 u[7];
+      for (int i = 0; i < XL; ++i) {
+        const int e4 = ln + 64 * i;
+        const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
+        const float* p = r1 + (e4 < N4 ? row * LD + col : PADCOL);
+        const float2 g0 = *reinterpret_cast<const float2*>(p), g1 = *reinterpret_cast<const float2*>(p + 2);
+        float g[4] = {g0.x, g0.y, g1.x, g1.y};
+        if (pre && e4 < N4) {
+          const float uu[4] = {u[i].x, u[i].y, u[i].z, u[i].w};
 #pragma unroll
-        for (int k = 0; k < 7; ++k)
-          if (i0 + k < NL) u[k] = pre ? buf_load4(xres, l16, 64 * (i0 + k) * 16) : float4{1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-          if (i0 + k < NL) {
-            const int e4 = lane + 64 * (i0 + k);
-            const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
-            const float* p = r1 + (e4 < N4 ? row * LD + col : PADCOL);
-            const float2 g0 = *reinterpret_cast<const float2*>(p), g1 = *reinterpret_cast<const float2*>(p + 2);
-            float g[4] = {g0.x, g0.y, g1.x, g1.y};
-            const float uu[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
-            if (pre && e4 < N4) {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                if (uu[c] < 0.f) da = fmaf(g[c], uu[c], da);
-                g[c] = uu[c] > 0.f ? g[c] : a_in * g[c];
-              }
-            }
-            buf_store4(ores, l16, 64 * (i0 + k) * 16, float4{g[0], g[1], g[2], g[3]});    // beyond the clip: dropped (bounds check)
+          for (int c = 0; c < 4; ++c) {
+            if (uu[c] < 0.f) da = fmaf(g[c], uu[c], da);
+            g[c] = uu[c] > 0.f ? g[c] : a_in * g[c];
           }
+        }
+        buf_store4(ores, l16, 64 * i * 16, float4{g[0], g[1], g[2], g[3]});    // beyond the clip: dropped (bounds check)
+        xs[i] = buf_load4(xn, l16, 64 * i * 16);
       }
     }
   }
+  // ---- this wave's dA / dT sums: one lane-major row per wave, written once ----------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    buf_store4(pres, l16, (PR_A + t) * 1024, float4{dAacc[t][0], dAacc[t][1], dAacc[t][2], dAacc[t][3]});
+  buf_store4(pres, l16, PR_XA * 1024, float4{exA[0], exA[1], exA[2], exA[3]});
+  buf_store4(pres, l16, PR_XB * 1024, float4{exB[0], exB[1], exB[2], exB[3]});
+  buf_store4(pres, l16, PR_C * 1024, float4{quad_sum(corner), 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+    buf_store4(pres, l16, (PR_T + v) * 1024, float4{dTacc[v][0], dTacc[v][1], dTacc[v][2], dTacc[v][3]});
+#ifdef FB_TIMING
+  FB_STAMP(8);
+  __syncthreads();
+  if (wave == 0) {
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mine = lane == k ? tacc[k] : mine;
+    if (lane < 16) dIn[blockIdx.x * 16 + lane] = mine;
+  }
+#endif
   da = wave_sum(da);
   if (lane == 0 && dap) dap[blockIdx.x * 4 + wave] = da;
 }
@@ -461,13 +485,16 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
   if ((rc = check_launch("bwd_build_btab"))) return rc;
   const size_t lds = (size_t)4 * ff::WAVE_LDS * sizeof(float);
   const int nblk = (B + 3) / 4;
-  const int grid = nblk < 256 ? nblk : 256;
+#ifndef FB_GRID
+#define FB_GRID 256   // one 4-wave block per CU (LDS-bound)
+#endif
+  const int grid = nblk < FB_GRID ? nblk : FB_GRID;
   *rows_out = grid * 4;
 #define LAUNCH_FB(CT, OT)                                                                                              \
   do {                                                                                                                 \
     auto k = fb::k_layer_bwd_fused<CT, OT>;                                                                            \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, xscr, B); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, B); \
   } while (0)
   {
     ProbeScope probe(KID_BWD_DATA, Ci, Co, st);

@@ -1306,7 +1306,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
                      Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate);
   if ((rc = check_launch("bwd_fold"))) return rc;
   // 3 + 4 in one kernel (fused_bwd.hip) for the stored-Z path at the shapes it is built for: dZ never leaves the CU
-  if (Zg && dIn && !dz_ext && layer_bwd_fused_ok(T, V, Ci, Co)) {
+  if (Zg && dIn && in_slope && !dz_ext && layer_bwd_fused_ok(T, V, Ci, Co)) {
     int rows = 0;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
     if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows)))
