@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
   const int l16 = lane * 16;
   const BufRes tabres = make_res(btab, BTAB_F4 * 16u);
   const BufRes cres = make_res(coef, (KR0 + CiP) * 4u);
-  const BufRes pres = make_res(partials + (size_t)(blockIdx.x * 4 + wave) * EROW, EROW * 4u);
+  const BufRes pres = make_res(partials + (size_t)blockIdx.x * EROW, EROW * 4u);
   const int nwaves = gridDim.x * 4;
   float da = 0.f;
   int clip = blockIdx.x * 4 + wave;
@@ -450,16 +450,34 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
       }
     }
   }
-  // ---- this wave's dA / dT sums: one lane-major row per wave, written once ----------------------------------------------------
+  // ---- the block's dA / dT sums: the four waves park their 32 records in their own LDS images, then each wave adds a
+  // quarter of them across the four (fixed order) and writes that quarter of the block's lane-major row -----------------------
+  {
+    float4* mine = reinterpret_cast<float4*>(lds) + lane;
 #pragma unroll
-  for (int t = 0; t < T; ++t)
-    buf_store4(pres, l16, (PR_A + t) * 1024, float4{dAacc[t][0], dAacc[t][1], dAacc[t][2], dAacc[t][3]});
-  buf_store4(pres, l16, PR_XA * 1024, float4{exA[0], exA[1], exA[2], exA[3]});
-  buf_store4(pres, l16, PR_XB * 1024, float4{exB[0], exB[1], exB[2], exB[3]});
-  buf_store4(pres, l16, PR_C * 1024, float4{quad_sum(corner), 0.f, 0.f, 0.f});
+    for (int t = 0; t < T; ++t) mine[(PR_A + t) * 64] = float4{dAacc[t][0], dAacc[t][1], dAacc[t][2], dAacc[t][3]};
+    mine[PR_XA * 64] = float4{exA[0], exA[1], exA[2], exA[3]};
+    mine[PR_XB * 64] = float4{exB[0], exB[1], exB[2], exB[3]};
+    mine[PR_C * 64] = float4{quad_sum(corner), 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int v = 0; v < V; ++v)
-    buf_store4(pres, l16, (PR_T + v) * 1024, float4{dTacc[v][0], dTacc[v][1], dTacc[v][2], dTacc[v][3]});
+    for (int v = 0; v < V; ++v) mine[(PR_T + v) * 64] = float4{dTacc[v][0], dTacc[v][1], dTacc[v][2], dTacc[v][3]};
+    da = wave_sum(da);
+    if (lane == 0) lds[PR_N * 256] = da;                 // behind the records
+    __syncthreads();
+    constexpr int RPW = PR_N / 4;                        // records per wave (8)
+    static_assert(PR_N % 4 == 0, "records split evenly over the four waves");
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int rec = wave * RPW + k;
+      float4 s = reinterpret_cast<const float4*>(lds_all)[rec * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 o = reinterpret_cast<const float4*>(lds_all + w * WAVE_LDS)[rec * 64 + lane];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+      }
+      buf_store4(pres, l16, rec * 1024, s);
+    }
+  }
 #ifdef FB_TIMING
   FB_STAMP(8);
   __syncthreads();
@@ -470,13 +488,14 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     if (lane < 16) dIn[blockIdx.x * 16 + lane] = mine;
   }
 #endif
-  da = wave_sum(da);
-  if (lane == 0 && dap) dap[blockIdx.x * 4 + wave] = da;
+  if (threadIdx.x == 0 && dap)
+    dap[blockIdx.x] = ((lds_all[PR_N * 256] + lds_all[WAVE_LDS + PR_N * 256]) + lds_all[2 * WAVE_LDS + PR_N * 256]) +
+                      lds_all[3 * WAVE_LDS + PR_N * 256];
 }
 
 }  // namespace fb
 
-// stage 3 + 4 of launch_layer_bwd for the shapes this kernel is built for; partials: >= 4 * grid rows of T*V*V + V*T*T floats
+// stage 3 + 4 of launch_layer_bwd for the shapes this kernel is built for; partials: >= grid rows of EROW floats, dap: >= grid floats
 int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
                            const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
                            float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out) {
@@ -489,7 +508,7 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
 #define FB_GRID 256   // one 4-wave block per CU (LDS-bound)
 #endif
   const int grid = nblk < FB_GRID ? nblk : FB_GRID;
-  *rows_out = grid * 4;
+  *rows_out = grid;
 #define LAUNCH_FB(CT, OT)                                                                                              \
   do {                                                                                                                 \
     auto k = fb::k_layer_bwd_fused<CT, OT>;                                                                            \
