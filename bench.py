@@ -169,7 +169,7 @@ def main():
     for _ in range(args.warmup):
         eng.step(x)
     sync()
-    # dominant kernel (rocprof, profiles/r01_kernel_instances.csv): k_bwd_data_f of layer 4 (C_in 32 -> C_out 64).  The library brackets each
+    # dominant kernel (rocprof, profiles/r02_kernel_instances.csv): the fused backward of layer 4 (C_in 32 -> C_out 64).  The library brackets each
     # of its launches with HIP events on the launch stream (coskad_probe_*), inside the timed region.
     import ctypes
     lib = _lib.lib()
@@ -231,7 +231,7 @@ def main():
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this script)
         traffic = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
                 traffic = json.load(f)
         except OSError:
             pass
@@ -239,16 +239,17 @@ def main():
             # SURVEY 8d, backward of one layer: read dOut (C_out), read the saved input (C_in), write dIn (C_in)
             byts = B * tvb * (HID + 2 * CHANNELS[-1])
             ach = byts / (probe_ms.value * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_bwd_data_f<12,17,2,1> (layer 4 backward data path, 64 -> 32 channels, single-read variant)",
+            roof = {"bound": "hbm", "kernel": "k_layer_bwd_fused<2,4> (layer 4 backward, 64 -> 32 channels: data path and dA/dT in one "
+                                               "wave-per-clip kernel)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": (traffic.get("bwd_data layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
-                    "traffic_source": "profiles/r01_hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE, B=4096)",
+                    "traffic": (traffic.get("bwd_fused layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
+                    "traffic_source": "profiles/r02_hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE, B=4096)",
                     "algorithmic_bytes_per_launch": byts,
                     "avg_launch_us": round(probe_ms.value * 1e3, 2), "launches": probe_n.value}
             # the same launches against the fp32 MFMA roof: convs Bt.dU, Br.dU (C_in x C_out each),
-            # Kt.Z, Kr.X (C_in x C_in each) + the mixing and its adjoint; intensity 31 FLOP/B > ridge 19.6
+            # Kt.Z, Kr.X (C_in x C_in each) + forward temporal mix, both adjoint mixes, dA and dT (3 T + 2 V per element)
             ci, co = CHANNELS[-1], HID
-            flops = B * (2 * T * V * (2 * ci * co + 2 * ci * ci) + 2 * ci * 2 * T * V * (T + V))
+            flops = B * (2 * T * V * (2 * ci * co + 2 * ci * ci) + 2 * ci * T * V * (3 * T + 2 * V))
             tf = flops / (probe_ms.value * 1e-3) / 1e12
             roof["mfma_f32"] = {"achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": flops}

@@ -285,7 +285,6 @@ __global__ __launch_bounds__(256, 1) void k_fused_encoder(const float* __restric
       for (int ot = 0; ot < 4; ++ot) ap[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tile = 0; tile < NTILE; ++tile) {
-        TILE_GEO(tile);
         const int t2 = tile + 2 < T ? tile + 2 : T - 1;
         const SpatRec rec2 = load_spat(tabres, tb, t2, l16);
         const SOp op20 = spatial_read<16>(r1, 0, t2, L), op21 = spatial_read<16>(r1, 1, t2, L);

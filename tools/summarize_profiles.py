@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name: str) -> str:
-    m = re.search(r"coskad::(\w+(?:<[^>]*>)?)", name)
+    m = re.search(r"coskad::(?:\w+::)*(\w+(?:<[^>]*>)?)", name)
     return m.group(1).replace(" ", "") if m else name.split("(")[0]
 
 
@@ -129,7 +129,9 @@ def main(tag: str) -> None:
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, B=4096); "
                    "counters are KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE reads "
                    "1/2 of a wide coalesced stream; narrower accesses uncalibrated: upper bound)"}
-    for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2,1>"), ("layer_apply layer4", "k_layer_apply_m<12,17,4>")):
+    for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2,1>"), ("bwd_fused layer4", "k_layer_bwd_fused<2,4>"),
+                          ("bwd_fused layer3", "k_layer_bwd_fused<1,2>"), ("bwd_fused layer2", "k_layer_bwd_fused<2,1>"),
+                          ("layer_apply layer4", "k_layer_apply_m<12,17,4>"), ("fused_encoder", "k_fused_encoder")):
         b = biggest(prefix)
         if b:
             (k, lds, wg), (fe, wr, hbm) = b
