@@ -475,6 +475,9 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         const float4 o = reinterpret_cast<const float4*>(lds_all + w * WAVE_LDS)[rec * 64 + lane];
         s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
       }
+      // one record at a time, drained: with all 32 b128 reads of the unrolled loop in flight (more than the 4-bit LGKM
+      // counter can count) the first sums consumed registers before their data had landed (tools/dbg_ragged.py showed it)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       buf_store4(pres, l16, rec * 1024, s);
     }
   }

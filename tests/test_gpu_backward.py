@@ -108,6 +108,51 @@ def test_layer_backward(Ci, Co, V, B, first, identity):
         close(grads["slope_in"], so.grad, rtol=5e-4, atol_rel=1e-4, msg="dslope_in")
 
 
+@pytest.mark.parametrize("Ci,Co,B", [(32, 64, 1031), (16, 32, 2053), (32, 16, 1026)])
+def test_fused_backward_ragged_batch_vs_split_kernels(Ci, Co, B):
+    """Stored-Z path (csrc/fused_bwd.hip: one clip per wavefront, several clips per wave, ragged last round) against the
+    recompute path of the same library (k_bwd_reduce / k_bwd_data / k_bwd_gcn_params: block-per-tile kernels, no stored Z):
+    two independent implementations of stsgcn.py:94-116's autograd.  dIn sits inside a guarded buffer: the fused kernel
+    addresses clips through bounds-checked buffer descriptors and must not write a byte outside the tensor."""
+    from coskad_amd import ops
+    T, V = 12, 17
+    st = make_layer_state(Ci, Co, V, seed=Ci + Co)
+    g = torch.Generator().manual_seed(B)
+    x_pre = dev(torch.randn(B, Ci, T, V, generator=g))
+    probe = dev(torch.randn(B, Co, T, V, generator=g) * 0.1)
+    d = {k[2:]: dev(v) for k, v in st.items()}
+    sl = dev(torch.tensor([0.2]))
+    Wt, Wr = d["tcn.0.weight"].reshape(Co, Ci), d["residual.0.weight"].reshape(Co, Ci)
+    ws = torch.empty(max(ops.train_stats_ws_bytes(Ci), ops.layer_bwd_ws_bytes(B, Ci, Co, T, V)), dtype=torch.uint8, device="cuda")
+    Z = torch.empty_like(x_pre)
+    _, _, stat = ops.layer_train_stats(
+        x_pre, d["gcn.A"], d["gcn.T"], sl, Wt, d["tcn.0.bias"], d["tcn.1.weight"], d["tcn.1.bias"],
+        d["tcn.1.running_mean"], d["tcn.1.running_var"], d["tcn.1.num_batches_tracked"],
+        Wr, d["residual.0.bias"], d["residual.1.weight"], d["residual.1.bias"],
+        d["residual.1.running_mean"], d["residual.1.running_var"], d["residual.1.num_batches_tracked"], ws, Z=Z)
+
+    def run(zz):
+        z = lambda *s_: torch.full(s_, float("nan"), device="cuda")
+        gr = {"A": z(T, V, V), "T": z(V, T, T), "Wt": z(Co, Ci), "bt": z(Co), "gt": z(Co), "bet": z(Co), "Wr": z(Co, Ci),
+              "br": z(Co), "gr": z(Co), "ber": z(Co), "slope_in": z(1)}
+        n, guard = x_pre.numel(), 4096
+        buf = torch.full((n + 2 * guard,), 12345.0, device="cuda")
+        dIn = buf[guard:guard + n].view_as(x_pre)
+        ops.layer_bwd(x_pre, probe, d["gcn.A"], d["gcn.T"], sl, stat, Wt, d["tcn.1.weight"], Wr, d["residual.1.weight"], gr, ws,
+                      dIn=dIn, Z=zz)
+        torch.cuda.synchronize()
+        assert bool((buf[:guard] == 12345.0).all()) and bool((buf[guard + n:] == 12345.0).all()), "wrote outside dIn"
+        return dIn.clone(), gr
+
+    dIn_f, g_f = run(Z)
+    dIn_s, g_s = run(None)
+    close(dIn_f, dIn_s.cpu(), rtol=5e-4, atol_rel=5e-5, msg="dIn")
+    for k in g_s:
+        a, b = g_f[k].cpu().numpy(), g_s[k].cpu().numpy()
+        assert np.isfinite(a).all(), k
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-4 * max(np.abs(b).max(), 1e-9), err_msg=k)
+
+
 @pytest.mark.parametrize("B,hid,V,L,with_slope", [(37, 64, 17, 16, True), (5, 8, 25, 8, True), (16, 4, 17, 4, False), (300, 16, 17, 16, True)])
 def test_bottleneck(B, hid, V, L, with_slope):
     from coskad_amd import ops
