@@ -1,0 +1,286 @@
+// The backward of a layer with a handful of input channels (the first layer of every stack: 2 or 3 pose channels;
+// autograd of models/graph_layers/stsgcn.py:94-116 without a dIn) on the stored-Z path.
+//
+// With C_in <= 4 the matrix-core kernels pad the channel axis to 16 and spend their time in staging, tables and
+// barriers (round-2 profile, B = 4096: statistics 41 us + data 37 us + dA/dT 16 us for a layer whose only real traffic is
+// TWO reads of dU, 2 x 107 MB = 2 x 17 us at the HBM rate).  Here the channel products are plain FMAs on
+// full-line loads:
+//
+//   k_first_stats : P[o][c] = sum dU[o] . Z[c],  Q[o][c] = sum dU[o] . X[c],  s[o] = sum dU[o]      (stage 1)
+//                   one clip per block round, the block's four waves split the dU rows, a lane owns four positions of every row;
+//                   per-lane accumulators, summed over the lanes once at the very end; rows [P][Q][s] as k_bwd_fold reads them
+//   k_first_bwd   : dZ = Bt.dU + Kt.Z + kt (C_in channels), Y = temporal mix of X, dY = spatial adjoint of dZ,
+//                   dA[t][v][w] += sum_c Y[c][t,v] dZ[c][t,w],  dT[v][t][q] += sum_c X[c][t,v] dY[c][q,v]   (stages 3 + 4)
+//                   the four waves split the dU rows of the clip, partial dZ meets in LDS; every thread keeps its share of
+//                   the dA / dT sums in registers for the whole launch; rows [dA][dT] as k_reduce_gcn reads them
+#include "mfma_ops.h"
+
+namespace coskad {
+namespace fl {
+
+__device__ __forceinline__ float act(float x, bool pre, float a) { return (pre && x < 0.f) ? a * x : x; }
+__device__ __forceinline__ float4 act4(float4 v, bool pre, float a) {
+  return float4{act(v.x, pre, a), act(v.y, pre, a), act(v.z, pre, a), act(v.w, pre, a)};
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+// NW waves per block, RW = rows of dU per wave (C_out <= NW RW).  Measured at B = 4096, 2 -> 32 channels: 32 us as is (4 waves
+// per SIMD); prefetching the next clip's rows at half the occupancy 39 us, 8 waves per SIMD (64 registers, spills) 49 us
+constexpr int NW = 4;
+template <int CI, int RW>
+__global__ __launch_bounds__(64 * NW, 4) void k_first_stats(const float* __restrict__ in, const float* __restrict__ Zg,
+                                                           const float* __restrict__ dU, const float* __restrict__ in_slope,
+                                                           float* __restrict__ partials, int B, int Co, int TVr, int need_q) {
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const int n4 = TVr >> 2;                      // float4 per row
+  float pP[RW][CI], pQ[RW][CI], pS[RW];
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    pS[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) { pP[k][c] = 0.f; pQ[k][c] = 0.f; }
+  }
+  for (int clip = blockIdx.x; clip < B; clip += gridDim.x) {
+    const float* gz = Zg + (size_t)clip * CI * TVr;
+    const float* gx = in + (size_t)clip * CI * TVr;
+    const float* gd = dU + ((size_t)clip * Co + (size_t)wave * RW) * TVr;
+    for (int l = lane; l < n4; l += 64) {       // (one trip for T V <= 256)
+      float4 z[CI], x[CI];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        z[c] = *reinterpret_cast<const float4*>(gz + c * TVr + 4 * l);
+        x[c] = need_q ? act4(*reinterpret_cast<const float4*>(gx + c * TVr + 4 * l), pre, a_in) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+      float4 d[RW];
+#pragma unroll
+      for (int k = 0; k < RW; ++k)
+        d[k] = (wave * RW + k < Co) ? *reinterpret_cast<const float4*>(gd + (size_t)k * TVr + 4 * l) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        pS[k] += (d[k].x + d[k].y) + (d[k].z + d[k].w);
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          pP[k][c] += dot4(d[k], z[c]);
+          pQ[k][c] += dot4(d[k], x[c]);
+        }
+      }
+    }
+  }
+  // lanes -> one value per (row, channel); every wave owns its own rows of the block's partial row
+  const int Ci = CI;
+  float* dst = partials + (size_t)blockIdx.x * (2 * Co * Ci + Co);
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const int o = wave * RW + k;
+    const float s = wave_sum(pS[k]);
+    if (lane == 0 && o < Co) dst[2 * Co * Ci + o] = s;
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+      const float p = wave_sum(pP[k][c]), q = wave_sum(pQ[k][c]);
+      if (lane == 0 && o < Co) {
+        dst[o * Ci + c] = p;
+        dst[Co * Ci + o * Ci + c] = q;
+      }
+    }
+  }
+}
+
+template <int T, int V, int CI, int RW>
+__global__ __launch_bounds__(64 * NW, 4) void k_first_bwd(const float* __restrict__ in, const float* __restrict__ Zg,
+                                                      const float* __restrict__ dU, const float* __restrict__ Aw,
+                                                      const float* __restrict__ Tw, const float* __restrict__ coef,
+                                                      const float* __restrict__ in_slope, float* __restrict__ partials, int B,
+                                                      int Co) {
+  constexpr int TV = T * V, NA = T * V * V, NT = V * T * T, N4 = TV / 4;
+  constexpr int CiP = 16;                       // round_up(C_in, 16): row stride of the coefficient block
+  static_assert(TV % 4 == 0 && CI <= 4, "few-channel layer: T V a multiple of 4");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* AwL = lds;                             // [T][V][V]
+  float* TwL = AwL + NA;                        // [V][T][T]
+  float* Xl = TwL + NT;                         // [CI][TV]
+  float* Yl = Xl + CI * TV;
+  float* dZl = Yl + CI * TV;
+  float* dYl = dZl + CI * TV;
+  float* part = dYl + CI * TV;                  // [NW waves][CI][TV]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  constexpr int NTH = 64 * NW;
+  for (int e = tid; e < NA; e += NTH) AwL[e] = Aw[e];
+  for (int e = tid; e < NT; e += NTH) TwL[e] = Tw[e];
+  const float* Bt = coef;                       // rows o < Co: Bt[o][c];  rows Co + c2: Kt[c2][c];  then kt[c]
+  const float* Kt = coef + (size_t)Co * CiP;
+  const float* kt = coef + (size_t)(Co + CI) * CiP;
+  // this thread's share of the sums: dA outputs e = tid + NTH k, dT outputs likewise
+  constexpr int KA = (NA + NTH - 1) / NTH, KT = (NT + NTH - 1) / NTH;
+  float accA[KA], accT[KT];
+  int ya[KA], za[KA], xt[KT], yt[KT];            // LDS offsets of the two factors (channel 0)
+#pragma unroll
+  for (int k = 0; k < KA; ++k) {
+    const int e = tid + NTH * k, ec = e < NA ? e : 0;
+    const int t = ec / (V * V), v = (ec / V) % V, w = ec % V;
+    ya[k] = t * V + v;
+    za[k] = t * V + w;
+    accA[k] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const int e = tid + NTH * k, ec = e < NT ? e : 0;
+    const int v = ec / (T * T), t = (ec / T) % T, q = ec % T;
+    xt[k] = t * V + v;
+    yt[k] = q * V + v;
+    accT[k] = 0.f;
+  }
+
+  for (int clip = blockIdx.x; clip < B; clip += gridDim.x) {
+    // ---- partial dZ over this wave's rows of dU (a lane owns four positions) ----------------------------------------------
+    const float* gd = dU + ((size_t)clip * Co + (size_t)wave * RW) * TV;
+    for (int l = lane; l < N4; l += 64) {
+      float4 dz[CI];
+#pragma unroll
+      for (int c = 0; c < CI; ++c) dz[c] = float4{0.f, 0.f, 0.f, 0.f};
+      float4 d[RW];
+#pragma unroll
+      for (int k = 0; k < RW; ++k)
+        d[k] = (wave * RW + k < Co) ? *reinterpret_cast<const float4*>(gd + (size_t)k * TV + 4 * l) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        const int o = wave * RW + k < Co ? wave * RW + k : 0;
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          const float b = Bt[o * CiP + c];      // wave-uniform
+          dz[c].x = fmaf(b, d[k].x, dz[c].x); dz[c].y = fmaf(b, d[k].y, dz[c].y);
+          dz[c].z = fmaf(b, d[k].z, dz[c].z); dz[c].w = fmaf(b, d[k].w, dz[c].w);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CI; ++c) *reinterpret_cast<float4*>(part + (wave * CI + c) * TV + 4 * l) = dz[c];
+    }
+    __syncthreads();                            // (also: the previous clip's dA / dT reads of Xl .. dYl are done)
+    // ---- dZ = kt + Kt.Z + the four partials;  X ------------------------------------------------------------------------------
+    for (int e = tid; e < CI * TV; e += NTH) {
+      const int c = e / TV, p = e - c * TV;
+      float v = kt[c];
+#pragma unroll
+      for (int c2 = 0; c2 < CI; ++c2) v = fmaf(Kt[c2 * CiP + c], Zg[((size_t)clip * CI + c2) * TV + p], v);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += part[(w * CI + c) * TV + p];
+      dZl[e] = v;
+      Xl[e] = act(in[(size_t)clip * CI * TV + e], pre, a_in);
+    }
+    __syncthreads();
+    // ---- Y[c][q,v] = sum_t X[c][t,v] T[v][t][q];  dY[c][t,v] = sum_w A[t][v][w] dZ[c][t,w] ----------------------------------------
+    for (int e = tid; e < CI * TV; e += NTH) {
+      const int c = e / TV, p = e - c * TV, q = p / V, v = p - q * V;
+      float y = 0.f, dy = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) y = fmaf(Xl[c * TV + t * V + v], TwL[v * T * T + t * T + q], y);
+#pragma unroll
+      for (int w = 0; w < V; ++w) dy = fmaf(AwL[q * V * V + v * V + w], dZl[c * TV + q * V + w], dy);
+      Yl[e] = y;
+      dYl[e] = dy;
+    }
+    __syncthreads();
+    // ---- dA, dT ---------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) s = fmaf(Yl[c * TV + ya[k]], dZl[c * TV + za[k]], s);
+      accA[k] += s;
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < CI; ++c) s = fmaf(Xl[c * TV + xt[k]], dYl[c * TV + yt[k]], s);
+      accT[k] += s;
+    }
+  }
+  float* dst = partials + (size_t)blockIdx.x * (NA + NT);
+#pragma unroll
+  for (int k = 0; k < KA; ++k)
+    if (tid + NTH * k < NA) dst[tid + NTH * k] = accA[k];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+    if (tid + NTH * k < NT) dst[NA + tid + NTH * k] = accT[k];
+}
+
+}  // namespace fl
+
+bool first_layer_ok(int T_, int V_, int Ci, int Co) { return Ci <= 4 && Co <= 64 && (T_ * V_) % 4 == 0; }
+
+// stage 1 for a few-channel layer; partial rows written: *rows_out (each 2 Co Ci + Co floats)
+int launch_first_stats(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B, int Ci,
+                       int Co, int TVr, int need_q, int max_rows, hipStream_t st, int* rows_out) {
+  int grid = B < 1024 ? B : 1024;
+  if (grid > max_rows) grid = max_rows;
+  *rows_out = grid;
+  const int rw = ceil_div(Co, fl::NW);
+#define LAUNCH_FS(CI, RW) \
+  hipLaunchKernelGGL((fl::k_first_stats<CI, RW>), dim3(grid), dim3(64 * fl::NW), 0, st, in, Zg, dU, in_slope, partials, B, Co, TVr, need_q)
+#define LAUNCH_FS_C(CI)                         \
+  do {                                          \
+    if (rw <= 4) LAUNCH_FS(CI, 4);              \
+    else if (rw <= 8) LAUNCH_FS(CI, 8);         \
+    else LAUNCH_FS(CI, 16);                     \
+  } while (0)
+  {
+    ProbeScope probe(KID_BWD_REDUCE, Ci, Co, st);
+    if (Ci == 1) LAUNCH_FS_C(1);
+    else if (Ci == 2) LAUNCH_FS_C(2);
+    else if (Ci == 3) LAUNCH_FS_C(3);
+    else LAUNCH_FS_C(4);
+  }
+#undef LAUNCH_FS_C
+#undef LAUNCH_FS
+  return check_launch("first_stats");
+}
+
+// stages 3 + 4 for a few-channel layer without dIn; partial rows written: *rows_out (each T V V + V T T floats)
+template <int T, int V>
+static int launch_first_bwd_tv(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw, const float* coef,
+                               const float* in_slope, float* partials, int B, int Ci, int Co, int max_rows, hipStream_t st,
+                               int* rows_out) {
+  int grid = B < 1024 ? B : 1024;
+  if (grid > max_rows) grid = max_rows;
+  *rows_out = grid;
+  const int rw = ceil_div(Co, fl::NW);
+  const size_t lds = ((size_t)T * V * V + (size_t)V * T * T + (4 + fl::NW) * (size_t)Ci * T * V) * sizeof(float);
+#define LAUNCH_FB1(CI, RW)                                                                                              \
+  do {                                                                                                                  \
+    auto k = fl::k_first_bwd<T, V, CI, RW>;                                                                             \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * fl::NW), lds, st, in, Zg, dU, Aw, Tw, coef, in_slope, partials, B, Co);          \
+  } while (0)
+#define LAUNCH_FB1_C(CI)                        \
+  do {                                          \
+    if (rw <= 4) LAUNCH_FB1(CI, 4);             \
+    else if (rw <= 8) LAUNCH_FB1(CI, 8);        \
+    else LAUNCH_FB1(CI, 16);                    \
+  } while (0)
+  {
+    ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
+    if (Ci == 1) LAUNCH_FB1_C(1);
+    else if (Ci == 2) LAUNCH_FB1_C(2);
+    else if (Ci == 3) LAUNCH_FB1_C(3);
+    else LAUNCH_FB1_C(4);
+  }
+#undef LAUNCH_FB1_C
+#undef LAUNCH_FB1
+  return check_launch("first_bwd");
+}
+
+int launch_first_bwd(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw, const float* coef,
+                     const float* in_slope, float* partials, int B, int Ci, int Co, int T, int V, int max_rows, hipStream_t st,
+                     int* rows_out) {
+#define CALL(T_, V_) return launch_first_bwd_tv<T_, V_>(in, Zg, dU, Aw, Tw, coef, in_slope, partials, B, Ci, Co, max_rows, st, rows_out)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+}  // namespace coskad

@@ -1116,6 +1116,13 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
                            float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out);
 constexpr size_t kXscrFloats = (size_t)kMaxGridBwd * 13 * 2 * 256;   // fused_bwd.hip: one tile-major dXres slab per wave
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
+// first_layer.hip
+bool first_layer_ok(int T_, int V_, int Ci, int Co);
+int launch_first_stats(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B, int Ci,
+                       int Co, int TVr, int need_q, int max_rows, hipStream_t st, int* rows_out);
+int launch_first_bwd(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw, const float* coef,
+                     const float* in_slope, float* partials, int B, int Ci, int Co, int T, int V, int max_rows, hipStream_t st,
+                     int* rows_out);
 int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, const float* dap, float* dslope, int accumulate,
                         hipStream_t st);
 constexpr size_t kFusedRowFloats = 37 * 256;   // lane-major partial row of fused_bwd.hip
@@ -1225,7 +1232,13 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     // stored Z: one dU pass with X and Z both resident, no mixing tables in LDS.  When one clip's X + Z images exceed
     // the LDS (64 input channels at 25 joints: the default-width decoder on the NTU layout) the two-pass kernel below
     // runs instead; it takes the stored Z as well.
-    if (Zg && zlds(1) <= (size_t)kMaxLdsBytes) {
+    if (Zg && first_layer_ok(T, V, Ci, Co)) {
+      // a handful of input channels (the first layer): plain FMAs on full-line loads (first_layer.hip)
+      int rows = 0;
+      if ((rc = launch_first_stats(in, Zg, dU, in_slope, w.partials, B, Ci, Co, TV, need_q, kMaxGridBwd, st, &rows))) return rc;
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, w.red);
+      if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+    } else if (Zg && zlds(1) <= (size_t)kMaxLdsBytes) {
       const bool three_z = nto * ntc <= 2;
       const size_t cap = three_z ? (size_t)52 * 1024 : (size_t)76 * 1024;
       int NBz = NB;
@@ -1312,6 +1325,13 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows)))
       return rc;
     return launch_reduce_fused(w.partials, rows, dA, dT, dap, dslope_in, accumulate, st);
+  }
+  if (Zg && !dIn && !dz_ext && first_layer_ok(T, V, Ci, Co)) {
+    int rows = 0;
+    if ((rc = launch_first_bwd(in, Zg, dU, Aw, Tw, w.coef, in_slope, w.partials, B, Ci, Co, T, V, kMaxGridBwd, st, &rows))) return rc;
+    hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(T * V * V + V * T * T, 64)), dim3(1024), 0, st, w.partials, rows, T * V * V,
+                       V * T * T, dA, dT, (const float*)nullptr, 0, (float*)nullptr, accumulate);
+    return check_launch("bwd_gcn_reduce");
   }
   // 3. data path
   int grid_d;

@@ -108,6 +108,47 @@ def test_layer_backward(Ci, Co, V, B, first, identity):
         close(grads["slope_in"], so.grad, rtol=5e-4, atol_rel=1e-4, msg="dslope_in")
 
 
+@pytest.mark.parametrize("Ci,Co,V,B", [(2, 32, 17, 37), (2, 32, 17, 1500), (3, 32, 25, 21), (2, 64, 14, 9), (4, 8, 18, 5)])
+def test_first_layer_backward_stored_z_vs_oracle(Ci, Co, V, B):
+    """The few-channel layer (no dIn, raw input) on the stored-Z path = csrc/first_layer.hip (k_first_stats, k_first_bwd)
+    against the torch-autograd oracle of stsgcn.py:94-116 on the CPU."""
+    from coskad_amd import ops
+    T = 12
+    st = make_layer_state(Ci, Co, V, seed=Ci * 100 + Co + V)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Ci, T, V, generator=g)
+    probe = torch.randn(B, Co, T, V, generator=g)
+    pk = [k for k in st if R.is_param_key(k) and st[k].is_floating_point()]
+    stc = {k: v.clone() for k, v in st.items()}
+    for k in pk:
+        stc[k].requires_grad_(True)
+    U = R.st_gcnn_layer(x, stc, "L", training=True, return_preact=True)
+    (U * probe).sum().backward()
+    d = {k[2:]: dev(v) for k, v in st.items()}
+    ws = torch.empty(max(ops.train_stats_ws_bytes(Ci), ops.layer_bwd_ws_bytes(B, Ci, Co, T, V)), dtype=torch.uint8, device="cuda")
+    Wt, Wr = d["tcn.0.weight"].reshape(Co, Ci), d["residual.0.weight"].reshape(Co, Ci)
+    Z = torch.empty(B, Ci, T, V, device="cuda")
+    _, _, stat = ops.layer_train_stats(
+        dev(x), d["gcn.A"], d["gcn.T"], None, Wt, d["tcn.0.bias"], d["tcn.1.weight"], d["tcn.1.bias"],
+        d["tcn.1.running_mean"], d["tcn.1.running_var"], d["tcn.1.num_batches_tracked"],
+        Wr, d["residual.0.bias"], d["residual.1.weight"], d["residual.1.bias"],
+        d["residual.1.running_mean"], d["residual.1.running_var"], d["residual.1.num_batches_tracked"], ws, Z=Z)
+    z = lambda *s_: torch.full(s_, float("nan"), device="cuda")
+    grads = {"A": z(T, V, V), "T": z(V, T, T), "Wt": z(Co, Ci), "bt": z(Co), "gt": z(Co), "bet": z(Co), "Wr": z(Co, Ci),
+             "br": z(Co), "gr": z(Co), "ber": z(Co)}
+    ops.layer_bwd(dev(x), dev(probe), d["gcn.A"], d["gcn.T"], None, stat, Wt, d["tcn.1.weight"], Wr, d["residual.1.weight"],
+                  grads, ws, need_dx=False, Z=Z)
+    gmax = max(float(stc[k].grad.abs().max()) for k in pk if stc[k].grad is not None)
+    ref = {"A": stc["L.gcn.A"].grad, "T": stc["L.gcn.T"].grad, "Wt": stc["L.tcn.0.weight"].grad.reshape(Co, Ci),
+           "bt": stc["L.tcn.0.bias"].grad, "gt": stc["L.tcn.1.weight"].grad, "bet": stc["L.tcn.1.bias"].grad,
+           "Wr": stc["L.residual.0.weight"].grad.reshape(Co, Ci), "br": stc["L.residual.0.bias"].grad,
+           "gr": stc["L.residual.1.weight"].grad, "ber": stc["L.residual.1.bias"].grad}
+    for k, r in ref.items():
+        a, b = grads[k].cpu().numpy(), r.numpy()
+        assert np.isfinite(a).all(), k
+        np.testing.assert_allclose(a, b, rtol=5e-4, atol=5e-5 * max(np.abs(b).max(), 1e-9) + 2e-5 * gmax, err_msg=k)
+
+
 @pytest.mark.parametrize("Ci,Co,B", [(32, 64, 1031), (16, 32, 2053), (32, 16, 1026)])
 def test_fused_backward_ragged_batch_vs_split_kernels(Ci, Co, B):
     """Stored-Z path (csrc/fused_bwd.hip: one clip per wavefront, several clips per wave, ragged last round) against the
