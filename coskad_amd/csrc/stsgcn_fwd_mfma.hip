@@ -241,6 +241,13 @@ template int launch_layer_apply_m<12, 18>(const float*, float*, const float*, co
 
 }  // namespace coskad
 
+namespace coskad {
+// fused_apply.hip
+bool layer_apply_ring_ok(int T_, int V_, int Ci, int Co);
+int launch_layer_apply_ring(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
+                            const float* in_slope, int B, int Ci, int Co, hipStream_t st);
+}  // namespace coskad
+
 using namespace coskad;
 extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const float* A, const float* Tm,
                                         const float* wfold, const float* bias, const float* in_slope,
@@ -248,6 +255,8 @@ extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* 
                                         hipStream_t stream) {
   if (!Z || !in || !out || !A || !Tm || !wfold || !bias) return fail(COSKAD_ERR_ARG, "layer_apply_z: null pointer");
   if (B <= 0 || Ci <= 0 || Co <= 0 || Co > 64 || Ci > 64) return fail(COSKAD_ERR_ARG, "layer_apply_z: B=%d Ci=%d Co=%d", B, Ci, Co);
+  // default geometry, 16 / 32 input channels, pre-activation output: the wave-per-clip K-ring GEMM (fused_apply.hip)
+  if (!out_slope && layer_apply_ring_ok(T, V, Ci, Co)) return launch_layer_apply_ring(Z, in, out, wfold, bias, in_slope, B, Ci, Co, stream);
   // <= 32 output channels: streaming GEMM over Z and `in`; wider: the LDS-tiled kernel with Z staged instead of mixed
   // (needs the mixing tables only as a layout; A/Tm are not read when Z is given)
 #define CALL(T_, V_)                                                                                              \

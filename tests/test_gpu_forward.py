@@ -133,3 +133,34 @@ def test_train_forward_large_ragged_batch():
         np.testing.assert_allclose(a.numpy(), r.numpy(), rtol=1e-4, atol=1e-4, err_msg=f"layer {i}")
     for k, v in bufs.items():
         np.testing.assert_allclose(v.numpy(), st_ref[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("Ci,Co,B", [(32, 64, 1031), (16, 32, 2053), (32, 16, 1026), (16, 16, 7), (32, 32, 5), (16, 64, 6)])
+def test_apply_ring_ragged_batch_vs_recompute_kernel(Ci, Co, B):
+    """Training-mode apply on the stored-Z path (csrc/fused_apply.hip: wave-per-clip K-ring GEMM, several clips per wave,
+    ragged last round) against the recompute kernel of the same library (k_layer_apply / _m: mixes X itself) with the same
+    folded weights: two independent implementations of stsgcn.py:94-116's forward.  The output sits inside a guarded buffer."""
+    from coskad_amd import ops
+    T, V = 12, 17
+    g = torch.Generator().manual_seed(Ci * 7 + Co + B)
+    x = (torch.randn(B, Ci, T, V, generator=g)).cuda()
+    A = ((torch.rand(T, V, V, generator=g) * 2 - 1) / V ** 0.5).cuda()
+    Tm = ((torch.rand(V, T, T, generator=g) * 2 - 1) / T ** 0.5).cuda()
+    sl = torch.tensor([0.2], device="cuda")
+    Wt, Wr = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).cuda(), (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).cuda()
+    one, zero = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
+    gt, gr = (torch.rand(Co, generator=g) + 0.5).cuda(), (torch.rand(Co, generator=g) + 0.5).cuda()
+    bt, br = (torch.randn(Co, generator=g) * 0.1).cuda(), (torch.randn(Co, generator=g) * 0.1).cuda()
+    nb = [torch.zeros((), dtype=torch.int64, device="cuda") for _ in range(2)]
+    ws = torch.empty(ops.train_stats_ws_bytes(Ci), dtype=torch.uint8, device="cuda")
+    Z = torch.empty_like(x)
+    wfold, bias, _ = ops.layer_train_stats(x, A, Tm, sl, Wt, zero.clone(), gt, bt, zero.clone(), one.clone(), nb[0],
+                                           Wr, zero.clone(), gr, br, zero.clone(), one.clone(), nb[1], ws, Z=Z)
+    n, guard = B * Co * T * V, 4096
+    buf = torch.full((n + 2 * guard,), 12345.0, device="cuda")
+    out = buf[guard:guard + n].view(B, Co, T, V)
+    ops.layer_apply_z(Z, x, A, Tm, wfold, bias, Co, in_slope=sl, out=out)
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 12345.0).all()) and bool((buf[guard + n:] == 12345.0).all()), "wrote outside the output"
+    ref = ops.layer_apply(x, A, Tm, wfold, bias, Co, in_slope=sl)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
