@@ -1,0 +1,231 @@
+// Stage 1 of the layer backward on the stored-Z path, wave-per-clip: the batch reductions behind both BatchNorm
+// backward folds (autograd of models/graph_layers/stsgcn.py:94-116 in training mode)
+//     P[o][c] = sum_{b,pos} dU[b][o][pos] Z[b][c][pos]      Q[o][c] = sum dU[b][o][pos] PReLU(U_prev)[b][c][pos]
+//     s[o]    = sum_{b,pos} dU[b][o][pos]
+// for T = 12, V = 17, 16 or 32 input channels.  The contraction runs over positions: both MFMA operands are (row,
+// position) reads of LDS row images of stride 206 (conflict-free; one ds_read_b64 serves two k-steps -- any assignment
+// of positions to k slots is as good as any other as long as both operands use the same one).  One clip per wavefront,
+// no workgroup barrier in the clip loop: the 32-row image holds the B side (Z and X together for 16 input channels; Z,
+// then X in a second phase for 32), the 16-row window the current group of dU rows; the next group / the next source /
+// the next clip's rows travel in registers while the current group multiplies.  Sums of all of a wave's clips stay in
+// accumulator registers; the four waves of a block add theirs into one [P][Q][s] row at the very end (fixed order).
+// Replaces k_bwd_reduce_z (block-per-tile: LDS images + a block barrier per 68-position slab) for these shapes.
+#include "fused_ops.h"
+
+namespace coskad {
+namespace fs {
+
+using namespace ff;
+
+template <int CT, int OT>
+__global__ __launch_bounds__(256, 1) void k_bwd_stats_ring(const float* __restrict__ in, const float* __restrict__ Zg,
+                                                          const float* __restrict__ dU, const float* __restrict__ in_slope,
+                                                          float* __restrict__ partials, int B) {
+  constexpr int Ci = 16 * CT, Co = 16 * OT, NPH = CT;    // phases: one with Z | X side by side (16 channels), else Z then X
+  constexpr int E = 2 * Co * Ci + Co;
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* lds = lds_all + wave * WAVE_LDS;
+  float* r1 = lds + R1;
+  float* r2 = lds + R2;
+  auto geo = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return Lane{l & 15, l >> 4};
+  };
+  auto olane = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const int l16 = lane * 16;
+  const int nwaves = gridDim.x * 4;
+  auto clip_res = [&](const float* base, int c, int rows) {
+    const bool in_range = c < B;
+    return make_res(base + (size_t)(in_range ? c : 0) * rows * TV, in_range ? rows * TV * 4u : 0u);
+  };
+  // ---- a 16-row group of dU through 16 registers per lane (quarters of 4 rows: 3 full 64-lane pieces + one of 12) ----------
+  constexpr int QTAIL = 4 * (TV / 4) - 192;
+  const int l16t = lane < QTAIL ? l16 : 0x7ffffff0;
+  float4 gb[16];
+  auto gload = [&](const BufRes& res, int row0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gb[4 * q + c] = buf_load4(res, c < 3 ? l16 : l16t, ((row0 + 4 * q) * (TV / 4) + 64 * c) * 16);
+  };
+  auto gstore = [&]() {
+    const int ln = olane();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e = ln + 64 * c;
+        const float4 v = gb[4 * q + c];
+        const int row = e / (TV / 4), col = 4 * (e - row * (TV / 4));
+        float* d = r2 + (4 * q + row) * LD + col;
+        if (c < 3 || lane < QTAIL) {
+          *reinterpret_cast<float2*>(d) = float2{v.x, v.y};
+          *reinterpret_cast<float2*>(d + 2) = float2{v.z, v.w};
+        }
+      }
+  };
+  // ---- 16 rows of a B-side source through 13 registers per lane into image rows [row0, row0 + 16) ----------------------------
+  constexpr int SL = (16 * (TV / 4) + 63) / 64;          // 13
+  auto sload = [&](float4 (&dst)[SL], const BufRes& res, int src_row0) {
+#pragma unroll
+    for (int i = 0; i < SL; ++i) dst[i] = buf_load4(res, l16, (src_row0 * (TV / 4) + 64 * i) * 16);
+  };
+  auto sstore = [&](const float4 (&src)[SL], int row0, bool act) {
+    const int ln = olane();
+    constexpr int n4 = 16 * (TV / 4);
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const int e4 = ln + 64 * i;
+      float4 v = src[i];
+      if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+      const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
+      const bool ok = 64 * (i + 1) <= n4 || e4 < n4;
+      *reinterpret_cast<float2*>(r1 + (ok ? (row0 + row) * LD + col : PADCOL)) = float2{v.x, v.y};
+      *reinterpret_cast<float2*>(r1 + (ok ? (row0 + row) * LD + col + 2 : PADCOL)) = float2{v.z, v.w};
+    }
+  };
+  // sums of all this wave's clips
+  f32x4 pacc[OT][CT], qacc[OT][CT];
+  float srow[OT];
+#pragma unroll
+  for (int g = 0; g < OT; ++g) {
+    srow[g] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { pacc[g][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; qacc[g][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  // source halves in flight: sa / sb = the two 16-row halves the next phase puts into the image
+  float4 sa[SL], sb[SL];
+  int clip = blockIdx.x * 4 + wave;
+  {
+    const BufRes z0 = clip_res(Zg, clip, Ci), x0 = clip_res(in, clip, Ci), d0 = clip_res(dU, clip, Co);
+    sload(sa, z0, 0);
+    if (CT == 1) sload(sb, x0, 0); else sload(sb, z0, 16);
+    gload(d0, 0);
+  }
+  for (; clip < B; clip += nwaves) {
+    const BufRes xres = clip_res(in, clip, Ci), dures = clip_res(dU, clip, Co);
+    const BufRes zn = clip_res(Zg, clip + nwaves, Ci), xn = clip_res(in, clip + nwaves, Ci), dn = clip_res(dU, clip + nwaves, Co);
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      Lane L = geo();
+      // the image takes this phase's two halves; the next phase's (or the next clip's first) take off
+      const bool xphase = ph == 1;                       // (32 channels) second phase: both halves are X
+      sstore(sa, 0, xphase && pre);
+      sstore(sb, 16, (CT == 1 || xphase) && pre);
+      if (CT == 2 && ph == 0) { sload(sa, xres, 0); sload(sb, xres, 16); }
+      else if (CT == 2) { sload(sa, zn, 0); sload(sb, zn, 16); }
+      else { sload(sa, zn, 0); sload(sb, xn, 0); }
+#pragma unroll
+      for (int g = 0; g < OT; ++g) {
+        gstore();                                        // group g of dU -> window (all reads of the previous group are issued)
+        if (g + 1 < OT) gload(dures, 16 * (g + 1));
+        else if (ph + 1 < NPH) gload(dures, 0);
+        else gload(dn, 0);
+        // 26 double steps: lane (j, q) reads positions 8 m + 2 q, + 1 of row j of each operand
+        const float* ap = r2 + L.j * LD + 2 * L.q;
+        const float* bp0 = r1 + L.j * LD + 2 * L.q;
+        const float* bp1 = r1 + (16 + L.j) * LD + 2 * L.q;
+        f32x4 c0 = (CT == 2 && xphase) ? qacc[g][0] : pacc[g][0];
+        f32x4 c1 = (CT == 1 || xphase) ? qacc[g][CT - 1] : pacc[g][CT - 1];
+        float ssum = 0.f;
+        constexpr int NM = (TV + 7) / 8;                 // 26
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          float2 a = *reinterpret_cast<const float2*>(ap + 8 * m);
+          float2 b0 = *reinterpret_cast<const float2*>(bp0 + 8 * m);
+          float2 b1 = *reinterpret_cast<const float2*>(bp1 + 8 * m);
+          if (8 * (m + 1) > TV) {                        // the last step's tail lies in the rows' padding: zero the A side
+            const bool ok = 8 * m + 2 * L.q < TV;
+            a.x = ok ? a.x : 0.f; a.y = ok ? a.y : 0.f;
+            b0.x = ok ? b0.x : 0.f; b0.y = ok ? b0.y : 0.f;
+            b1.x = ok ? b1.x : 0.f; b1.y = ok ? b1.y : 0.f;
+          }
+          c0 = mfma(a.x, b0.x, c0);
+          c1 = mfma(a.x, b1.x, c1);
+          c0 = mfma(a.y, b0.y, c0);
+          c1 = mfma(a.y, b1.y, c1);
+          ssum += a.x + a.y;
+        }
+        if (CT == 2 && xphase) qacc[g][0] = c0; else pacc[g][0] = c0;
+        if (CT == 1 || xphase) qacc[g][CT - 1] = c1; else pacc[g][CT - 1] = c1;
+        if (ph == 0) srow[g] += ssum;
+      }
+    }
+  }
+
+  // ---- block sum: the waves add their tiles into one LDS row one after another (fixed order), then the row leaves ------------
+  float* row = lds_all;                                  // E floats (<= 16.6 KB) over wave 0's image: all clip loops are done
+  __syncthreads();
+  const Lane L = geo();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int g = 0; g < OT; ++g) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 16 * g + 4 * L.q + r, c = 16 * ct + L.j;   // D layout: register r <-> row 4 q + r, column j
+            float* p = row + o * Ci + c;
+            p[0] = (w ? p[0] : 0.f) + pacc[g][ct][r];
+            p[Co * Ci] = (w ? p[Co * Ci] : 0.f) + qacc[g][ct][r];
+          }
+        const float s = quad_sum(srow[g]);               // lane (j, q): the positions 8 m + 2 q, + 1 of row 16 g + j
+        if (L.q == 0) {
+          float* p = row + 2 * Co * Ci + 16 * g + L.j;
+          p[0] = (w ? p[0] : 0.f) + s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* dst = partials + (size_t)blockIdx.x * E;
+  for (int e = threadIdx.x; e < E; e += 256) dst[e] = row[e];
+}
+
+}  // namespace fs
+
+// Used where it wins (B = 4096, in-step timings): 32 -> 16 channels 54 vs 73 us, 16 -> 32 channels 44-55 vs 55 us; at
+// 32 -> 64 the rows of dU pass the window twice (two phases x four groups) and the block-per-tile kernel is faster (125 vs
+// 148 us), so wide outputs on 32 input channels stay there.
+bool bwd_stats_ring_ok(int T_, int V_, int Ci, int Co) {
+  return T_ == ff::T && V_ == ff::V && ((Ci == 16 && (Co == 16 || Co == 32 || Co == 64)) || (Ci == 32 && Co == 16));
+}
+
+// partial rows written: *rows_out (<= 256), each 2 Co Ci + Co floats
+int launch_bwd_stats_ring(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
+                          int Ci, int Co, hipStream_t st, int* rows_out) {
+  const size_t lds = (size_t)4 * ff::WAVE_LDS * sizeof(float);
+  const int nblk = (B + 3) / 4;
+  const int grid = nblk < 256 ? nblk : 256;
+  *rows_out = grid;
+#define LAUNCH_FS(CT, OT)                                                                                        \
+  do {                                                                                                           \
+    auto k = fs::k_bwd_stats_ring<CT, OT>;                                                                       \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, in_slope, partials, B);                    \
+  } while (0)
+  {
+    ProbeScope probe(KID_BWD_REDUCE, Ci, Co, st);
+    if (Ci == 16 && Co == 16) LAUNCH_FS(1, 1);
+    else if (Ci == 16 && Co == 32) LAUNCH_FS(1, 2);
+    else if (Ci == 16 && Co == 64) LAUNCH_FS(1, 4);
+    else if (Ci == 32 && Co == 16) LAUNCH_FS(2, 1);
+    else if (Ci == 32 && Co == 32) LAUNCH_FS(2, 2);
+    else if (Ci == 32 && Co == 64) LAUNCH_FS(2, 4);
+    else return fail(COSKAD_ERR_SHAPE, "bwd_stats_ring: unsupported channels (%d, %d)", Ci, Co);
+  }
+#undef LAUNCH_FS
+  return check_launch("bwd_stats_ring");
+}
+
+}  // namespace coskad

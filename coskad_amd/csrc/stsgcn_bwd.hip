@@ -1116,6 +1116,10 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
                            float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out);
 constexpr size_t kXscrFloats = (size_t)kMaxGridBwd * 13 * 2 * 256;   // fused_bwd.hip: one tile-major dXres slab per wave
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
+// fused_stats.hip
+bool bwd_stats_ring_ok(int T_, int V_, int Ci, int Co);
+int launch_bwd_stats_ring(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
+                          int Ci, int Co, hipStream_t st, int* rows_out);
 // first_layer.hip
 bool first_layer_ok(int T_, int V_, int Ci, int Co);
 int launch_first_stats(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B, int Ci,
@@ -1236,6 +1240,12 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
       // a handful of input channels (the first layer): plain FMAs on full-line loads (first_layer.hip)
       int rows = 0;
       if ((rc = launch_first_stats(in, Zg, dU, in_slope, w.partials, B, Ci, Co, TV, need_q, kMaxGridBwd, st, &rows))) return rc;
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, w.red);
+      if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+    } else if (Zg && bwd_stats_ring_ok(T, V, Ci, Co)) {
+      // default geometry, 16 / 32 input channels: wave-per-clip reductions (fused_stats.hip)
+      int rows = 0;
+      if ((rc = launch_bwd_stats_ring(in, Zg, dU, in_slope, w.partials, B, Ci, Co, st, &rows))) return rc;
       hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, w.red);
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
     } else if (Zg && zlds(1) <= (size_t)kMaxLdsBytes) {
