@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_ring(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* lds = lds_all + wave * WAVE_LDS;
+  float* lds = lds_all + wave * WAVE_LDS_W;
   float* r1 = lds + R1;
   float* r2 = lds + R2;
   auto geo = [&]() {
@@ -63,11 +63,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_ring(const float* __rest
       float4 v = gb[4 * q + c];
       if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
       const int row = e / (TV / 4), col = 4 * (e - row * (TV / 4));
-      float* d = r2 + (4 * q + row) * LD + col;
-      if (c < 3 || lane < QTAIL) {
-        *reinterpret_cast<float2*>(d) = float2{v.x, v.y};
-        *reinterpret_cast<float2*>(d + 2) = float2{v.z, v.w};
-      }
+      if (c < 3 || lane < QTAIL) *reinterpret_cast<float4*>(r2 + (4 * q + row) * LDW + col) = v;
     }
   };
   int clip = blockIdx.x * 4 + wave;
@@ -110,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_ring(const float* __rest
       cload(0, 0);
       float b[2][NTILE];
 #pragma unroll
-      for (int t = 0; t < NTILE; ++t) b[0][t] = r2[L.q * LD + (t < T ? t * V + L.j : jc * V + 16)];
+      for (int t = 0; t < NTILE; ++t) b[0][t] = r2[L.q * LDW + (t < T ? t * V + L.j : jc * V + 16)];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         if (g + 1 < NG) cload((g + 1) & 1, g + 1);
@@ -125,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_ring(const float* __rest
           if (s + 1 < 4 || g + 1 < NG) {
             const int sn = (s + 1) & 3;
 #pragma unroll
-            for (int t = 0; t < NTILE; ++t) b[(s + 1) & 1][t] = r2[(4 * sn + L.q) * LD + (t < T ? t * V + L.j : jc * V + 16)];
+            for (int t = 0; t < NTILE; ++t) b[(s + 1) & 1][t] = r2[(4 * sn + L.q) * LDW + (t < T ? t * V + L.j : jc * V + 16)];
           }
           if (g + 1 < NG) {
             qstore(s, g + 1 >= CT && pre);
@@ -176,7 +172,7 @@ bool layer_apply_ring_ok(int T_, int V_, int Ci, int Co) {
 
 int launch_layer_apply_ring(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
                             const float* in_slope, int B, int Ci, int Co, hipStream_t st) {
-  const size_t lds = (size_t)4 * ff::WAVE_LDS * sizeof(float);
+  const size_t lds = (size_t)4 * ff::WAVE_LDS_W * sizeof(float);
   const int nblk = (B + 3) / 4;
   const int grid = nblk < 256 ? nblk : 256;
 #define LAUNCH_FA(CT, OTP, NP)                                                                                   \

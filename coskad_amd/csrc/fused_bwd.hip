@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* lds = lds_all + wave * WAVE_LDS;
+  float* lds = lds_all + wave * WAVE_LDS_W;
   float* r1 = lds + R1;
   float* r2 = lds + R2;
   auto geo = [&]() {
@@ -176,11 +176,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
       float4 v = gb[4 * q + c];
       if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
       const int row = e / (TV / 4), col = 4 * (e - row * (TV / 4));
-      float* d = r2 + (4 * q + row) * LD + col;
-      if (c < 3 || lane < QTAIL) {
-        *reinterpret_cast<float2*>(d) = float2{v.x, v.y};
-        *reinterpret_cast<float2*>(d + 2) = float2{v.z, v.w};
-      }
+      if (c < 3 || lane < QTAIL) *reinterpret_cast<float4*>(r2 + (4 * q + row) * LDW + col) = v;
     }
   };
   auto gload = [&](const BufRes& res, int row0) {
@@ -266,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
       cload(0, 0);
       float b[2][NTILE];
 #pragma unroll
-      for (int t = 0; t < NTILE; ++t) b[0][t] = r2[L.q * LD + (t < T ? t * V + L.j : jc * V + 16)];
+      for (int t = 0; t < NTILE; ++t) b[0][t] = r2[L.q * LDW + (t < T ? t * V + L.j : jc * V + 16)];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         if (g + 1 < NG) cload((g + 1) & 1, g + 1);
@@ -276,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
           if (s + 1 < 4 || g + 1 < NG) {                 // operands of the next k-step (the next group's first: stored at s = 0)
             const int sn = (s + 1) & 3;
 #pragma unroll
-            for (int t = 0; t < NTILE; ++t) b[(s + 1) & 1][t] = r2[(4 * sn + L.q) * LD + (t < T ? t * V + L.j : jc * V + 16)];
+            for (int t = 0; t < NTILE; ++t) b[(s + 1) & 1][t] = r2[(4 * sn + L.q) * LDW + (t < T ? t * V + L.j : jc * V + 16)];
           }
           if (g + 1 < NG) {                              // this k-step's rows are free: the next group's quarter moves in
             qstore(s, g + 1 >= OT && act2);
@@ -370,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
           float a[V], b[V];
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            a[v] = r2[(4 * s + L.q) * LD + ic * V + v];
+            a[v] = r2[(4 * s + L.q) * LDW + ic * V + v];
             b[v] = r1[(16 * h + 4 * s + L.q) * LD + ic * V + v];
           }
 #pragma unroll
@@ -472,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
       float4 s = reinterpret_cast<const float4*>(lds_all)[rec * 64 + lane];
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
-        const float4 o = reinterpret_cast<const float4*>(lds_all + w * WAVE_LDS)[rec * 64 + lane];
+        const float4 o = reinterpret_cast<const float4*>(lds_all + w * WAVE_LDS_W)[rec * 64 + lane];
         s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
       }
       // one record at a time, drained: with all 32 b128 reads of the unrolled loop in flight (more than the 4-bit LGKM
@@ -492,8 +488,8 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
   }
 #endif
   if (threadIdx.x == 0 && dap)
-    dap[blockIdx.x] = ((lds_all[PR_N * 256] + lds_all[WAVE_LDS + PR_N * 256]) + lds_all[2 * WAVE_LDS + PR_N * 256]) +
-                      lds_all[3 * WAVE_LDS + PR_N * 256];
+    dap[blockIdx.x] = ((lds_all[PR_N * 256] + lds_all[WAVE_LDS_W + PR_N * 256]) + lds_all[2 * WAVE_LDS_W + PR_N * 256]) +
+                      lds_all[3 * WAVE_LDS_W + PR_N * 256];
 }
 
 }  // namespace fb
@@ -505,7 +501,7 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
   hipLaunchKernelGGL(fb::k_build_btab, dim3(ceil_div(fb::BTAB_F4 * 4, 256)), dim3(256), 0, st, Aw, Tw, btab);
   int rc;
   if ((rc = check_launch("bwd_build_btab"))) return rc;
-  const size_t lds = (size_t)4 * ff::WAVE_LDS * sizeof(float);
+  const size_t lds = (size_t)4 * ff::WAVE_LDS_W * sizeof(float);
   const int nblk = (B + 3) / 4;
 #ifndef FB_GRID
 #define FB_GRID 256   // one 4-wave block per CU (LDS-bound)

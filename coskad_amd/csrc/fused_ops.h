@@ -14,6 +14,12 @@ constexpr int LD = 206;                 // row stride: = 2 (mod 4) -> (row, k) o
 constexpr int R1 = 0, R2 = 32 * LD;     // float offsets inside the wave's LDS image
 constexpr int PADCOL = TV;              // columns 204, 205 of every row are padding: masked lanes store there (no divergent branches)
 constexpr int WAVE_LDS = 48 * LD;       // floats per wave
+// The K-ring kernels (fused_bwd.hip, fused_apply.hip) give their 16-row window its own stride: 208 = 16 (mod 64) makes the
+// window's only read pattern -- lane (j, q) reads row 4 s + q, position base + j -- conflict-free, and rows 16-byte aligned,
+// so a staged float4 is ONE ds_write_b128 instead of two half-bank ds_write_b64 (the LDS pipe, shared by the CU's four
+// waves, was ~85 % busy in the K passes with the 206 stride)
+constexpr int LDW = 208;
+constexpr int WAVE_LDS_W = 32 * LD + 16 * LDW;   // floats per wave with that window (9 920: 4 x 39 680 B <= 160 KB)
 constexpr int NTILE = T + 1;
 #ifndef FF_AB_UNROLL
 #define FF_AB_UNROLL _Pragma("unroll")     // tile loops of layers 1-2: fully unrolled like layers 3-4 (rolled: 213 vs 199 us at B = 4096 --
