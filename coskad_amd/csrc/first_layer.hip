@@ -111,7 +111,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_first_bwd(const float* __restric
   const float a_in = pre ? in_slope[0] : 0.f;
   constexpr int NTH = 64 * NW;
   for (int e = tid; e < NA; e += NTH) AwL[e] = Aw[e];
-  for (int e = tid; e < NT; e += NTH) TwL[e] = Tw[e];
+  for (int e = tid; e < NT; e += NTH) {         // [t][q][v]: consecutive lanes (joints) read consecutive words
+    const int v = e / (T * T), tq = e - v * T * T;
+    TwL[tq * V + v] = Tw[e];
+  }
   const float* Bt = coef;                       // rows o < Co: Bt[o][c];  rows Co + c2: Kt[c2][c];  then kt[c]
   const float* Kt = coef + (size_t)Co * CiP;
   const float* kt = coef + (size_t)(Co + CI) * CiP;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_first_bwd(const float* __restric
       const int c = e / TV, p = e - c * TV, q = p / V, v = p - q * V;
       float y = 0.f, dy = 0.f;
 #pragma unroll
-      for (int t = 0; t < T; ++t) y = fmaf(Xl[c * TV + t * V + v], TwL[v * T * T + t * T + q], y);
+      for (int t = 0; t < T; ++t) y = fmaf(Xl[c * TV + t * V + v], TwL[(t * T + q) * V + v], y);
 #pragma unroll
       for (int w = 0; w < V; ++w) dy = fmaf(AwL[q * V * V + v * V + w], dZl[c * TV + q * V + w], dy);
       Yl[e] = y;
@@ -208,6 +211,118 @@ __global__ __launch_bounds__(64 * NW, 4) void k_first_bwd(const float* __restric
 #pragma unroll
   for (int k = 0; k < KT; ++k)
     if (tid + NTH * k < NT) dst[NA + tid + NTH * k] = accT[k];
+}
+
+
+// ---- forward (training) of the few-channel layer ------------------------------------------------------------------------------------
+// k_first_moments: per clip X -> sum x x^T, sum x;  Z = gcn(X) (stsgcn.py:154-155) -> stored;  sum z z^T, sum z.  One clip per
+//   wave round, a lane owns positions lane + 64 k; the mixing is 12 + 17 FMAs per element on LDS operands.  Partial row per
+//   block: [MX C^2][sumX C][MZ C^2][sumZ C] (what k_reduce_partials / k_train_fold consume).
+template <int T, int V, int CI>
+__global__ __launch_bounds__(256, 4) void k_first_moments(const float* __restrict__ in, const float* __restrict__ Aw,
+                                                          const float* __restrict__ Tw, const float* __restrict__ in_slope,
+                                                          float* __restrict__ partials, int B, float* __restrict__ Zout) {
+  constexpr int TV = T * V, NA = T * V * V, NT = V * T * T, KP = (TV + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* AwL = lds;
+  float* TwL = AwL + NA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  float* Xl = TwL + NT + wave * 2 * CI * TV;     // this wave's X and Y
+  float* Yl = Xl + CI * TV;
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  for (int e = tid; e < NA; e += 256) AwL[e] = Aw[e];
+  for (int e = tid; e < NT; e += 256) {         // [t][q][v]: consecutive lanes (joints) read consecutive words
+    const int v = e / (T * T), tq = e - v * T * T;
+    TwL[tq * V + v] = Tw[e];
+  }
+  float mx[CI][CI], mz[CI][CI], sx[CI], sz[CI];
+#pragma unroll
+  for (int a = 0; a < CI; ++a) {
+    sx[a] = 0.f; sz[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < CI; ++b) { mx[a][b] = 0.f; mz[a][b] = 0.f; }
+  }
+  __syncthreads();
+  const int rounds = (B + gridDim.x * 4 - 1) / (gridDim.x * 4);
+  for (int r = 0; r < rounds; ++r) {              // every wave runs every round (the block barriers below are uniform)
+    const int clip = (r * gridDim.x + blockIdx.x) * 4 + wave;
+    const bool live = clip < B;
+    const float* gx = in + (size_t)(live ? clip : 0) * CI * TV;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int p = lane + 64 * k;
+      if (p < TV) {
+        float x[CI];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          x[c] = live ? act(gx[c * TV + p], pre, a_in) : 0.f;
+          Xl[c * TV + p] = x[c];
+          sx[c] += x[c];
+        }
+#pragma unroll
+        for (int a = 0; a < CI; ++a)
+#pragma unroll
+          for (int b = 0; b < CI; ++b) mx[a][b] = fmaf(x[a], x[b], mx[a][b]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int p = lane + 64 * k;
+      if (p < TV) {
+        const int q = p / V, v = p - q * V;
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          float y = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) y = fmaf(Xl[c * TV + t * V + v], TwL[(t * T + q) * V + v], y);
+          Yl[c * TV + p] = y;
+        }
+      }
+    }
+    __syncthreads();
+    float* gz = Zout + (size_t)(live ? clip : 0) * CI * TV;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int p = lane + 64 * k;
+      if (p < TV) {
+        const int t = p / V, w = p - t * V;
+        float z[CI];
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          float acc = 0.f;
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc = fmaf(Yl[c * TV + t * V + v], AwL[t * V * V + v * V + w], acc);
+          z[c] = acc;
+          if (live) gz[c * TV + p] = acc;
+          sz[c] += acc;
+        }
+#pragma unroll
+        for (int a = 0; a < CI; ++a)
+#pragma unroll
+          for (int b = 0; b < CI; ++b) mz[a][b] = fmaf(z[a], z[b], mz[a][b]);
+      }
+    }
+    __syncthreads();                              // Xl / Yl are rewritten next round
+  }
+  // lanes, then waves (fixed order) -> the block's partial row
+  constexpr int E = 2 * (CI * CI + CI);
+  float* row = TwL + NT;                          // E floats per wave, over the (now idle) X images
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < CI; ++a) {
+    const float s0 = wave_sum(sx[a]), s1 = wave_sum(sz[a]);
+    if (lane == 0) { row[wave * E + CI * CI + a] = s0; row[wave * E + 2 * CI * CI + CI + a] = s1; }
+#pragma unroll
+    for (int b = 0; b < CI; ++b) {
+      const float m0 = wave_sum(mx[a][b]), m1 = wave_sum(mz[a][b]);
+      if (lane == 0) { row[wave * E + a * CI + b] = m0; row[wave * E + CI * CI + CI + a * CI + b] = m1; }
+    }
+  }
+  __syncthreads();
+  if (tid < E) partials[(size_t)blockIdx.x * E + tid] = (row[tid] + row[E + tid]) + (row[2 * E + tid] + row[3 * E + tid]);
 }
 
 }  // namespace fl
@@ -279,6 +394,39 @@ int launch_first_bwd(const float* in, const float* Zg, const float* dU, const fl
                      const float* in_slope, float* partials, int B, int Ci, int Co, int T, int V, int max_rows, hipStream_t st,
                      int* rows_out) {
 #define CALL(T_, V_) return launch_first_bwd_tv<T_, V_>(in, Zg, dU, Aw, Tw, coef, in_slope, partials, B, Ci, Co, max_rows, st, rows_out)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+// training forward of a few-channel layer: moments + stored Z (partial rows: *rows_out, each 2 (Ci^2 + Ci) floats)
+template <int T, int V>
+static int launch_first_moments_tv(const float* in, const float* Aw, const float* Tw, const float* in_slope, float* partials, int B,
+                                   int Ci, float* Zout, int max_rows, hipStream_t st, int* rows_out) {
+  int grid = (B + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  if (grid > max_rows) grid = max_rows;
+  *rows_out = grid;
+  const size_t lds = ((size_t)T * V * V + (size_t)V * T * T + 8 * (size_t)Ci * T * V) * sizeof(float);
+#define LAUNCH_FM(CI)                                                                                                   \
+  do {                                                                                                                  \
+    auto k = fl::k_first_moments<T, V, CI>;                                                                             \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Aw, Tw, in_slope, partials, B, Zout);                      \
+  } while (0)
+  {
+    ProbeScope probe(KID_FWD_MOMENTS, Ci, 0, st);
+    if (Ci == 1) LAUNCH_FM(1);
+    else if (Ci == 2) LAUNCH_FM(2);
+    else if (Ci == 3) LAUNCH_FM(3);
+    else LAUNCH_FM(4);
+  }
+#undef LAUNCH_FM
+  return check_launch("first_moments");
+}
+
+int launch_first_moments(const float* in, const float* Aw, const float* Tw, const float* in_slope, float* partials, int B, int Ci,
+                         int T, int V, float* Zout, int max_rows, hipStream_t st, int* rows_out) {
+#define CALL(T_, V_) return launch_first_moments_tv<T_, V_>(in, Aw, Tw, in_slope, partials, B, Ci, Zout, max_rows, st, rows_out)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

@@ -217,6 +217,10 @@ static int pick_nb_rows(int rows_per_clip, int B, int LD, int budget_bytes) {
   return nb;
 }
 
+// first_layer.hip
+int launch_first_moments(const float* in, const float* Aw, const float* Tw, const float* in_slope, float* partials, int B, int Ci,
+                         int T, int V, float* Zout, int max_rows, hipStream_t st, int* rows_out);
+
 size_t train_stats_ws_bytes(int Ci) {
   const size_t E = 2 * ((size_t)Ci * Ci + Ci);
   return kMaxGrid * E * sizeof(float) + round_up((int)(E * sizeof(double)), 256) + 256;
@@ -249,6 +253,12 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + round_up((int)(kMaxGrid * (size_t)E * sizeof(float)), 256));
   const int need_x = Wr != nullptr;
   const int ntc = ceil_div(Ci, 16);
+  int rows = grid;
+  if (Zout && Ci <= 4 && TV % 4 == 0) {
+    // a handful of input channels (the first layer): plain FMAs, one clip per wave (first_layer.hip)
+    int rc1 = launch_first_moments(in, Aw, Tw, in_slope, partials, B, Ci, T, V, Zout, kMaxGrid, st, &rows);
+    if (rc1) return rc1;
+  } else {
 #define LAUNCH_M(NTC)                                                                           \
   do {                                                                                          \
     auto k = k_fwd_moments<T, V, NTC>;                                                          \
@@ -263,9 +273,10 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   else LAUNCH_M(4);
   }
 #undef LAUNCH_M
+  }
   int rc = check_launch("fwd_moments");
   if (rc) return rc;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, grid, E, red);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, rows, E, red);
   rc = check_launch("reduce_partials");
   if (rc) return rc;
   const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + 4 * (size_t)Co * Ci * sizeof(float);

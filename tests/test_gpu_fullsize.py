@@ -56,7 +56,7 @@ def test_train_step_vs_oracle_deterministic_and_permutation_invariant(setup):
     loss3, grad3, _, _ = step(x[perm])
     np.testing.assert_allclose(loss3, loss, rtol=1e-5)
     gmax = float(grad.abs().max())
-    np.testing.assert_allclose(grad3.cpu().numpy(), grad.cpu().numpy(), rtol=1e-3, atol=1e-5 * gmax)
+    np.testing.assert_allclose(grad3.cpu().numpy(), grad.cpu().numpy(), rtol=1e-3, atol=2e-5 * gmax)   # fp32 sums in another order
     # oracle: the same step with torch autograd on the CPU, in fp32 (the parity target) and in fp64 (the truth).  At this
     # size the fp32 reference itself carries summation error (gradients are sums over 4096 x 204 x C terms), so the HIP
     # gradients must be (a) within the fp32 tolerance of the fp32 oracle on the scale of each tensor and (b) no further
