@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * kBtlFwdWaves) void k_btlnk_fwd(const float* __
 // the L2 traffic of W drops to a quarter of the HBM traffic of U) x one of KS slices of K; the four waves split the
 // slice again.  Partials [KS][B][16] are summed in a fixed order by k_btlnk_fwd_sum (deterministic, no atomics).
 #ifndef BTL_KS
-#define BTL_KS 8
+#define BTL_KS 4      // sweep at B = 4096 (tools/ab_fused.sh, -DBTL_KS / -DBTL_UB): 4 x 2 -> 40.6 us, 8 x 2 -> 44.5, 16 x 2 -> 51.5, 8 x 4 -> 50
 #endif
 #ifndef BTL_UB
 #define BTL_UB 2

@@ -185,18 +185,26 @@ def test_split_backward_on_side_stream_matches(golden):
     from coskad_amd.trainer import STSETrainStep
     from oracle import ref_cpu as R
     x = R.synthetic_clips(64, seed=9).cuda()
-    flats = []
+    flats, grads = [], []
     for side in (False, True):
         st = R.init_stse_state(2, (32, 16, 32), 64, 16, 12, 17, seed=0)
         st["c"] = torch.full((16,), 0.1)
         m = STSE(2, [32, 16, 32], 64, 16, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
         m.load_state_dict(st, strict=True)
         eng = STSETrainStep(m.cuda().train(), lr=1e-3, alpha=1e-6, side_stream=side)
-        for _ in range(3):
+        eng.step(x)
+        torch.cuda.synchronize()
+        grads.append(eng.fp.grad.clone())
+        for _ in range(2):
             eng.step(x)
         torch.cuda.synchronize()
         flats.append(eng.fp.flat.clone())
-    np.testing.assert_allclose(flats[0].cpu().numpy(), flats[1].cpu().numpy(), rtol=2e-3, atol=2e-5)
+    # the gradients of the first step: equal up to fp32 summation order
+    g0, g1 = grads[0].cpu().numpy(), grads[1].cpu().numpy()
+    np.testing.assert_allclose(g0, g1, rtol=2e-3, atol=2e-5 * float(np.abs(g1).max()))
+    # three Adam steps later: Adam turns the sign noise of near-zero gradient elements into +-lr steps, so the parameters
+    # are only required to stay within the three steps' reach of each other
+    np.testing.assert_allclose(flats[0].cpu().numpy(), flats[1].cpu().numpy(), rtol=2e-3, atol=3.5e-3)
 
 
 def test_wide_stack_c256_vs_oracle():
