@@ -325,6 +325,42 @@ __global__ __launch_bounds__(256, 4) void k_first_moments(const float* __restric
   if (tid < E) partials[(size_t)blockIdx.x * E + tid] = (row[tid] + row[E + tid]) + (row[2 * E + tid] + row[3 * E + tid]);
 }
 
+// k_first_apply: U[o][p] = (sum_c Wz[c][o] Z[c][p] + Wx[c][o] X[c][p]) + b[o]  (wfold rows: Z channels, then X channels; the
+//   bias joins LAST: a folded BatchNorm bias can dwarf the result, and added first it costs a per-channel offset of an ulp of
+//   the BIAS -- tools/dbg_sens.py shows what a 1e-6 per-channel offset does to the golden model's gradients).  One clip per
+//   block round; the 2 C_in rows sit in LDS, every thread writes full float4 lines of the output.
+template <int CI>
+__global__ __launch_bounds__(256, 4) void k_first_apply(const float* __restrict__ Zg, const float* __restrict__ in,
+                                                        float* __restrict__ out, const float* __restrict__ wfold,
+                                                        const float* __restrict__ bias, const float* __restrict__ in_slope, int B,
+                                                        int Co, int CoP, int TVr) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 CI][TVr]
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const int n4 = TVr >> 2;
+  for (int clip = blockIdx.x; clip < B; clip += gridDim.x) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < CI * n4; e += 256) {
+      reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(Zg + (size_t)clip * CI * TVr)[e];
+      reinterpret_cast<float4*>(lds)[CI * n4 + e] = act4(reinterpret_cast<const float4*>(in + (size_t)clip * CI * TVr)[e], pre, a_in);
+    }
+    __syncthreads();
+    float4* go = reinterpret_cast<float4*>(out + (size_t)clip * Co * TVr);
+    for (int e = threadIdx.x; e < Co * n4; e += 256) {
+      const int o = e / n4, l = e - o * n4;
+      float4 u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2 * CI; ++c) {
+        const float w = wfold[c * CoP + o];
+        const float4 v = reinterpret_cast<const float4*>(lds)[c * n4 + l];
+        u.x = fmaf(w, v.x, u.x); u.y = fmaf(w, v.y, u.y); u.z = fmaf(w, v.z, u.z); u.w = fmaf(w, v.w, u.w);
+      }
+      const float b = bias[o];
+      go[e] = float4{u.x + b, u.y + b, u.z + b, u.w + b};
+    }
+  }
+}
+
 }  // namespace fl
 
 bool first_layer_ok(int T_, int V_, int Ci, int Co) { return Ci <= 4 && Co <= 64 && (T_ * V_) % 4 == 0; }
@@ -429,6 +465,23 @@ int launch_first_moments(const float* in, const float* Aw, const float* Tw, cons
 #define CALL(T_, V_) return launch_first_moments_tv<T_, V_>(in, Aw, Tw, in_slope, partials, B, Ci, Zout, max_rows, st, rows_out)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
+}
+
+int launch_first_apply(const float* Z, const float* in, float* out, const float* wfold, const float* bias, const float* in_slope,
+                       int B, int Ci, int Co, int TVr, hipStream_t st) {
+  const int grid = B < 2048 ? B : 2048;
+  const size_t lds = 2 * (size_t)Ci * TVr * sizeof(float);
+  const int CoP = round_up(Co, 16);
+#define LAUNCH_FAP(CI) hipLaunchKernelGGL((fl::k_first_apply<CI>), dim3(grid), dim3(256), lds, st, Z, in, out, wfold, bias, in_slope, B, Co, CoP, TVr)
+  {
+    ProbeScope probe(KID_LAYER_APPLY, Ci, Co, st);
+    if (Ci == 1) LAUNCH_FAP(1);
+    else if (Ci == 2) LAUNCH_FAP(2);
+    else if (Ci == 3) LAUNCH_FAP(3);
+    else LAUNCH_FAP(4);
+  }
+#undef LAUNCH_FAP
+  return check_launch("first_apply");
 }
 
 }  // namespace coskad

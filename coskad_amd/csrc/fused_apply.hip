@@ -87,12 +87,15 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_ring(const float* __rest
       // group 0 (fetched a phase ago) goes to the window, group 1 takes its registers
 #pragma unroll
       for (int q = 0; q < 4; ++q) { qstore(q, false); kq(1, q); }
-      f32x4 acc[NTILE][OTP];
+      // the bias joins the finished sums (added first, a folded BatchNorm bias much larger than the result would cost every
+      // partial sum an ulp of the BIAS: a per-channel offset, the kind of error tools/dbg_sens.py shows the model amplifies)
+      f32x4 acc[NTILE][OTP], bq[OTP];
 #pragma unroll
       for (int ot = 0; ot < OTP; ++ot) {
-        const float4 bq = buf_load4(bres, L.q * 16, (16 * (p * OTP + ot)) * 4);
+        const float4 b4 = buf_load4(bres, L.q * 16, (16 * (p * OTP + ot)) * 4);
+        bq[ot] = f32x4{b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) acc[t][ot] = f32x4{bq.x, bq.y, bq.z, bq.w};
+        for (int t = 0; t < NTILE; ++t) acc[t][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       const int lq = (L.q * CoP + L.j) * 4;
       float wc[2][4][OTP];
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_ring(const float* __rest
         for (int t = 0; t < NTILE; ++t)
 #pragma unroll
           for (int o2 = 0; o2 < 2; ++o2)
-            if (o2 < nt) tile_store(r1, 16 * o2, t < T ? t * V + L.j : jc * V + 16, t < T || L.j < T, acc[t][2 * h + o2], L);
+            if (o2 < nt) tile_store(r1, 16 * o2, t < T ? t * V + L.j : jc * V + 16, t < T || L.j < T, acc[t][2 * h + o2] + bq[2 * h + o2], L);
         const int n4 = 16 * nt * (TV / 4);
         const int ch0 = 16 * (p * OTP + 2 * h);                    // first output channel of this flush
         const int ln = olane();

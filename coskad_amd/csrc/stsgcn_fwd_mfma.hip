@@ -246,6 +246,9 @@ namespace coskad {
 bool layer_apply_ring_ok(int T_, int V_, int Ci, int Co);
 int launch_layer_apply_ring(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
                             const float* in_slope, int B, int Ci, int Co, hipStream_t st);
+// first_layer.hip
+int launch_first_apply(const float* Z, const float* in, float* out, const float* wfold, const float* bias, const float* in_slope,
+                       int B, int Ci, int Co, int TVr, hipStream_t st);
 }  // namespace coskad
 
 using namespace coskad;
@@ -255,6 +258,8 @@ extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* 
                                         hipStream_t stream) {
   if (!Z || !in || !out || !A || !Tm || !wfold || !bias) return fail(COSKAD_ERR_ARG, "layer_apply_z: null pointer");
   if (B <= 0 || Ci <= 0 || Co <= 0 || Co > 64 || Ci > 64) return fail(COSKAD_ERR_ARG, "layer_apply_z: B=%d Ci=%d Co=%d", B, Ci, Co);
+  // a handful of input channels (the first layer): plain FMAs on full-line stores (first_layer.hip)
+  if (!out_slope && Ci <= 4 && (T * V) % 4 == 0) return launch_first_apply(Z, in, out, wfold, bias, in_slope, B, Ci, Co, T * V, stream);
   // default geometry, 16 / 32 input channels, pre-activation output: the wave-per-clip K-ring GEMM (fused_apply.hip)
   if (!out_slope && layer_apply_ring_ok(T, V, Ci, Co)) return launch_layer_apply_ring(Z, in, out, wfold, bias, in_slope, B, Ci, Co, stream);
   // <= 32 output channels: streaming GEMM over Z and `in`; wider: the LDS-tiled kernel with Z staged instead of mixed
