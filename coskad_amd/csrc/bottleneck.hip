@@ -289,9 +289,15 @@ __global__ __launch_bounds__(256) void k_btlnk_reduce(const float* __restrict__ 
   }
 }
 
-static int btl_chunks(int B) {
-  int s = ceil_div(B, 256);
-  return s < 1 ? 1 : (s > 16 ? 16 : s);
+// Clip chunks of the backward grid: (column blocks) x (chunks) ~ 1024 = four 4-wave blocks per CU, all resident at once
+// (sweep at B = 4096, K = 13 056: 51 x 16 blocks 140 us, 51 x 20 = 1020 blocks 123 us, 51 x 24 138 us, 51 x 32 135 us)
+static int btl_chunks(int B, int K) {
+  const int gx = ceil_div(K, 256);
+  int s = (1024 + gx / 2) / gx;
+  const int smax = ceil_div(B, 16);      // at least one 16-clip tile per chunk
+  if (s > smax) s = smax;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
 }
 
 }  // namespace coskad
@@ -330,7 +336,7 @@ int coskad_btlnk_fwd_ws_f32(const float* U, const float* W, const float* bias, c
 }
 
 size_t coskad_btlnk_bwd_ws_bytes(int B, int K, int L) {
-  const int S = btl_chunks(B);
+  const int S = btl_chunks(B, K);
   return ((size_t)S * L * K + (size_t)S * ceil_div(K, 256) + 64) * sizeof(float);
 }
 
@@ -343,7 +349,7 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
   if (L > 16) return fail(COSKAD_ERR_SHAPE, "btlnk_bwd: latent_dim=%d > 16 not supported", L);
   if (K % 4) return fail(COSKAD_ERR_SHAPE, "btlnk_bwd: K=%d must be a multiple of 4", K);
   if (ws_bytes < coskad_btlnk_bwd_ws_bytes(B, K, L)) return fail(COSKAD_ERR_WORKSPACE, "btlnk_bwd: workspace too small");
-  const int S = btl_chunks(B);
+  const int S = btl_chunks(B, K);
   const int chunk = round_up(ceil_div(B, S), 16);
   const int gx = ceil_div(K, 256);
   float* dWp = reinterpret_cast<float*>(ws);
