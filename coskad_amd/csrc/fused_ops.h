@@ -10,7 +10,10 @@ namespace ff {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int T = 12, V = 17, TV = T * V;
-constexpr int LD = 206;                 // row stride: = 2 (mod 4) -> (row, k) operand reads of the mixing phases are conflict-free
+#ifndef FF_LD
+#define FF_LD 206
+#endif
+constexpr int LD = FF_LD;               // row stride: = 2 (mod 4) -> (row, k) operand reads of the mixing phases are conflict-free
 constexpr int R1 = 0, R2 = 32 * LD;     // float offsets inside the wave's LDS image
 constexpr int PADCOL = TV;              // columns 204, 205 of every row are padding: masked lanes store there (no divergent branches)
 constexpr int WAVE_LDS = 48 * LD;       // floats per wave
