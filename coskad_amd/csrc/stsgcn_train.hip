@@ -226,6 +226,23 @@ size_t train_stats_ws_bytes(int Ci) {
   return kMaxGrid * E * sizeof(float) + round_up((int)(E * sizeof(double)), 256) + 256;
 }
 
+// moment partials [rows][2 (Ci^2 + Ci)] -> fp64 sums (fixed order) -> statistics, folded weights, running-stat update
+static int launch_reduce_fold(const float* partials, int rows, double* red, double npos, const float* Wt, const float* bt,
+                              const float* gs, const float* bs, float* rm_s, float* rv_s, long long* nbt_s, const float* Wr,
+                              const float* br, const float* gr, const float* brr, float* rm_r, float* rv_r, long long* nbt_r,
+                              float momentum, float* wfold, float* bias, float* stat, int Ci, int Co, hipStream_t st) {
+  const int E = 2 * (Ci * Ci + Ci);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, rows, E, red);
+  int rc = check_launch("reduce_partials");
+  if (rc) return rc;
+  const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + 4 * (size_t)Co * Ci * sizeof(float);
+  if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_train_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
+  hipLaunchKernelGGL(k_train_fold, dim3(1), dim3(1024), fold_lds, st, red, npos, Wt, bt, gs, bs, rm_s,
+                     rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r, nbt_r, momentum, wfold, bias, stat, Ci,
+                     Co, round_up(Co, 16));
+  return check_launch("train_fold");
+}
+
 template <int T, int V>
 static int launch_train_stats(const float* in, const float* Aw, const float* Tw, const float* in_slope,
                               const float* Wt, const float* bt, const float* gs, const float* bs,
@@ -276,15 +293,8 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   }
   int rc = check_launch("fwd_moments");
   if (rc) return rc;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, rows, E, red);
-  rc = check_launch("reduce_partials");
-  if (rc) return rc;
-  const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + 4 * (size_t)Co * Ci * sizeof(float);
-  if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_train_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
-  hipLaunchKernelGGL(k_train_fold, dim3(1), dim3(1024), fold_lds, st, red, (double)B * TV, Wt, bt, gs, bs, rm_s,
-                     rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r, nbt_r, momentum, wfold, bias, stat, Ci,
-                     Co, round_up(Co, 16));
-  return check_launch("train_fold");
+  return launch_reduce_fold(partials, rows, red, (double)B * TV, Wt, bt, gs, bs, rm_s, rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r,
+                            nbt_r, momentum, wfold, bias, stat, Ci, Co, st);
 }
 
 }  // namespace coskad
@@ -337,6 +347,27 @@ int coskad_layer_train_stats_z_f32(const float* in, const float* A, const float*
                                     bias, stat, ws, ws_bytes, B, Ci, Co, stream, Z)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
+}
+
+/* Statistics of a layer whose moment partials were produced by the PREVIOUS layer's coskad_layer_apply_next_f32:
+ * partials [rows][2 (Ci^2 + Ci)] -> fold.  ws: >= coskad_train_stats_ws_bytes(Ci) (the fp64 sums live behind the
+ * partial area, as in coskad_layer_train_stats_f32). */
+int coskad_layer_train_fold_f32(const float* partials, int rows, const float* Wt, const float* bt, const float* gamma_t,
+                                const float* beta_t, float* rmean_t, float* rvar_t, long long* nbt_t,
+                                const float* Wr, const float* br, const float* gamma_r,
+                                const float* beta_r, float* rmean_r, float* rvar_r, long long* nbt_r,
+                                float momentum, float* wfold, float* bias, float* stat, void* ws,
+                                size_t ws_bytes, int B, int Ci, int Co, int T, int V, hipStream_t stream) {
+  if (!partials || !Wt || !gamma_t || !beta_t || !wfold || !bias || !stat || !ws)
+    return fail(COSKAD_ERR_ARG, "layer_train_fold: null pointer");
+  if (Wr && (!gamma_r || !beta_r)) return fail(COSKAD_ERR_ARG, "layer_train_fold: residual BN missing");
+  if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_train_fold: identity residual needs Ci == Co");
+  if (B <= 0 || Ci <= 0 || Co <= 0 || Ci > 64 || rows <= 0) return fail(COSKAD_ERR_ARG, "layer_train_fold: B=%d Ci=%d Co=%d rows=%d", B, Ci, Co, rows);
+  const size_t E = 2 * ((size_t)Ci * Ci + Ci);
+  if (ws_bytes < round_up((int)(E * sizeof(double)), 256)) return fail(COSKAD_ERR_WORKSPACE, "layer_train_fold: workspace %zu too small", ws_bytes);
+  return launch_reduce_fold(partials, rows, reinterpret_cast<double*>(ws), (double)B * T * V, Wt, bt, gamma_t, beta_t, rmean_t,
+                            rvar_t, nbt_t, Wr, br, gamma_r, beta_r, rmean_r, rvar_r, nbt_r, momentum, wfold, bias, stat, Ci, Co,
+                            stream);
 }
 
 }  // extern "C"

@@ -117,7 +117,22 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
     B, C, T, V = x.shape
     ctx = ChainCtx(in_slope=in_slope) if want_ctx else None
     h, slope = x, in_slope
-    for L in layers:
+    n = len(layers)
+    # fuse[i]: layer i's apply kernel also forms layer i+1's Z and moment partials (csrc/fused_apply_next.hip), so
+    # layer i+1 needs no statistics pass of its own
+    fuse = [False] * n
+    ftab = None
+    if training and STORE_Z and FUSE_NEXT:
+        for i in range(n - 1):
+            fuse[i] = layers[i + 1].Ci == layers[i].Co and ops.layer_apply_next_ok(layers[i].Ci, layers[i].Co, T, V)
+        nxt = [i + 1 for i in range(n - 1) if fuse[i]]
+        if nxt:
+            ftab = torch.empty(n, ops.ftab_floats(), device=x.device, dtype=torch.float32)
+            for k in range(0, len(nxt), 4):
+                grp = nxt[k:k + 4]
+                ops.build_ftabs([layers[i].A for i in grp], [layers[i].T for i in grp], [ftab[i] for i in grp])
+    pending = None              # (Z, partials, rows) of THIS layer, written by the previous layer's apply
+    for i, L in enumerate(layers):
         if h.shape[1] != L.Ci:
             raise ValueError(f"layer expects {L.Ci} input channels, got {h.shape[1]}")
         Z = None
@@ -126,11 +141,17 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
                 L.cache.clear()   # running stats (and, after the optimiser, the weights) change through raw-pointer kernels
                                   # that do not bump torch's version counters: drop the eval-mode fold
             buf = ws.get(ops.train_stats_ws_bytes(L.Ci), x.device)
-            if STORE_Z:
-                Z = torch.empty_like(h)     # gcn(PReLU(h)): written by the statistics pass, read by everything after
-            wfold, bias, stat = ops.layer_train_stats(
-                h, L.A, L.T, slope, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
-                L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum, Z=Z)
+            if pending is not None:
+                Z, partials, rows = pending
+                wfold, bias, stat = ops.layer_train_fold(
+                    partials, rows, B, T, V, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
+                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum)
+            else:
+                if STORE_Z:
+                    Z = torch.empty_like(h)     # gcn(PReLU(h)): written by the statistics pass, read by everything after
+                wfold, bias, stat = ops.layer_train_stats(
+                    h, L.A, L.T, slope, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
+                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum, Z=Z)
         else:
             key = L.fold_key() if L.cache is not None else None
             if key is not None and L.cache.get("key") == key:
@@ -141,7 +162,13 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
                 if key is not None:
                     L.cache["key"], L.cache["fold"] = key, (wfold, bias)
             stat = None
-        if Z is not None:
+        pending = None
+        if fuse[i]:
+            rows_max = min((B + 3) // 4, 256)
+            partials = torch.empty(rows_max * 2 * (L.Co * L.Co + L.Co), device=x.device, dtype=torch.float32)
+            u, Zn, rows = ops.layer_apply_next(Z, h, wfold, bias, L.Co, slope, L.slope, ftab[i + 1], partials, T, V)
+            pending = (Zn, partials, rows)
+        elif Z is not None:
             u = ops.layer_apply_z(Z, h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)
         else:
             u = ops.layer_apply(h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)
@@ -156,6 +183,9 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
 # training forward keeps Z = gcn(X) of every layer (82 channels x 816 B per clip) instead of recomputing the mixing in the
 # apply and backward kernels.  A module constant, not an environment switch: tests flip it to cover the recompute path.
 STORE_Z = True
+# with the stored-Z path: layer i's apply kernel also produces layer i+1's Z and BatchNorm moment partials where
+# csrc/fused_apply_next.hip takes the shape (tests flip it to cover the separate statistics pass)
+FUSE_NEXT = True
 
 
 class SideStream:

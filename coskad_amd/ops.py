@@ -36,6 +36,10 @@ def _chk(t: Optional[Tensor], name: str, shape=None, dtype=torch.float32, option
         raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
 
 
+def _bytes(t: Tensor) -> int:
+    return t.numel() * t.element_size()
+
+
 def cop(co: int) -> int:
     return (co + 15) // 16 * 16
 
@@ -147,6 +151,80 @@ def layer_apply_z(Z, x, A, Tm, wfold, bias, Co, in_slope=None, out_slope=None, o
     return out
 
 
+def layer_apply_next_ok(Ci: int, Co: int, T: int, V: int) -> bool:
+    """Does csrc/fused_apply_next.hip take a (Ci -> Co) layer (apply + the next layer's statistics in one kernel)?"""
+    fn = _lib.lib().coskad_layer_apply_next_ok
+    fn.restype = ctypes.c_int
+    return bool(fn(i32(Ci), i32(Co), i32(T), i32(V)))
+
+
+def ftab_floats() -> int:
+    fn = _lib.lib().coskad_ftab_floats
+    fn.restype = ctypes.c_int
+    return fn()
+
+
+def build_ftabs(As, Ts, tabs) -> None:
+    """Forward mixing tables of up to 4 layers (lists of A [T,V,V], T [V,T,T], tab [ftab_floats()]) in one launch."""
+    n = len(As)
+    if not (1 <= n <= 4) or len(Ts) != n or len(tabs) != n:
+        raise ValueError("build_ftabs: 1..4 layers, equal list lengths")
+    T, V = As[0].shape[0], As[0].shape[1]
+    nf = ftab_floats()
+    for A, Tm, tab in zip(As, Ts, tabs):
+        _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T)); _chk(tab, "tab", (nf,))
+    arr = ctypes.c_void_p * n
+    call("coskad_build_ftab_f32", arr(*[t.data_ptr() for t in As]), arr(*[t.data_ptr() for t in Ts]),
+         arr(*[t.data_ptr() for t in tabs]), i32(n), i32(T), i32(V), _stream())
+
+
+def layer_apply_next(Z, x, wfold, bias, Co, in_slope, out_slope, ftab_next, partials, T, V, out=None, Z_next=None):
+    """U = Wz.Z + Wx.PReLU(x) + b  AND  the next layer's Z_next = gcn_next(PReLU_out(U)) + its moment partials
+    (csrc/fused_apply_next.hip).  -> (U, Z_next, rows): `rows` partial rows of 2 (Co^2 + Co) floats were written."""
+    B, Ci = x.shape[0], x.shape[1]
+    _chk(x, "x", (B, Ci, T, V)); _chk(Z, "Z", (B, Ci, T, V)); _chk(wfold, "wfold", (2 * Ci, cop(Co))); _chk(bias, "bias", (cop(Co),))
+    _chk(in_slope, "in_slope", (1,), optional=True); _chk(out_slope, "out_slope", (1,)); _chk(ftab_next, "ftab_next", (ftab_floats(),))
+    _chk(partials, "partials")
+    if out is None:
+        out = torch.empty(B, Co, T, V, device=x.device, dtype=torch.float32)
+    if Z_next is None:
+        Z_next = torch.empty(B, Co, T, V, device=x.device, dtype=torch.float32)
+    _chk(out, "out", (B, Co, T, V)); _chk(Z_next, "Z_next", (B, Co, T, V))
+    fn = _lib.lib().coskad_layer_apply_next_rows
+    fn.restype = ctypes.c_int
+    rows = fn(i32(B))
+    call("coskad_layer_apply_next_f32", ptr(Z), ptr(x), ptr(out), ptr(wfold), ptr(bias), ptr(in_slope), ptr(out_slope),
+         ptr(ftab_next), ptr(Z_next), ptr(partials), ctypes.c_size_t(_bytes(partials)), i32(B), i32(Ci), i32(Co), i32(T), i32(V),
+         _stream(), tag=(Ci, Co))
+    return out, Z_next, rows
+
+
+def layer_train_fold(partials, rows, B, T, V, Wt, bt, gt, bet, rm_t, rv_t, nbt_t, Wr, br, gr, ber, rm_r, rv_r, nbt_r, ws,
+                     momentum: float = 0.1):
+    """The statistics of a layer from moment partials a previous layer_apply_next wrote -> (wfold, bias, stat)."""
+    Co, Ci = Wt.shape
+    _chk(partials, "partials"); _chk(Wt, "Wt", (Co, Ci)); _chk(gt, "gamma_t", (Co,)); _chk(bet, "beta_t", (Co,))
+    for n, t in (("bt", bt), ("rm_t", rm_t), ("rv_t", rv_t), ("br", br), ("gamma_r", gr), ("beta_r", ber),
+                 ("rm_r", rm_r), ("rv_r", rv_r)):
+        _chk(t, n, (Co,), optional=True)
+    _chk(Wr, "Wr", (Co, Ci), optional=True)
+    _chk(nbt_t, "nbt_t", (), dtype=torch.int64, optional=True)
+    _chk(nbt_r, "nbt_r", (), dtype=torch.int64, optional=True)
+    if partials.numel() < rows * 2 * (Ci * Ci + Ci):
+        raise ValueError("layer_train_fold: partials smaller than rows x 2 (Ci^2 + Ci)")
+    need = train_stats_ws_bytes(Ci)
+    if ws is None or _bytes(ws) < need:
+        raise ValueError(f"workspace too small: need {need} bytes")
+    wfold = torch.empty(2 * Ci, cop(Co), device=Wt.device, dtype=torch.float32)
+    bias = torch.empty(cop(Co), device=Wt.device, dtype=torch.float32)
+    stat = torch.empty(stat_floats(Ci, Co), device=Wt.device, dtype=torch.float32)
+    call("coskad_layer_train_fold_f32", ptr(partials), i32(rows), ptr(Wt), ptr(bt), ptr(gt), ptr(bet), ptr(rm_t), ptr(rv_t),
+         ptr(nbt_t), ptr(Wr), ptr(br), ptr(gr), ptr(ber), ptr(rm_r), ptr(rv_r), ptr(nbt_r), ctypes.c_float(momentum),
+         ptr(wfold), ptr(bias), ptr(stat), ptr(ws), ctypes.c_size_t(_bytes(ws)), i32(B), i32(Ci), i32(Co), i32(T), i32(V),
+         _stream())
+    return wfold, bias, stat
+
+
 def gather(src: Tensor, idx: Tensor) -> Tensor:
     """out[i] = src[idx[i]] (0 where idx < 0): operand streams of the fused encoder from the concatenated parameters."""
     _chk(src, "src"); _chk(idx, "idx", dtype=torch.int32)
@@ -175,10 +253,6 @@ def fused_encoder(x: Tensor, tab: Tensor, wreg: Tensor, slopes: Tensor, out: Opt
         _chk(out, "out", (B, kp))
     call("coskad_fused_encoder_f32", ptr(x), ptr(out), ptr(tab), ptr(wreg), ptr(slopes), i32(B), i32(T), i32(V), _stream())
     return out
-
-
-def _bytes(t: Tensor) -> int:
-    return t.numel() * t.element_size()
 
 
 def layer_bwd_ws_bytes(B, Ci, Co, T, V) -> int:

@@ -95,6 +95,32 @@ int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const 
                              const float* wfold, const float* bias, const float* in_slope, const float* out_slope,
                              int B, int Ci, int Co, int T, int V, hipStream_t stream);
 
+/* ---- training forward with the NEXT layer's statistics fused into the apply kernel (csrc/fused_apply_next.hip) --------
+ * Layer i's apply holds a clip's whole U_i on chip; for T = 12, V = 17, C_in in {2, 16, 32}, C_out in {16, 32} it also forms
+ * X_{i+1} = PReLU_i(U_i), Z_{i+1} = gcn_{i+1}(X_{i+1}) (stsgcn.py:154-155 of the next layer) and the moment partials
+ * [sum x x^T | sum x | sum z z^T | sum z] that layer i+1's BatchNorms need (stsgcn.py:65,76), so the statistics pass of
+ * layer i+1 (coskad_layer_train_stats_z_f32's first kernel) and its re-read of U_i disappear.
+ *   coskad_build_ftab_f32       : forward mixing tables (coskad_ftab_floats() floats each) of n <= 4 layers from their A / T
+ *                                 (host arrays of n device pointers), one launch
+ *   coskad_layer_apply_next_f32 : out = U_i [B,Co,T,V]; Z_next [B,Co,T,V]; partials [coskad_layer_apply_next_rows(B)][2 (Co^2 + Co)]
+ *   coskad_layer_train_fold_f32 : the rest of coskad_layer_train_stats_f32 for layer i+1 (fp64 sums of the partial rows, statistics,
+ *                                 folded weights, stat block, running-stat update); ws >= coskad_train_stats_ws_bytes(Ci). */
+int coskad_layer_apply_next_ok(int Ci, int Co, int T, int V);
+int coskad_ftab_floats(void);
+int coskad_layer_apply_next_rows(int B);
+int coskad_build_ftab_f32(const float* const* A, const float* const* Tm, float* const* tab, int n, int T, int V,
+                          hipStream_t stream);
+int coskad_layer_apply_next_f32(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
+                                const float* in_slope, const float* out_slope, const float* ftab_next, float* Z_next,
+                                float* partials, size_t partials_bytes, int B, int Ci, int Co, int T, int V,
+                                hipStream_t stream);
+int coskad_layer_train_fold_f32(const float* partials, int rows, const float* Wt, const float* bt, const float* gamma_t,
+                                const float* beta_t, float* rmean_t, float* rvar_t, long long* nbt_t,
+                                const float* Wr, const float* br, const float* gamma_r,
+                                const float* beta_r, float* rmean_r, float* rvar_r, long long* nbt_r,
+                                float momentum, float* wfold, float* bias, float* stat, void* ws,
+                                size_t ws_bytes, int B, int Ci, int Co, int T, int V, hipStream_t stream);
+
 /* ---- fused eval-mode encoder (models/common/components.py:94-105 in one kernel) ------------------------------
  * Built for the reference's default geometry: n_frames 12, n_joints 17, channels 2-32-16-32-64.
  * coskad_gather_f32 : out[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- builds the operand streams (coskad_amd/fused_plan.py

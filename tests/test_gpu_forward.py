@@ -164,3 +164,104 @@ def test_apply_ring_ragged_batch_vs_recompute_kernel(Ci, Co, B):
     assert bool((buf[:guard] == 12345.0).all()) and bool((buf[guard + n:] == 12345.0).all()), "wrote outside the output"
     ref = ops.layer_apply(x, A, Tm, wfold, bias, Co, in_slope=sl)
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def _rand_layer(g, Ci, Co, T=12, V=17):
+    """random parameters of one ST_GCNN layer (conv weights, BN affine, mixing matrices) on the device"""
+    d = {"A": ((torch.rand(T, V, V, generator=g) * 2 - 1) / V ** 0.5).cuda(),
+         "T": ((torch.rand(V, T, T, generator=g) * 2 - 1) / T ** 0.5).cuda(),
+         "Wt": (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).cuda(), "Wr": (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).cuda(),
+         "gt": (torch.rand(Co, generator=g) + 0.5).cuda(), "gr": (torch.rand(Co, generator=g) + 0.5).cuda(),
+         "bet": (torch.randn(Co, generator=g) * 0.1).cuda(), "ber": (torch.randn(Co, generator=g) * 0.1).cuda(),
+         "slope": torch.tensor([0.1 + 0.3 * float(torch.rand(1, generator=g))], device="cuda")}
+    return d
+
+
+def _bn_bufs(Co):
+    return [torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda"),
+            torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")]
+
+
+@pytest.mark.parametrize("Ci,Co,Cn,B", [(2, 32, 16, 1031), (32, 16, 32, 1026), (16, 32, 64, 2053), (16, 16, 16, 7), (32, 32, 16, 5),
+                                        (2, 16, 32, 3), (32, 16, 32, 1)])
+def test_apply_next_vs_separate_kernels(Ci, Co, Cn, B):
+    """csrc/fused_apply_next.hip (layer i's apply + layer i+1's Z and BatchNorm moments in one wave-per-clip kernel, several
+    clips per wave, ragged last round) against the separate kernels of the same library: U_i, Z_{i+1}, and everything the
+    fold makes of the moment partials (folded weights, stat block, running statistics).  Outputs sit in guarded buffers."""
+    from coskad_amd import ops
+    T, V = 12, 17
+    g = torch.Generator().manual_seed(Ci * 131 + Co * 7 + Cn + B)
+    x = torch.randn(B, Ci, T, V, generator=g).cuda()
+    L1, L2 = _rand_layer(g, Ci, Co), _rand_layer(g, Co, Cn)
+    sl_in = torch.tensor([0.2], device="cuda") if Ci > 2 else None
+    zero1 = torch.zeros(Co, device="cuda")
+    ws = torch.empty(ops.train_stats_ws_bytes(64), dtype=torch.uint8, device="cuda")
+    Z = torch.empty_like(x)
+    b1 = _bn_bufs(Co)
+    wfold, bias, _ = ops.layer_train_stats(x, L1["A"], L1["T"], sl_in, L1["Wt"], zero1.clone(), L1["gt"], L1["bet"], b1[0], b1[1], b1[2],
+                                           L1["Wr"], zero1.clone(), L1["gr"], L1["ber"], b1[3], b1[4], b1[5], ws, Z=Z)
+    # separate kernels: apply, then the next layer's statistics pass over U
+    U_ref = ops.layer_apply_z(Z, x, L1["A"], L1["T"], wfold, bias, Co, in_slope=sl_in)
+    zero2 = torch.zeros(Cn, device="cuda")
+    Z2_ref = torch.empty_like(U_ref)
+    br = _bn_bufs(Cn)
+    ref = ops.layer_train_stats(U_ref, L2["A"], L2["T"], L1["slope"], L2["Wt"], zero2.clone(), L2["gt"], L2["bet"], br[0], br[1], br[2],
+                                L2["Wr"], zero2.clone(), L2["gr"], L2["ber"], br[3], br[4], br[5], ws, Z=Z2_ref)
+    # fused kernel
+    ftab = torch.empty(ops.ftab_floats(), device="cuda")
+    ops.build_ftabs([L2["A"]], [L2["T"]], [ftab])
+    n, guard = B * Co * T * V, 4096
+    bufU = torch.full((n + 2 * guard,), 12345.0, device="cuda")
+    bufZ = torch.full((n + 2 * guard,), 12345.0, device="cuda")
+    rows_max = min((B + 3) // 4, 256)
+    E = 2 * (Co * Co + Co)
+    bufP = torch.full((rows_max * E + 2 * guard,), 12345.0, device="cuda")
+    U, Z2, partials = bufU[guard:guard + n].view(B, Co, T, V), bufZ[guard:guard + n].view(B, Co, T, V), bufP[guard:guard + rows_max * E]
+    _, _, rows = ops.layer_apply_next(Z, x, wfold, bias, Co, sl_in, L1["slope"], ftab, partials, T, V, out=U, Z_next=Z2)
+    bf = _bn_bufs(Cn)
+    got = ops.layer_train_fold(partials, rows, B, T, V, L2["Wt"], zero2.clone(), L2["gt"], L2["bet"], bf[0], bf[1], bf[2],
+                               L2["Wr"], zero2.clone(), L2["gr"], L2["ber"], bf[3], bf[4], bf[5], ws)
+    torch.cuda.synchronize()
+    for name, b, m in (("U", bufU, n), ("Z", bufZ, n), ("partials", bufP, rows_max * E)):
+        assert bool((b[:guard] == 12345.0).all()) and bool((b[guard + m:] == 12345.0).all()), f"wrote outside {name}"
+    assert rows == rows_max
+    np.testing.assert_allclose(U.cpu().numpy(), U_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(Z2.cpu().numpy(), Z2_ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    for name, a, r in zip(("wfold", "bias", "stat"), got, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
+    for i, (a, r) in enumerate(zip(bf, br)):
+        np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=f"bn buffer {i}")
+
+
+@pytest.mark.parametrize("name,B", [("stse_default.npz", 0), ("stse_default.npz", 203)])
+def test_chain_forward_fused_next_vs_separate(golden, name, B):
+    """engine.chain_forward in training mode with the next-layer statistics fused into the apply kernels (default) against the
+    same chain with a statistics pass per layer: activations, stat blocks, stored Z and BatchNorm buffers."""
+    from coskad_amd import engine
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.models.graph_layers.stsgcn import layer_tensors
+    g = golden(name)
+    st = state_from(g)
+    x = torch.from_numpy(g["x"]) if B == 0 else R.synthetic_clips(B, seed=9)
+    res = []
+    for fuse in (True, False):
+        m = STSE(2, [32, 16, 32], 64, 16, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+        m.load_state_dict(st, strict=True)
+        m.cuda().train()
+        layers = [layer_tensors(l) for l in m.encoder.model]
+        old = engine.FUSE_NEXT
+        engine.FUSE_NEXT = fuse
+        try:
+            u, ctx = engine.chain_forward(x.cuda(), layers, True, engine.Workspace(), want_ctx=True)
+        finally:
+            engine.FUSE_NEXT = old
+        torch.cuda.synchronize()
+        res.append((u, ctx, {k: v.clone() for k, v in m.state_dict().items()}))
+    (u1, c1, s1), (u0, c0, s0) = res
+    np.testing.assert_allclose(u1.cpu().numpy(), u0.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    for i in range(4):
+        np.testing.assert_allclose(c1.inputs[i].cpu().numpy(), c0.inputs[i].cpu().numpy(), rtol=1e-4, atol=1e-4, err_msg=f"input {i}")
+        np.testing.assert_allclose(c1.zs[i].cpu().numpy(), c0.zs[i].cpu().numpy(), rtol=1e-4, atol=1e-4, err_msg=f"Z {i}")
+        np.testing.assert_allclose(c1.stats[i].cpu().numpy(), c0.stats[i].cpu().numpy(), rtol=1e-3, atol=1e-4, err_msg=f"stat {i}")
+    for k in s0:
+        np.testing.assert_allclose(s1[k].cpu().numpy(), s0[k].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
