@@ -14,6 +14,10 @@
 // k_first_apply / k_layer_apply_ring of layers 1..3 at T = 12, V = 17, <= 32 output channels.
 #include "fused_ops.h"
 
+#ifndef FN_ABLATE
+#define FN_ABLATE 0   // timing-only builds (tools/bench_apply_next.py): bit 0 U rows, 1 Gram x, 2 temporal, 3 spatial, 4 Z rows, 5 Gram z, 6 GEMM
+#endif
+
 namespace coskad {
 namespace fn {
 
@@ -281,14 +285,14 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_next(const float* __rest
     TTab tt;
     load_ttab(tt, tabres, 0, l16);
     // ---- U -> HBM; X_next = PReLU(U) back into the image; sum x x^T ---------------------------------------------------------
-    rows_out(ores, true);
-    gram(gx, sx);
+    if (!(FN_ABLATE & 1)) rows_out(ores, true);
+    if (!(FN_ABLATE & 2)) gram(gx, sx);
     // ---- Z_next = gcn_next(X_next) in place: temporal per joint, spatial per frame (operands of frame t+1 are read before
     // the tiles of frame t are written) --------------------------------------------------------------------------------------
     L = geo();
-    temporal_phase<16, OTP>(r1, tt, L);
+    if (!(FN_ABLATE & 4)) temporal_phase<16, OTP>(r1, tt, L);
     L = geo();
-    {
+    if (!(FN_ABLATE & 8)) {
       SpatRec rec = load_spat(tabres, 0, 0, l16);
       SOp op[OTP];
 #pragma unroll
@@ -312,8 +316,8 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_next(const float* __rest
       }
     }
     // ---- Z_next -> HBM; sum z z^T ------------------------------------------------------------------------------------------
-    rows_out(zores, false);
-    gram(gz, sz);
+    if (!(FN_ABLATE & 16)) rows_out(zores, false);
+    if (!(FN_ABLATE & 32)) gram(gz, sz);
   }
 
   // ---- block sum: the waves add their tiles into one LDS row one after another (fixed order), then the row leaves ------------

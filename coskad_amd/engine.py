@@ -283,18 +283,21 @@ class FusedEncoderPlan:
                                  (FP.tab_index(latent), FP.wreg_index(latent), FP.wb_index(latent)))
         return self._idx[k]
 
-    def get(self, layers: List[LayerTensors], W: Tensor, ver_extra=()):
+    def get(self, layers: List[LayerTensors], W, ver_extra=()):
+        """W: the weight [L, hid*T*V] the tile-major output is multiplied with, or a tuple of such weights stacked along
+        their rows (the VAE's mean / concentration heads share one pass)."""
+        Ws = tuple(W) if isinstance(W, (tuple, list)) else (W,)
         key = tuple(L.fold_key() for L in layers) + tuple((t.data_ptr(), t._version) for L in layers for t in (L.A, L.T, L.slope)) \
-            + ((W.data_ptr(), W._version),) + tuple(ver_extra)
+            + tuple((w.data_ptr(), w._version) for w in Ws) + tuple(ver_extra)
         if self.key == key and self.token is not None and all(L.cache is not None and L.cache.get("fused") is self.token for L in layers):
             return self
         from . import fused_plan as FP
-        latent = W.shape[0]
+        latent = sum(w.shape[0] for w in Ws)
         parts = []
         for L in layers:
             wfold, bias = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
             parts += [L.A.detach().reshape(-1), L.T.detach().reshape(-1), wfold.reshape(-1), bias.reshape(-1)]
-        parts.append(W.detach().reshape(-1))
+        parts += [w.detach().reshape(-1) for w in Ws]
         src = torch.cat(parts)
         assert src.numel() == FP.src_layout(latent).total
         ti, wi, bi = self._indices(latent, src.device)

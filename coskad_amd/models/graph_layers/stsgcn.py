@@ -21,6 +21,26 @@ _FITS: dict = {}      # (Ci, Co, T, V) -> the tile kernels take the layer (coska
 WIDE_CHANNELS = 64   # widest layer the fused tile kernels take (csrc: `channels > 64 not supported`)
 
 
+def layer_fits(Ci: int, Co: int, T: int, V: int) -> bool:
+    """Host arithmetic of `coskad_layer_fits` (csrc/stsgcn_bwd.hip): does one clip of a (Ci -> Co) layer fit the
+    LDS-resident tile kernels?  Restated here so that building or inspecting a model needs no native library;
+    tests/test_lib_abi.py holds the two in agreement."""
+    if Ci <= 0 or Co <= 0 or Ci > 64 or Co > 64:
+        return False
+    up = lambda a, b: (a + b - 1) // b * b
+    TV = T * V
+    LD = TV + 1 if TV % 2 == 0 else TV
+    NB = 1 if Ci >= 32 else 32 // Ci
+    CiP, KZ, K1 = up(Ci, 16), up(Ci, 4), up(Co, 4)
+    tables = T * V * V + V * T * T
+    data = (NB * Ci * LD + tables + 2 * (KZ + K1) * CiP + 2 * CiP) * 4
+    CH = ((TV + 2) // 3 + 3) // 4 * 4
+    red = (Ci * LD + Co * (CH + 1) + tables) * 4
+    fwd = (NB * Ci * LD + tables + 2 * KZ * up(Co, 16) + up(Co, 16)) * 4
+    cap = 160 * 1024
+    return data <= cap and red <= cap and fwd <= cap
+
+
 class _GcnFn(torch.autograd.Function):
     """ConvTemporalGraphical.forward (reference stsgcn.py:143-156) and its gradients."""
 
@@ -58,10 +78,24 @@ class ConvTemporalGraphical(nn.Module):
         return _GcnFn.apply(X, self.A, self.T)
 
 
+def check_bn(bn) -> None:
+    """The kernels implement nn.BatchNorm's default configuration (what the reference builds, stsgcn.py:65,76 and
+    components.py:221): an exponential running average with a fixed momentum and tracked running statistics.  Anything
+    else fails loudly instead of computing something subtly different."""
+    if bn is None:
+        return
+    if bn.momentum is None:
+        raise NotImplementedError("coskad_amd: BatchNorm with momentum=None (cumulative moving average) is not on the HIP path")
+    if not bn.track_running_stats or bn.running_mean is None:
+        raise NotImplementedError("coskad_amd: BatchNorm with track_running_stats=False is not on the HIP path")
+
+
 def layer_tensors(layer: "ST_GCNN_layer") -> engine.LayerTensors:
     tc, tb = layer.tcn[0], layer.tcn[1]
     has_res = not isinstance(layer.residual, nn.Identity)
     rc, rb = (layer.residual[0], layer.residual[1]) if has_res else (None, None)
+    check_bn(tb)
+    check_bn(rb)
     return engine.LayerTensors(
         A=layer.gcn.A, T=layer.gcn.T, Wt=tc.weight, bt=tc.bias, gt=tb.weight, bet=tb.bias,
         rm_t=tb.running_mean, rv_t=tb.running_var, nbt_t=tb.num_batches_tracked,
@@ -143,7 +177,7 @@ class _WideLayerFn(torch.autograd.Function):
     """out = PReLU(BN_t(Wt . gcn(X) + bt) + BN_r(Wr . X + br))  (identity residual when Wr is None) for one wide layer."""
 
     @staticmethod
-    def forward(ctx, X, A, T, Wt, bt, gt, bet, Wr, br, gr, ber, slope, bn_t, bn_r, training):
+    def forward(ctx, X, A, T, Wt, bt, gt, bet, Wr, br, gr, ber, slope, bn_t, bn_r, training, drop_p=0.0, drop_seed=0):
         X = X.contiguous()
         B, Ci, Tn, V = X.shape
         Co, P = Wt.shape[0], Tn * V
@@ -156,7 +190,8 @@ class _WideLayerFn(torch.autograd.Function):
             st_r = ops.bn2_stats(Cr, bn_r, training)
         else:
             Cr, st_r = X.view(B, Ci, P), None
-        out = ops.bn2_apply_prelu(Ct, Cr, st_t, gt, bet, st_r, gr, ber, slope)
+        out = ops.bn2_apply_prelu(Ct, Cr, st_t, gt, bet, st_r, gr, ber, slope, drop_p, drop_seed)
+        ctx.drop = (drop_p, drop_seed)
         ctx.save_for_backward(X, Z, A, T, Wt, gt, bet, Wr, gr, ber, slope, Ct, Cr if Wr is not None else None, st_t, st_r)
         ctx.training, ctx.has_bt, ctx.has_br = training, bt is not None, br is not None
         return out.view(B, Co, Tn, V)
@@ -169,7 +204,7 @@ class _WideLayerFn(torch.autograd.Function):
         Xv = X.view(B, Ci, P)
         Crv = Cr if Cr is not None else Xv
         dCt, dCr, dgt, dbet, dgr, dber, dslope = ops.bn2_bwd(Ct, Crv, dOut.contiguous().view(B, Co, P), st_t, gt, bet, st_r, gr, ber,
-                                                             slope, ctx.training)
+                                                             slope, ctx.training, *ctx.drop)
         Wt2 = Wt.view(Co, Ci)
         dWt = ops.gemm_reduce(dCt, Z.view(B, Ci, P).transpose(1, 2), torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
         dZ = ops.gemm(Wt2.t(), dCt).view(B, Ci, Tn, V)
@@ -186,7 +221,7 @@ class _WideLayerFn(torch.autograd.Function):
         dbt = None
         if ctx.has_bt:
             dbt = dCt.sum((0, 2)) if not ctx.training else torch.zeros(Co, device=X.device, dtype=torch.float32)
-        return (dX, dA, dT, dWt.view_as(Wt), dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope.view_as(slope), None, None, None)
+        return (dX, dA, dT, dWt.view_as(Wt), dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope.view_as(slope), None, None, None, None, None)
 
 
 class ST_GCNN_layer(nn.Module):
@@ -205,9 +240,8 @@ class ST_GCNN_layer(nn.Module):
         if tuple(kernel_size) != (1, 1) or stride != 1:
             raise NotImplementedError("coskad_amd ST_GCNN_layer: only kernel_size (1,1), stride 1 (what every "
                                       "reference Encoder/Decoder builds, components.py:77-78,150-151)")
-        if dropout:
-            raise NotImplementedError("coskad_amd ST_GCNN_layer: dropout > 0 is not on the HIP path "
-                                      "(all reference configs use dropout: 0)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), but got {dropout}")
         if emb_dim is not None:
             raise NotImplementedError("coskad_amd ST_GCNN_layer: emb_dim is unused by the reference's models")
         self.build_model()
@@ -233,9 +267,14 @@ class ST_GCNN_layer(nn.Module):
         the 160 KB of LDS (64 input channels on the 25-joint layout: the default-width decoder of BASELINE config 4)."""
         if max(self.in_channels, self.out_channels) > WIDE_CHANNELS:
             return True
+        if self.dropout > 0:
+            # train-mode Dropout (stsgcn.py:66) sits between the tcn BatchNorm and the residual add, so the two branches cannot be
+            # folded into one GEMM: such layers take the composed path, whose BatchNorm / add / PReLU kernels apply the mask
+            # (every reference config sets dropout: 0)
+            return True
         key = (self.in_channels, self.out_channels, self.time_dim, self.joints_dim)
         if key not in _FITS:
-            _FITS[key] = ops.layer_fits(*key)
+            _FITS[key] = layer_fits(*key)
         return not _FITS[key]
 
     def forward_wide(self, X: Tensor) -> Tensor:
@@ -247,10 +286,19 @@ class ST_GCNN_layer(nn.Module):
         has_res = not isinstance(self.residual, nn.Identity)
         tc, tb = self.tcn[0], self.tcn[1]
         rc, rb = (self.residual[0], self.residual[1]) if has_res else (None, None)
+        check_bn(tb)
+        check_bn(rb)
         return _WideLayerFn.apply(X, self.gcn.A, self.gcn.T, tc.weight, tc.bias, tb.weight, tb.bias,
                                   rc.weight if has_res else None, rc.bias if has_res else None,
                                   rb.weight if has_res else None, rb.bias if has_res else None, self.prelu.weight,
-                                  tb, rb, self.training)
+                                  tb, rb, self.training, *self._dropout_args())
+
+    def _dropout_args(self):
+        """(p, seed) of this forward's train-mode Dropout mask: the seed is drawn from torch's CPU generator, so
+        torch.manual_seed makes runs repeatable (no device synchronisation); p = 0 in eval mode or without dropout."""
+        if not self.training or self.dropout <= 0:
+            return 0.0, 0
+        return float(self.dropout), int(torch.randint(0, 2 ** 62, (1,)).item())
 
     def forward(self, X: Tensor, t: Tensor = None) -> Tensor:
         if self.is_wide:

@@ -27,7 +27,7 @@ class _BottleneckFn(torch.autograd.Function):
         U = U.contiguous()
         ctx.save_for_backward(U, slope, W)
         ctx.ws, ctx.has_bias = ws, b is not None
-        return ops.btlnk_fwd(U, W.contiguous(), b, slope)
+        return ops.btlnk_fwd(U, W.contiguous(), b, slope, ws=ws)
 
     @staticmethod
     def backward(ctx, dz):
@@ -123,14 +123,14 @@ class STSE(nn.Module):
             return Z, X_shape
         return Z
 
-    def _encode_fused(self, X: Tensor) -> Optional[Tensor]:
-        """Eval-mode fast path: the whole encoder in ONE kernel (csrc/fused_fwd.hip: every activation stays in LDS /
-        registers) + the bottleneck on its tile-major output.  Taken for the reference's default geometry (T = 12,
-        V = 17, channels 2-32-16-32-64, linear projector, latent <= 16) when no gradient is needed; everything else
-        runs layer by layer."""
-        if self.training or torch.is_grad_enabled() or not X.is_cuda or not isinstance(self.btlnk, nn.Linear):
+    def _fused_hidden(self, X: Tensor, Ws):
+        """Eval-mode fast path, first half: the whole encoder in ONE kernel (csrc/fused_fwd.hip: every activation stays in
+        LDS / registers).  -> (H [B, KP]: the activated last layer in tile-major order, plan with `wb` = the weights `Ws`
+        stacked and permuted the same way), or None when the model is outside the kernel's geometry (T = 12, V = 17,
+        channels 2-32-16-32-64, at most 16 rows of weights) or a gradient is needed."""
+        if self.training or torch.is_grad_enabled() or not X.is_cuda or not isinstance(self.encoder, Encoder):
             return None
-        if self.latent_dim > 16 or not isinstance(self.encoder, Encoder):
+        if sum(w.shape[0] for w in Ws) > 16:
             return None
         from ..graph_layers.stsgcn import layer_tensors
         mods = list(self.encoder.model)
@@ -139,9 +139,33 @@ class STSE(nn.Module):
         layers = [layer_tensors(m) for m in mods]
         if not engine.fused_encoder_supported(layers, self.n_frames, self.n_joints):
             return None
-        plan = self.__dict__.setdefault("_fused_plan", engine.FusedEncoderPlan()).get(layers, self.btlnk.weight)
-        H = ops.fused_encoder(X.contiguous(), plan.tab, plan.wreg, plan.slopes)
-        return ops.btlnk_fwd(H, plan.wb, self.btlnk.bias, None)
+        plan = self.__dict__.setdefault("_fused_plan", engine.FusedEncoderPlan()).get(layers, tuple(Ws))
+        return ops.fused_encoder(X.contiguous(), plan.tab, plan.wreg, plan.slopes), plan
+
+    def _project_fused(self, X: Tensor) -> Optional[Tensor]:
+        """fused encoder + this model's projector (components.py:209-226 for `mlp`): the first (wide) Linear is the
+        bottleneck kernel on the tile-major output, every [BatchNorm1d, ReLU, Linear] block behind it csrc/mlp_head.hip
+        with the running statistics."""
+        if isinstance(self.btlnk, nn.Linear):
+            first, blocks = self.btlnk, []
+        elif isinstance(self.btlnk, MLP) and self.btlnk.hip_ok:
+            first, blocks = self.btlnk.net[0], self.btlnk.blocks()
+            if any(bn.running_mean is None or bn.running_var is None for bn, _ in blocks):
+                return None          # track_running_stats=False: batch statistics even in eval mode -> module path
+        else:
+            return None
+        r = self._fused_hidden(X, (first.weight,))
+        if r is None:
+            return None
+        H, plan = r
+        y = ops.btlnk_fwd(H, plan.wb, first.bias, None, ws=self._ws)
+        for bn, lin in blocks:
+            y, _ = ops.mlp_head_fwd(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                    lin.weight, lin.bias, False, eps=bn.eps)
+        return y
+
+    def _encode_fused(self, X: Tensor) -> Optional[Tensor]:
+        return self._project_fused(X)
 
     def forward(self, X: Tensor) -> Tensor:
         return self.encode(X)

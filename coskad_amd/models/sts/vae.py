@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
 from ..common.components import MLP
 from ..graph_layers.stsgcn import _PReLUFn
 from .ae import STSAE
@@ -101,9 +102,13 @@ class STSVAE(STSAE):
     def encode(self, X: Tensor, return_shape: bool = False):
         assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
         B = X.shape[0]
-        U, slope = self.encoder.forward_preact(X)
         X_shape = (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)
         n_var = self.fc_var.out_features
+        heads = self._heads_fused(X)
+        if heads is not None:
+            Z_mean, var_raw = heads
+            return self._finish_heads(Z_mean, var_raw, X_shape, return_shape)
+        U, slope = self.encoder.forward_preact(X)
         if isinstance(self.btlnk, nn.Identity) and self.latent_dim + n_var <= 16:
             # `linear` projector (vae.py:147-150): both heads read the flattened encoder output -- ONE pass of the
             # bottleneck kernel over U (PReLU fused into the load) with the two weights stacked
@@ -119,12 +124,35 @@ class STSVAE(STSAE):
             else:
                 Z = self.btlnk((U if slope is None else _PReLUFn.apply(U, slope)).reshape(B, -1))
             Z_mean, var_raw = self.fc_mean(Z), self.fc_var(Z)
+        return self._finish_heads(Z_mean, var_raw, X_shape, return_shape)
+
+    def _finish_heads(self, Z_mean: Tensor, var_raw: Tensor, X_shape, return_shape: bool):
         if self.distribution == 'ps':
             Z_mean = Z_mean / torch.norm(Z_mean, dim=-1, keepdim=True)
         Z_var = F.softplus(var_raw) + 1          # the `+ 1` prevents collapse (vae.py:85)
         if return_shape:
             return Z_mean, Z_var, X_shape
         return Z_mean, Z_var
+
+    def _heads_fused(self, X: Tensor):
+        """Eval-mode fast path (no gradient): the fused encoder kernel, then
+          `linear` projector (vae.py:147-150): ONE bottleneck pass over its tile-major output with fc_mean | fc_var stacked;
+          `mlp` projector (vae.py:141-146): the projector as in STSE, then both small heads as one strided MFMA GEMM.
+        -> (Z_mean pre-normalisation, var_raw) or None."""
+        L, n_var = self.latent_dim, self.fc_var.out_features
+        if isinstance(self.btlnk, nn.Identity):
+            r = self._fused_hidden(X, (self.fc_mean.weight, self.fc_var.weight))
+            if r is None:
+                return None
+            Hh, plan = r
+            Hd = ops.btlnk_fwd(Hh, plan.wb, torch.cat([self.fc_mean.bias, self.fc_var.bias]), None, ws=self._ws)
+            return Hd[:, :L], Hd[:, L:]
+        Z = self._project_fused(X)
+        if Z is None:
+            return None
+        Wc = torch.cat([self.fc_mean.weight, self.fc_var.weight], 0)          # [L + n_var, latent]
+        Hd = ops.gemm(Z, Wc.t(), bias=torch.cat([self.fc_mean.bias, self.fc_var.bias]), bias_mode=2)
+        return Hd[:, :L], Hd[:, L:]
 
     def reparameterize(self, Z_mean: Tensor, Z_var: Tensor):
         if self.distribution == 'normal':

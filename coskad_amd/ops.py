@@ -337,20 +337,21 @@ def layer_gcn_params(x_in, in_slope, dZ, A, Tm, dA, dT, ws, accumulate=False):
          ctypes.c_size_t(_bytes(ws)), i32(1 if accumulate else 0), i32(B), i32(Ci), i32(T), i32(V), _stream())
 
 
-def btlnk_fwd(U: Tensor, W: Tensor, bias: Optional[Tensor], slope: Optional[Tensor]) -> Tensor:
-    """z = Linear(flatten(PReLU(U)))  (reference ae.py:97-101)."""
+def btlnk_fwd(U: Tensor, W: Tensor, bias: Optional[Tensor], slope: Optional[Tensor], ws=None) -> Tensor:
+    """z = Linear(flatten(PReLU(U)))  (reference ae.py:97-101).  ws: an engine.Workspace to take the split-K scratch from
+    (stream-ordered reuse across the kernels of one module); None allocates it per call."""
     B = U.shape[0]
     K = U.numel() // B
     L = W.shape[0]
     _chk(U, "U"); _chk(W, "W", (L, K)); _chk(bias, "bias", (L,), optional=True); _chk(slope, "slope", (1,), optional=True)
     z = torch.empty(B, L, device=U.device, dtype=torch.float32)
     if B >= BTLNK_SPLITK_MIN_B and K % 16 == 0:
-        # large batches: blocks of 64 clips x 8 K slices (W operands shared by four clip tiles), fixed-order partial sums
+        # blocks of 64 clips x 4 K slices (W operands shared by four clip tiles), fixed-order partial sums
         fn = _lib.lib().coskad_btlnk_fwd_ws_bytes
         fn.restype = ctypes.c_size_t
         nbytes = fn(i32(B))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=U.device)
-        call("coskad_btlnk_fwd_ws_f32", ptr(U), ptr(W), ptr(bias), ptr(slope), ptr(z), ptr(ws), ctypes.c_size_t(nbytes),
+        buf = ws.get(nbytes, U.device) if ws is not None else torch.empty(nbytes, dtype=torch.uint8, device=U.device)
+        call("coskad_btlnk_fwd_ws_f32", ptr(U), ptr(W), ptr(bias), ptr(slope), ptr(z), ptr(buf), ctypes.c_size_t(nbytes),
              i32(B), i32(K), i32(L), _stream())
         return z
     call("coskad_btlnk_fwd_f32", ptr(U), ptr(W), ptr(bias), ptr(slope), ptr(z), i32(B), i32(K), i32(L), _stream())
@@ -515,16 +516,25 @@ def bn2_stats(x: Tensor, bn, training: bool) -> Tensor:
     return stat
 
 
-def bn2_apply_prelu(Ct, Cr, stat_t, gt, bt, stat_r, gr, br, slope) -> Tensor:
+def bn2_apply_prelu(Ct, Cr, stat_t, gt, bt, stat_r, gr, br, slope, drop_p: float = 0.0, drop_seed: int = 0) -> Tensor:
+    """out = PReLU(Dropout_p(BN_t(Ct)) + BN_r(Cr)); the dropout mask is a counter-based function of (drop_seed, element)."""
     Nb, C, P = Ct.shape
     _chk(Ct, "Ct"); _chk(Cr, "Cr", (Nb, C, P)); _chk(stat_t, "stat_t", (2 * C,)); _chk(stat_r, "stat_r", (2 * C,), optional=True)
     out = torch.empty_like(Ct)
     call("coskad_bn2_apply_prelu_f32", ptr(Ct), ptr(Cr), ptr(stat_t), ptr(gt), ptr(bt), ptr(stat_r), ptr(gr), ptr(br), ptr(slope),
-         ptr(out), i32(Nb), i32(C), i32(P), _stream())
+         ptr(out), i32(Nb), i32(C), i32(P), _stream(), ctypes.c_float(drop_p), ctypes.c_ulonglong(drop_seed))
     return out
 
 
-def bn2_bwd(Ct, Cr, dOut, stat_t, gt, bt, stat_r, gr, br, slope, training: bool):
+def dropout_mask(shape, drop_p: float, drop_seed: int, device) -> Tensor:
+    """The mask bn2_apply_prelu / bn2_bwd apply for (drop_p, drop_seed): values 0 or 1 / (1 - p), in element order."""
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    call("coskad_dropout_mask_f32", ptr(out), ctypes.c_size_t(out.numel()), ctypes.c_float(drop_p), ctypes.c_ulonglong(drop_seed),
+         _stream())
+    return out
+
+
+def bn2_bwd(Ct, Cr, dOut, stat_t, gt, bt, stat_r, gr, br, slope, training: bool, drop_p: float = 0.0, drop_seed: int = 0):
     """-> (dCt, dCr, dgt, dbt, dgr, dbr, dslope) (residual gradients None for an identity residual)."""
     Nb, C, P = Ct.shape
     _chk(dOut, "dOut", (Nb, C, P))
@@ -536,7 +546,7 @@ def bn2_bwd(Ct, Cr, dOut, stat_t, gt, bt, stat_r, gr, br, slope, training: bool)
     ws = _bn2_ws(Nb, C, Ct.device, bwd=True)
     call("coskad_bn2_bwd_f32", ptr(Ct), ptr(Cr), ptr(dOut), ptr(stat_t), ptr(gt), ptr(bt), ptr(stat_r), ptr(gr), ptr(br), ptr(slope),
          ptr(dCt), ptr(dCr), ptr(dgt), ptr(dbt), ptr(dgr), ptr(dbr), ptr(dslope), i32(1 if training else 0), ptr(ws),
-         ctypes.c_size_t(ws.numel()), i32(Nb), i32(C), i32(P), _stream())
+         ctypes.c_size_t(ws.numel()), i32(Nb), i32(C), i32(P), _stream(), ctypes.c_float(drop_p), ctypes.c_ulonglong(drop_seed))
     return dCt, dCr, dgt, dbt, dgr, dbr, dslope
 
 

@@ -45,20 +45,25 @@ def allreduce_mean_(flat_grad: Tensor, group=None) -> Tensor:
 
 def allreduce_grads_mean_(params, group=None) -> None:
     """Mean over ranks of the `.grad` of every parameter as ONE flat bucket (one collective per step instead of one
-    per parameter tensor: the model is ~1 MB, the cost is latency)."""
+    per parameter tensor: the model is ~1 MB, the cost is latency).  The bucket is laid out over EVERY parameter that
+    requires a gradient -- zeros where a rank has none (an unused branch on a ragged shard) -- so that its length and
+    the meaning of every slot are the same on all ranks; a parameter unused on this rank receives the others' mean."""
     w = world_size(group)
     if w == 1:
         return
-    gs = [p.grad for p in params if p.grad is not None]
-    if not gs:
+    ps = [p for p in params if p.requires_grad]
+    if not ps:
         return
-    flat = torch.cat([g.reshape(-1) for g in gs])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(w)
     off = 0
-    for g in gs:
-        k = g.numel()
-        g.copy_(flat[off:off + k].view(g.shape))
+    for p in ps:
+        k = p.numel()
+        if p.grad is None:
+            p.grad = flat[off:off + k].view(p.shape).clone()
+        else:
+            p.grad.copy_(flat[off:off + k].view(p.shape))
         off += k
 
 

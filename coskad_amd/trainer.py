@@ -130,19 +130,20 @@ class STSETrainStep:
             # [BatchNorm1d, ReLU, Linear] block on csrc/mlp_head.hip; parameters and gradients stay in the flat buffers
             first, wname = m.btlnk.net[0], "btlnk.net.0."
             W, b = first.weight, first.bias
-            y = ops.btlnk_fwd(U, W, b, slope)
+            y = ops.btlnk_fwd(U, W, b, slope, ws=self.ws)
             saved = []
+            if B == 1:                     # nn.BatchNorm1d's own check in training mode
+                raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d of the mlp projector)")
             for i, (bn, lin) in enumerate(m.btlnk.blocks()):
                 z, stat = ops.mlp_head_fwd(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                           lin.weight, lin.bias, True, momentum=bn.momentum if bn.momentum is not None else 0.1,
-                                           eps=bn.eps)
+                                           lin.weight, lin.bias, True, momentum=bn.momentum, eps=bn.eps)
                 saved.append((y, stat, bn, lin, f"btlnk.net.{3 * i + 1}.", f"btlnk.net.{3 * i + 3}."))
                 y = z
             z = y
         else:
             wname = "btlnk."
             W, b = m.btlnk.weight, m.btlnk.bias
-            z = ops.btlnk_fwd(U, W, b, slope)
+            z = ops.btlnk_fwd(U, W, b, slope, ws=self.ws)
         if self.head == 'euclidean':
             stats, dz, _ = ops.mse_head(z, m.c, acc=self.center_acc)
         elif self.head == 'poincare':

@@ -161,11 +161,17 @@ int coskad_bn2_stats_f32(const float* x, float* stat, float* running_mean, float
                          hipStream_t stream);
 int coskad_bn2_apply_prelu_f32(const float* Ct, const float* Cr, const float* stat_t, const float* gamma_t, const float* beta_t,
                                const float* stat_r, const float* gamma_r, const float* beta_r, const float* slope, float* out,
-                               int Nb, int C, int P, hipStream_t stream);
+                               int Nb, int C, int P, hipStream_t stream, float drop_p, unsigned long long drop_seed);
 int coskad_bn2_bwd_f32(const float* Ct, const float* Cr, const float* dOut, const float* stat_t, const float* gamma_t,
                        const float* beta_t, const float* stat_r, const float* gamma_r, const float* beta_r, const float* slope,
                        float* dCt, float* dCr, float* dgamma_t, float* dbeta_t, float* dgamma_r, float* dbeta_r, float* dslope,
-                       int training, void* ws, size_t ws_bytes, int Nb, int C, int P, hipStream_t stream);
+                       int training, void* ws, size_t ws_bytes, int Nb, int C, int P, hipStream_t stream, float drop_p,
+                       unsigned long long drop_seed);
+/* Train-mode nn.Dropout(p) of the tcn branch (stsgcn.py:66, between BatchNorm and the residual add) in the two calls above:
+ * drop_p in [0, 1) and a seed; element i of the [Nb, C, P] tensor is kept (and scaled by 1 / (1 - p)) iff a counter-based hash
+ * of (seed, i) says so -- the backward recomputes the mask from the same seed, nothing is stored.  drop_p = 0: no dropout.
+ * coskad_dropout_mask_f32 writes that mask (values 0 or 1 / (1 - p)) for tests / oracles. */
+int coskad_dropout_mask_f32(float* out, size_t n, float drop_p, unsigned long long drop_seed, hipStream_t stream);
 
 /* ---- `mlp` projector tail (models/common/components.py:209-226 behind its first Linear, which runs on the bottleneck
  * kernels): z = W2 . relu(BatchNorm1d(y1)) + b2 on y1 [B, H]; H, L <= 64.

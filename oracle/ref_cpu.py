@@ -97,8 +97,9 @@ def prelu(x: Tensor, a: Tensor) -> Tensor:
 
 
 def st_gcnn_layer(x: Tensor, st: State, prefix: str, training: bool,
-                  return_preact: bool = False, update: bool = True) -> Tensor:
-    """ST_GCNN_layer.forward, kernel (1,1), stride 1, dropout 0 (stsgcn.py:94-116).
+                  return_preact: bool = False, update: bool = True, drop_mask: Optional[Tensor] = None) -> Tensor:
+    """ST_GCNN_layer.forward, kernel (1,1), stride 1 (stsgcn.py:94-116).  `drop_mask` (values 0 or 1 / (1 - p), shape of
+    the output) stands for the train-mode nn.Dropout at the end of `tcn` (stsgcn.py:66); None = dropout 0 / eval mode.
 
     residual is Conv1x1+BN when the key exists (C_in != C_out, stsgcn.py:69-77),
     identity otherwise (stsgcn.py:79-80).
@@ -111,6 +112,8 @@ def st_gcnn_layer(x: Tensor, st: State, prefix: str, training: bool,
     z = gcn(x, st[prefix + ".gcn.A"], st[prefix + ".gcn.T"])
     s = conv1x1(z, st[prefix + ".tcn.0.weight"], st.get(prefix + ".tcn.0.bias"))
     s = batchnorm(s, st, prefix + ".tcn.1", training, update)
+    if drop_mask is not None:
+        s = s * drop_mask
     u = s + res
     if return_preact:
         return u

@@ -127,3 +127,37 @@ def test_module_broadcast_and_equal_shards():
     assert n == 17 and res[0][3] == res[1][3] == 3                # ceil(ceil(17/2)/4) batches on BOTH ranks
     for r in res:
         assert r[5] == 18 and sorted(r[4]) == list(range(17))     # 18 gathered rows, 17 distinct windows after the dedupe
+
+
+def _worker_unused(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coskad_amd import parallel
+    torch.manual_seed(0)
+    a, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2))
+    frozen = torch.nn.Parameter(torch.ones(4), requires_grad=False)
+    a.grad = torch.full((3,), float(rank + 1))
+    if rank == 0:                       # rank 1 never touched `b` (a branch its shard skipped)
+        b.grad = torch.full((2, 2), 4.0)
+    parallel.allreduce_grads_mean_([a, frozen, b])
+    q.put((rank, a.grad.numpy(), b.grad.numpy(), frozen.grad))
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_layout_is_rank_independent_with_unused_parameters():
+    """One rank has no gradient for a parameter: the flat bucket is laid out over every parameter that requires a gradient
+    (zeros where missing), so lengths agree, nothing hangs or lands in the wrong tensor, and every rank ends with the mean."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_unused, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ga, gb, gf in res:
+        np.testing.assert_allclose(ga, np.full(3, 1.5))
+        np.testing.assert_allclose(gb, np.full((2, 2), 2.0))
+        assert gf is None

@@ -328,6 +328,13 @@ def test_stsvae_v25_default_width_vs_reference_golden(golden):
         zref = torch.from_numpy(g["eval.z"]).cuda()
         np.testing.assert_allclose(zm.cpu().numpy(), (zref / zref.norm(dim=-1, keepdim=True)).cpu().numpy(), rtol=1e-4, atol=1e-4)
         assert bool((zv >= 1).all())                                                  # softplus + 1 (vae.py:85)
+        # the concentration head against the oracle's heads on the oracle's own flattened encoder output (vae.py:79-85)
+        from oracle import ref_cpu as R
+        sto = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        flat = R.stse_encode(x.cpu(), sto, training=False)
+        zm_o, zv_o = R.stsvae_heads(flat, sto, 'ps')
+        np.testing.assert_allclose(zv.cpu().numpy(), zv_o.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(zm.cpu().numpy(), zm_o.numpy(), rtol=1e-4, atol=1e-4)
         xr = m.decode(zref, (x.shape[0], 64, 12, 25, 1))
         np.testing.assert_allclose(xr.cpu().numpy(), g["eval.xrec"], rtol=1e-4, atol=1e-4)
     m.train()
@@ -401,3 +408,113 @@ def test_mlp_projector_hip_path_vs_oracle(hidden):
                                                                                  and k != max((q for q in st if q.startswith("btlnk.net.") and q.endswith(".bias") and st[q[:-4] + "weight"].dim() == 2))):
             continue   # Linear biases in front of a train-mode BatchNorm: analytically zero gradient (autograd noise moves torch's Adam)
         np.testing.assert_allclose(new[k].cpu().numpy(), p.detach().numpy(), rtol=2e-3, atol=3e-4, err_msg=k)
+
+
+def _randomise_bn(m):
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mod.weight.add_(0.2 * torch.randn_like(mod.weight)); mod.bias.add_(0.1 * torch.randn_like(mod.bias))
+                mod.running_mean.add_(0.1 * torch.randn_like(mod.running_mean)); mod.running_var.mul_(1.3)
+
+
+@pytest.mark.parametrize("B", [5, 261])
+def test_fused_eval_forward_with_mlp_projector(B):
+    """`projector: 'mlp'` (5 of the reference's 7 yamls; components.py:209-226) on the eval-mode fast path: ONE fused encoder
+    kernel, the first Linear on its tile-major output, the [BatchNorm1d, ReLU, Linear] block on csrc/mlp_head.hip --
+    against the CPU oracle and against the layer-by-layer path of the same module."""
+    from coskad_amd.models.sts.ae import STSE
+    from oracle import ref_cpu as R
+    torch.manual_seed(11)
+    m = STSE(2, [32, 16, 32], 64, 16, 12, 17, 'sts_gcn', 'mlp', 'euclidean', 0.0)
+    _randomise_bn(m)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = R.synthetic_clips(B, seed=12)
+    m.cuda().eval()
+    with torch.no_grad():
+        assert m._project_fused(x.cuda()) is not None, "the fused path must take the default geometry with an mlp projector"
+        z = m(x.cuda())
+        z_ref = R.stse_encode(x, st, training=False)
+    with torch.enable_grad():                     # a gradient is needed -> layer-by-layer kernels
+        z_layers = m(x.cuda()).detach()
+    np.testing.assert_allclose(z.cpu().numpy(), z_ref.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(z.cpu().numpy(), z_layers.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("projector", ["linear", "mlp"])
+def test_fused_eval_vae_heads(projector):
+    """STSVAE.encode in eval mode on the fused encoder kernel: `linear` -> fc_mean | fc_var stacked on ONE bottleneck pass
+    (vae.py:147-150), `mlp` -> the projector as in STSE, then both heads as one MFMA GEMM (vae.py:141-146); against the oracle's
+    heads and the layer-by-layer path."""
+    from coskad_amd.models.sts.vae import STSVAE
+    from oracle import ref_cpu as R
+    torch.manual_seed(5)
+    m = STSVAE(2, [32, 16, 32], 64, 8, 12, 17, 'sts_gcn', projector, 'euclidean', 0.0, distribution='ps')
+    _randomise_bn(m)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = R.synthetic_clips(37, seed=8)
+    m.cuda().eval()
+    with torch.no_grad():
+        assert m._heads_fused(x.cuda()) is not None
+        zm, zv = m.encode(x.cuda())
+        flat = R.stse_encode(x, st, training=False)          # linear: the flattened encoder output; mlp: the projector's output
+        zm_ref, zv_ref = R.stsvae_heads(flat, st, 'ps')
+    with torch.enable_grad():
+        zm_l, zv_l = m.encode(x.cuda())
+    np.testing.assert_allclose(zm.cpu().numpy(), zm_ref.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(zv.cpu().numpy(), zv_ref.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(zm.cpu().numpy(), zm_l.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(zv.cpu().numpy(), zv_l.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("Ci,Co", [(16, 32), (16, 16)])
+def test_train_mode_dropout_matches_oracle_with_the_same_mask(Ci, Co):
+    """nn.Dropout(p) at the end of `tcn` (stsgcn.py:66) in training mode: the layer's counter-based mask, recomputed in the
+    backward, against the oracle with the SAME explicit mask (forward, every gradient, running statistics); eval mode is the
+    identity; the mask has the right rate and scale and changes with the seed."""
+    from coskad_amd import ops
+    from coskad_amd.models.graph_layers.stsgcn import ST_GCNN_layer
+    from oracle import ref_cpu as R
+    torch.manual_seed(4)
+    p_drop, B, T, V = 0.3, 9, 12, 17
+    layer = ST_GCNN_layer(Ci, Co, (1, 1), 1, T, V, p_drop)
+    st = {"l." + k: v.detach().clone() for k, v in layer.state_dict().items()}
+    x = torch.randn(B, Ci, T, V)
+    layer.cuda().train()
+    seed = 123456789
+    layer._dropout_args = lambda: (p_drop, seed)
+    mask = ops.dropout_mask((B, Co, T, V), p_drop, seed, "cuda")
+    vals = torch.unique(mask).cpu().numpy()
+    np.testing.assert_allclose(vals, [0.0, 1 / (1 - p_drop)], rtol=1e-6)
+    n = mask.numel()
+    assert abs(float((mask == 0).float().mean()) - p_drop) < 4 * (p_drop * (1 - p_drop) / n) ** 0.5
+    assert not torch.equal(mask, ops.dropout_mask((B, Co, T, V), p_drop, seed + 1, "cuda"))
+    xg = x.cuda().requires_grad_(True)
+    out = layer(xg)
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).cuda()
+    (out * w).sum().backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
+    so = dict(st)
+    so.update(params)
+    xo = x.clone().requires_grad_(True)
+    ref = R.st_gcnn_layer(xo, so, "l", training=True, drop_mask=mask.cpu())
+    (ref * w.cpu()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xo.grad.numpy(), rtol=1e-3, atol=1e-4)
+    gmax = max(float(p_.grad.abs().max()) for p_ in params.values())
+    for name, prm in layer.named_parameters():
+        r = params["l." + name].grad.numpy()       # (conv biases in front of a train-mode BatchNorm: exactly 0 here, rounding noise in autograd)
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-4 * np.abs(r).max() + 5e-5 * gmax, err_msg=name)
+    for k, v in layer.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), so["l." + k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    # two training forwards draw different masks; eval mode: no dropout at all
+    del layer._dropout_args
+    torch.manual_seed(0)
+    a, b = layer(x.cuda()).detach(), layer(x.cuda()).detach()
+    assert not torch.equal(a, b)
+    layer.eval()
+    with torch.no_grad():
+        e = layer(x.cuda())
+        ref_e = R.st_gcnn_layer(x, {k: v.cpu() for k, v in {"l." + k: v for k, v in layer.state_dict().items()}.items()}, "l", training=False)
+    np.testing.assert_allclose(e.cpu().numpy(), ref_e.numpy(), rtol=1e-4, atol=1e-4)

@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: module surface, state_dict contract, flat-parameter views,
 regulariser mask, loud failure on CPU tensors."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -156,3 +158,84 @@ def test_legacy_wrapper_import_names():
     from coskad_amd.models.stse.stse_hidden_hypersphere import STSE
     from coskad_amd.models.stsve.stsve_hidden_hypersphere import STSVE
     assert STSE is ae.STSE and STSAE is ae.STSAE and STSVE is vae.STSVAE
+
+
+def test_oracle_mlp_equals_torch_sequential_of_the_reference_blocks():
+    """`oracle.ref_cpu.mlp` pinned against what the reference's MLP.build_model would assemble if its constructor ran
+    (components.py:209-226: [Linear, BatchNorm1d, ReLU(inplace)] per hidden size + a final Linear, as nn.Sequential):
+    eval and train mode outputs, gradients and the running statistics after the step."""
+    import torch.nn as nn
+    from oracle import ref_cpu as R
+    torch.manual_seed(0)
+    sizes, inp, out = [12, 10], 40, 6
+    layers, k = [], inp
+    for h in sizes:
+        layers += [nn.Linear(k, h), nn.BatchNorm1d(h), nn.ReLU(inplace=True)]
+        k = h
+    layers.append(nn.Linear(k, out))
+    net = nn.Sequential(*layers)
+    with torch.no_grad():
+        for m in net:
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.add_(0.3 * torch.randn_like(m.weight)); m.bias.add_(0.2 * torch.randn_like(m.bias))
+                m.running_mean.add_(0.1 * torch.randn_like(m.running_mean)); m.running_var.mul_(1.7)
+    x = torch.randn(33, inp)
+    st = {"btlnk.net." + k: v.detach().clone() for k, v in net.state_dict().items()}
+    net.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(R.mlp(x, st, "btlnk", training=False).numpy(), net(x).numpy(), rtol=1e-6, atol=1e-6)
+    net.train()
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.is_floating_point() and "running" not in k}
+    so = dict(st)
+    so.update(params)
+    y_o = R.mlp(x, so, "btlnk", training=True)
+    y_t = net(x)
+    np.testing.assert_allclose(y_o.detach().numpy(), y_t.detach().numpy(), rtol=1e-5, atol=1e-6)
+    (y_o ** 2).mean().backward()
+    (y_t ** 2).mean().backward()
+    for n, p in net.named_parameters():
+        np.testing.assert_allclose(params["btlnk.net." + n].grad.numpy(), p.grad.numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+    for n, b in net.named_buffers():
+        np.testing.assert_allclose(so["btlnk.net." + n].numpy(), b.numpy(), rtol=1e-6, atol=1e-7, err_msg=n)
+
+
+REF_CONFIGS = "/root/reference/config"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="the reference tree is only present in the build container")
+def test_reference_yaml_files_drive_the_wrappers():
+    """Config contract (train_COSKAD.py:15-62): every yaml the reference ships is read by argparser.init_sub_args and builds
+    the wrapper train_COSKAD.py would select, with the model family / projector / latent size the file names.
+    `UBnormal/euclidean_autoencoder.yaml` is malformed in the reference itself (yaml.load raises there too): expected."""
+    import argparse
+    import glob
+    import yaml
+    from coskad_amd import lit
+    from coskad_amd.models.common.components import MLP
+    from coskad_amd.utils.argparser import init_sub_args
+    files = sorted(glob.glob(os.path.join(REF_CONFIGS, "*", "*.yaml")))
+    assert len(files) >= 7
+    built, broken = 0, []
+    for f in files:
+        try:
+            raw = yaml.load(open(f), Loader=yaml.FullLoader)
+        except yaml.YAMLError:
+            broken.append(os.path.relpath(f, REF_CONFIGS))
+            continue
+        args = argparse.Namespace(**raw)
+        args.exp_dir = "/tmp/coskad_contract"       # nothing is written: the wrappers only read it
+        args, *_ = init_sub_args(args)
+        cls = lit.LitAutoEncoder if args.use_decoder else lit.LitVAE if args.use_vae else lit.LitEncoder
+        m = cls(args)
+        assert m.model.latent_dim == raw["latent_dim"], f
+        if not args.use_decoder:
+            proj = m.model.btlnk
+            want_mlp = raw.get("projector", "linear") == "mlp"
+            assert isinstance(proj, MLP) == want_mlp, f
+        if str(raw.get("encoder_type", "sts_gcn")).lower() == "sts_gcn":
+            chans = [l.tcn[0].weight.shape[0] for l in m.model.encoder.model]
+            assert chans == list(raw["channels"]) + [raw["h_dim"]], f
+        else:
+            assert type(m.model.encoder).__name__.lower().startswith("encoder" + str(raw["encoder_type"]).lower().split("_")[0]), f
+        built += 1
+    assert built >= 6 and broken == ["UBnormal/euclidean_autoencoder.yaml"], (built, broken)

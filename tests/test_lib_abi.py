@@ -50,3 +50,13 @@ def test_size_queries():
     assert lib.coskad_head_slots() == 19
     lib.coskad_train_stats_ws_bytes.restype = ctypes.c_size_t
     assert lib.coskad_train_stats_ws_bytes(32) > 512 * 2 * (32 * 32 + 32) * 4
+
+
+def test_python_layer_fits_agrees_with_the_library():
+    """`ST_GCNN_layer.is_wide` decides in Python (no native call while a model is built); same answer as coskad_layer_fits."""
+    from coskad_amd import ops
+    from coskad_amd.models.graph_layers.stsgcn import layer_fits
+    for V in (14, 17, 18, 25):
+        for Ci in (1, 2, 3, 4, 8, 16, 32, 48, 64, 65, 128):
+            for Co in (2, 16, 32, 64, 65, 256):
+                assert layer_fits(Ci, Co, 12, V) == ops.layer_fits(Ci, Co, 12, V), (Ci, Co, V)

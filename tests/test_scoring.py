@@ -86,4 +86,9 @@ def test_rec_and_hy_score_types():
         got = E.rec_and_hy_window_scores(x, xr, z, c, rec_loss_weight=0.2, loss_type=lt)
         want = RS.rec_and_hy_window_scores(x.numpy(), xr.numpy(), z.numpy(), c.numpy(), 0.2, lt)
         np.testing.assert_allclose(got.numpy(), want, rtol=1e-5)
+    z32, c32 = torch.randn(9, 32, generator=g), torch.randn(32, generator=g)           # a latent wider than the head kernel's 16
+    for lt in ('hyp', 'rec+hyp'):
+        got = E.rec_and_hy_window_scores(x, xr, z32, c32, rec_loss_weight=0.2, loss_type=lt)
+        want = RS.rec_and_hy_window_scores(x.numpy(), xr.numpy(), z32.numpy(), c32.numpy(), 0.2, lt)
+        np.testing.assert_allclose(got.numpy(), want, rtol=1e-5)
     assert [E.eval_loss_type(w) for w in (0, 0.2, 1000)] == ['hyp', 'rec+hyp', 'rec']     # eval_COSKAD.py:58-66
