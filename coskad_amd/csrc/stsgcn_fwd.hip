@@ -196,6 +196,54 @@ __global__ __launch_bounds__(256) void k_sum_small(const float* __restrict__ v, 
   if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)sh[0] : (float)sh[0];
 }
 
+// Reconstruction head of the decoder models (F.mse_loss(x_rec, x), euclidean_autoencoder.py:111, spherical_vae.py:90) fused
+// with the last decoder layer's PReLU: x_rec = PReLU(U), loss = mean (x_rec - x)^2, dU = upstream * 2 (x_rec - x) / n * PReLU'(U),
+// slope gradient.  partials[2 b] = block b's sum of squares, partials[2 b + 1] = its slope-gradient sum.
+__global__ __launch_bounds__(256) void k_rec_head(const float* __restrict__ u, const float* __restrict__ x,
+                                                   const float* __restrict__ slope, float* __restrict__ xrec,
+                                                   float* __restrict__ du, float* __restrict__ partials, float gscale, size_t n) {
+  __shared__ float sh[8];
+  const float a = slope[0];
+  float sq = 0.f, da = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = u[i];
+    const float r = v > 0.f ? v : a * v;
+    const float d = r - x[i];
+    if (xrec) xrec[i] = r;
+    sq = fmaf(d, d, sq);
+    if (du) {
+      const float g = gscale * d;
+      if (v < 0.f) da = fmaf(g, v, da);
+      du[i] = v > 0.f ? g : a * g;
+    }
+  }
+  sq = wave_sum(sq);
+  da = wave_sum(da);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = sq; sh[4 + (threadIdx.x >> 6)] = da; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    partials[2 * blockIdx.x + 1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rec_head_final(const float* __restrict__ partials, int nblk, double inv_n,
+                                                         float* __restrict__ loss, float* __restrict__ dslope, int accumulate) {
+  __shared__ double sh[2][256];
+  double s = 0.0, d = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) { s += (double)partials[2 * i]; d += (double)partials[2 * i + 1]; }
+  sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = d;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = (float)(sh[0][0] * inv_n);
+    if (dslope) dslope[0] = accumulate ? dslope[0] + (float)sh[1][0] : (float)sh[1][0];
+  }
+}
+
 static int pick_nb(int Ci, int B, int LD) {
   // 64 rows per row-phase batch is the sweet spot (one lane per row); cap by LDS.
   int nb = Ci >= 64 ? 1 : 64 / Ci;
@@ -323,6 +371,21 @@ int coskad_bn_fold_f32(const float* Wt, const float* bt, const float* gamma_t, c
   hipLaunchKernelGGL(k_bn_fold, dim3(1), dim3(256), 0, stream, Wt, bt, gamma_t, beta_t, mean_t, var_t,
                      Wr, br, gamma_r, beta_r, mean_r, var_r, wfold, bias, Ci, Co, CoP);
   return check_launch("bn_fold");
+}
+
+/* Reconstruction head: x_rec = PReLU_slope(U) (the last decoder layer's activation), loss[0] = mean((x_rec - x)^2)
+ * (F.mse_loss, euclidean_autoencoder.py:111 / spherical_vae.py:90); dU (optional) = upstream * dloss/dU, dslope (optional,
+ * with dU) (+)= upstream * dloss/dslope; xrec (optional) receives the reconstruction.  ws: >= 2048 floats. */
+int coskad_rec_head_f32(const float* U, const float* x, const float* slope, float* xrec, float* dU, float* loss, float* dslope,
+                        float upstream, float* ws, int accumulate, size_t n, hipStream_t stream) {
+  if (!U || !x || !slope || !loss || !ws || n == 0) return fail(COSKAD_ERR_ARG, "rec_head: bad argument");
+  if (dslope && !dU) return fail(COSKAD_ERR_ARG, "rec_head: the slope gradient comes with dU");
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_rec_head, dim3(grid), dim3(256), 0, stream, U, x, slope, xrec, dU, ws, (float)(2.0 * (double)upstream / (double)n), n);
+  int rc = check_launch("rec_head");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_rec_head_final, dim3(1), dim3(256), 0, stream, ws, grid, 1.0 / (double)n, loss, dslope, accumulate);
+  return check_launch("rec_head_final");
 }
 
 }  // extern "C"

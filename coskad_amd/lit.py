@@ -237,10 +237,28 @@ class _AutogradLit(LitEncoder):
         self.gts = None
         object.__setattr__(self, "_engine", self)   # the Trainer's plateau rule calls _engine.set_lr (not a submodule)
         self._opt = None
+        self._flat = None
 
     def set_lr(self, lr: float) -> None:
+        if self._flat is not None:
+            self._flat.set_lr(lr)
+            return
         for g in self._opt.param_groups:
             g['lr'] = lr
+
+    def _make_optimiser(self, mode: str, **weights) -> None:
+        """The flat-buffer step with the fused Adam (trainer.STSAETrainStep: no autograd around the encoder / decoder chains)
+        where the model is within its kernels; torch autograd + torch.optim.Adam over the module surface otherwise."""
+        from .trainer import STSAETrainStep
+        from .models.common.components import Encoder
+        self._flat = None
+        on_gpu = next(self.model.parameters()).is_cuda
+        if on_gpu and isinstance(self.model.encoder, Encoder) and STSAETrainStep.supports(self.model) \
+                and not self.model.encoder.model[-1].is_wide and not self.model.decoder.model[-1].is_wide:
+            self._flat = STSAETrainStep(self.model, mode=mode, lr=self.learning_rate,
+                                        alpha=float(getattr(self.args, "alpha", 0.0)), **weights)
+        else:
+            self._opt = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate)
 
     def _reg_loss(self) -> torch.Tensor:
         """utils/model_utils.py:90-105 (differentiable: it is part of these wrappers' loss)."""
@@ -305,10 +323,19 @@ class LitAutoEncoder(_AutogradLit):
         parallel.allreduce_sum_(acc)
         self.model.c.copy_(ops.center_finalize(acc, self.eps, self.model.latent_dim))
         self.model.train()
-        self._opt = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate)
+        self._make_optimiser('ae', lambda_=self.lambda_)
 
     def training_step(self, batch, batch_idx: int) -> torch.Tensor:
         x = batch[0].to(self.model.c.device, non_blocking=True)
+        if self._flat is not None:
+            out = self._flat.step(x)
+            loss = self.lambda_ * out['rec'] + out['head']
+            if batch_idx % 20 == 0:
+                loss_reg = self._flat.reg_loss()
+                self.log("loss", loss + float(getattr(self.args, "alpha", 0.0)) * loss_reg)
+                self.log("reconstruction_loss", out['rec']); self.log("hypersphere_loss", out['head'])
+                self.log("regularization", loss_reg)
+            return loss
         z, x_rec = self.model(x)
         loss_reco = F.mse_loss(x_rec, x)
         loss_h = F.mse_loss(z, self.model.c.expand_as(z))
@@ -353,11 +380,23 @@ class LitVAE(_AutogradLit):
     def setup(self, stage: str = None, train_loader=None) -> None:
         if stage == "fit":
             self.model.train()
-            self._opt = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate)
+            self._make_optimiser('vae', phi=self.phi, beta=self.beta, gamma=self.gamma)
 
     def training_step(self, batch, batch_idx: int) -> torch.Tensor:
         from .models.sts.vae import kl_ps_uniform
         x = batch[0].to(self.model.c.device, non_blocking=True)
+        if self._flat is not None:
+            out = self._flat.step(x)
+            s = out['z'].sum(0, keepdim=True)
+            self._zsum = s if self._zsum is None else self._zsum + s
+            self._zn += out['z'].shape[0]
+            loss = self.phi * out['rec'] + self.beta * out['head'] + self.gamma * out['exp']
+            if batch_idx % 20 == 0:
+                loss_reg = self._flat.reg_loss()
+                self.log("loss", loss + float(getattr(self.args, "alpha", 0.0)) * loss_reg)
+                self.log("reconstruction_loss", out['rec']); self.log("kl_loss", out['head'])
+                self.log("exp_dist_loss", out['exp']); self.log("regularization", loss_reg)
+            return loss
         z, x_rec, (q, p, kappa) = self.model(x)
         with torch.no_grad():
             s = z.sum(0, keepdim=True)

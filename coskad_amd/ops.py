@@ -688,6 +688,19 @@ def prelu_bwd(u: Tensor, dout: Tensor, slope: Tensor, dslope: Optional[Tensor] =
     return du
 
 
+def rec_head(U: Tensor, x: Tensor, slope: Tensor, need_grad: bool = True, need_xrec: bool = False, dslope: Optional[Tensor] = None,
+             upstream: float = 1.0, accumulate: bool = False):
+    """-> (loss [1] = F.mse_loss(PReLU(U), x), dU or None, x_rec or None); dslope (+)= the slope gradient."""
+    _chk(U, "U"); _chk(x, "x", U.shape); _chk(slope, "slope", (1,)); _chk(dslope, "dslope", (1,), optional=True)
+    dU = torch.empty_like(U) if need_grad else None
+    xrec = torch.empty_like(U) if need_xrec else None
+    loss = torch.empty(1, device=U.device, dtype=torch.float32)
+    ws = torch.empty(2048, device=U.device, dtype=torch.float32)
+    call("coskad_rec_head_f32", ptr(U), ptr(x), ptr(slope), ptr(xrec), ptr(dU), ptr(loss), ptr(dslope if need_grad else None),
+         ctypes.c_float(upstream), ptr(ws), i32(1 if accumulate else 0), ctypes.c_size_t(U.numel()), _stream())
+    return loss, dU, xrec
+
+
 def gcn_bwd_params(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor):
     """(dA, dT) of ConvTemporalGraphical given its input and output gradient."""
     N, C, T, V = x.shape

@@ -223,6 +223,218 @@ class STSETrainStep:
         return self.model.c
 
 
+def _layer_grad_views(fp: "FlatParams", prefix: str) -> Dict[str, Tensor]:
+    """gradient views of one ST_GCNN layer (state_dict prefix `encoder.model.3.`) in the kernels' vocabulary"""
+    g = {"A": "gcn.A", "T": "gcn.T", "Wt": "tcn.0.weight", "bt": "tcn.0.bias", "gt": "tcn.1.weight", "bet": "tcn.1.bias",
+         "Wr": "residual.0.weight", "br": "residual.0.bias", "gr": "residual.1.weight", "ber": "residual.1.bias",
+         "slope": "prelu.weight"}
+    return {k: fp.gviews[prefix + n] for k, n in g.items() if prefix + n in fp.gviews}
+
+
+class _FlatStack:
+    """A stack of ST_GCNN layers (Encoder / Decoder `model`, components.py:70-105,143-179) on flat parameter / gradient
+    buffers: runs of layers the LDS tile kernels take go through engine.chain_forward / chain_backward (no autograd);
+    a layer beyond them (`is_wide`: 64 input channels on the 25-joint layout, > 64 channels, dropout) runs its composed
+    HIP path under a LOCAL autograd graph whose gradients are copied into the flat buffer."""
+
+    def __init__(self, modules, fp: "FlatParams", prefix: str) -> None:
+        self.segs = []                 # ('tile', [LayerTensors], [grad dicts]) | ('wide', module, names)
+        i, n = 0, len(modules)
+        while i < n:
+            if modules[i].is_wide:
+                self.segs.append(('wide', modules[i], f"{prefix}{i}."))
+                i += 1
+            else:
+                j = i
+                while j < n and not modules[j].is_wide:
+                    j += 1
+                self.segs.append(('tile', [layer_tensors(m) for m in modules[i:j]],
+                                  [_layer_grad_views(fp, f"{prefix}{k}.") for k in range(i, j)]))
+                i = j
+        self.fp = fp
+        self.last_slope_grad = fp.gviews[f"{prefix}{n - 1}.prelu.weight"] if self.segs[-1][0] == 'tile' else None
+
+    def forward(self, x: Tensor, ws: engine.Workspace):
+        """x: raw (activated) input -> (h, slope, saved): apply PReLU(slope) to h for the stack's output (slope None: done)."""
+        h, slope, saved = x, None, []
+        for seg in self.segs:
+            if seg[0] == 'tile':
+                u, ctx = engine.chain_forward(h, seg[1], True, ws, in_slope=slope, want_ctx=True)
+                saved.append(ctx)
+                h, slope = u, seg[1][-1].slope
+            else:
+                pre_u, pre_slope = (h, slope) if slope is not None else (None, None)
+                xin = (ops.prelu_fwd(h, slope) if slope is not None else h).detach().requires_grad_(True)
+                with torch.enable_grad():
+                    out = seg[1].forward_wide(xin)
+                saved.append((xin, out, pre_u, pre_slope))
+                h, slope = out.detach(), None
+        return h, slope, saved
+
+    def backward(self, saved, d_last: Tensor, ws: engine.Workspace, need_dx: bool) -> Optional[Tensor]:
+        """d_last: gradient w.r.t. the last segment's output (pre-activation U of a tile run -- the caller owns its slope
+        gradient -- or the activated output of a wide layer)."""
+        d = d_last
+        for k in range(len(self.segs) - 1, -1, -1):
+            seg, sv = self.segs[k], saved[k]
+            first = k == 0
+            if seg[0] == 'tile':
+                d = engine.chain_backward(sv, seg[1], d, ws, seg[2], need_dx=need_dx or not first)
+            else:
+                xin, out, pre_u, pre_slope = sv
+                mod, prefix = seg[1], seg[2]
+                named = [(n, p) for n, p in mod.named_parameters()]
+                want_x = need_dx or not first
+                res = torch.autograd.grad(out, ([xin] if want_x else []) + [p for _, p in named], d)
+                off = 1 if want_x else 0
+                for (n, _), g in zip(named, res[off:]):
+                    self.fp.gviews[prefix + n].copy_(g)
+                d = res[0] if want_x else None
+                if d is not None and pre_u is not None:
+                    # the wide layer consumed PReLU(pre_u): back through it, into the producing tile run's last slope
+                    prev = self.segs[k - 1]
+                    d = ops.prelu_bwd(pre_u, d.contiguous(), pre_slope, prev[2][-1]["slope"])
+        return d
+
+
+class STSAETrainStep:
+    """One optimisation step of the decoder models on flat parameter / gradient buffers with the fused Adam -- the
+    reference's training_step + optimizer step of
+
+      mode 'ae'  (models/euclidean_autoencoder.py:106-118): lambda_ * MSE(x_rec, x) + MSE(z, c) + alpha * reg
+      mode 'vae' (models/spherical_vae.py:81-107):          phi * MSE(x_rec, x) + alpha * reg + beta * KL(q || p) + gamma * mean(1 / kappa)
+
+    encoder -> bottleneck (one kernel pass; the VAE's mean | concentration heads stacked) -> [VAE: normalise, softplus + 1,
+    PowerSpherical rsample, KL: torch ops on [B, latent] tensors under a local autograd graph] -> rev_btlnk (MFMA GEMM) ->
+    decoder -> reconstruction head (PReLU of the last layer + MSE + its gradient in one kernel) -> everything backwards
+    through the same kernels.  Gradients land in the flat buffer; data-parallel all-reduce and Adam as in STSETrainStep."""
+
+    def __init__(self, model, mode: str = 'ae', lr: float = 1e-4, alpha: float = 0.0, lambda_: float = 0.01, phi: float = 1.0,
+                 beta: float = 1.0, gamma: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None) -> None:
+        from .models.sts.ae import STSAE
+        from .models.sts.vae import STSVAE
+        from .models.common.components import Encoder
+        if not isinstance(model, STSAE) or not isinstance(model.encoder, Encoder):
+            raise TypeError("STSAETrainStep drives an STSAE / STSVAE with the STS-GCN encoder")
+        if mode not in ('ae', 'vae') or (mode == 'vae') != isinstance(model, STSVAE):
+            raise ValueError(f"mode {mode!r} does not fit {type(model).__name__}")
+        self.model, self.mode = model, mode
+        self.alpha, self.lambda_, self.phi, self.beta, self.gamma = float(alpha), float(lambda_), float(phi), float(beta), float(gamma)
+        self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if not self.supports(model):
+            raise TypeError("STSAETrainStep: projector / latent size outside the bottleneck kernels (latent rows <= 16, "
+                            "'linear' projector)")
+        self.fp = FlatParams(model)
+        dev = self.fp.flat.device
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], device=dev, dtype=torch.float32)
+        self.ws = engine.Workspace()
+        self.enc = _FlatStack(list(model.encoder.model), self.fp, "encoder.model.")
+        self.dec = _FlatStack(list(model.decoder.model), self.fp, "decoder.model.")
+        self.center_acc = torch.zeros(ops.HEAD_SLOTS, device=dev, dtype=torch.float32)
+        self.reg_scale = 0.5 / self.fp.n_reg_tensors
+        self.reg_coef = self.alpha * 2.0 * self.reg_scale
+        self.steps = 0
+        self.last = {}
+
+    @staticmethod
+    def supports(model) -> bool:
+        from .models.sts.vae import STSVAE
+        if isinstance(model, STSVAE):
+            return isinstance(model.btlnk, torch.nn.Identity) and model.latent_dim + model.fc_var.out_features <= 16
+        return isinstance(model.btlnk, torch.nn.Linear) and model.latent_dim <= 16
+
+    def set_lr(self, lr: float) -> None:
+        self.hyper[0] = lr
+
+    def reg_loss(self) -> Tensor:
+        return ops.sqnorm(self.fp.flat, self.fp.reg_mask, self.reg_scale)
+
+    def step(self, x: Tensor) -> Dict[str, Tensor]:
+        """-> {'rec': F.mse_loss(x_rec, x), 'head': MSE(z, c) | KL, ('exp': mean(1 / kappa)), 'z': the latents}"""
+        self.steps += 1
+        m, gv = self.model, self.fp.gviews
+        x = x.contiguous()
+        B = x.shape[0]
+        T, V, hid = m.n_frames, m.n_joints, m.hidden_dimension
+        U, slope, enc_saved = self.enc.forward(x, self.ws)
+        if slope is None:              # the encoder ended in a wide layer: already activated
+            raise NotImplementedError("STSAETrainStep: an encoder ending in a wide layer")
+        out: Dict[str, Tensor] = {}
+        if self.mode == 'ae':
+            W, b, wname = m.btlnk.weight, m.btlnk.bias, "btlnk."
+            z = ops.btlnk_fwd(U, W, b, slope, ws=self.ws)
+            stats, dz, _ = ops.mse_head(z, m.c, acc=self.center_acc)              # MSE(z, c) and its gradient
+            out['head'] = stats[0:1]
+            z_dec, graph = z, None
+        else:
+            from .models.sts.vae import kl_ps_uniform
+            L = m.latent_dim
+            W = torch.cat([m.fc_mean.weight, m.fc_var.weight], 0)                 # heads stacked: one pass over U
+            b = torch.cat([m.fc_mean.bias, m.fc_var.bias], 0)
+            Hd = ops.btlnk_fwd(U, W, b, slope, ws=self.ws).requires_grad_(True)
+            with torch.enable_grad():                                             # [B, latent] tensors: vae.py:79-91,104-118
+                Z_mean, Z_var = m._finish_heads(Hd[:, :L], Hd[:, L:], None, False)
+                q, p = m.reparameterize(Z_mean, Z_var)
+                zs = q.rsample()
+                if m.distribution == 'normal':
+                    loss_kl = torch.distributions.kl.kl_divergence(q, p).sum(-1).mean()
+                else:
+                    loss_kl = kl_ps_uniform(q, p).mean()
+                loss_exp = (1 / Z_var).mean()
+                small = self.beta * loss_kl + self.gamma * loss_exp
+            out['head'], out['exp'] = loss_kl.detach().reshape(1), loss_exp.detach().reshape(1)
+            z_dec, graph = zs.detach().contiguous(), (Hd, zs, small)
+            dz = None
+        out['z'] = z_dec
+        # rev_btlnk (ae.py:223-227): H = z Wr^T + br on the strided MFMA GEMM, straight into the decoder's [B, hid, T, V] view
+        Wr, br = m.rev_btlnk.weight, m.rev_btlnk.bias
+        H = ops.gemm(z_dec, Wr.t(), bias=br, bias_mode=2)
+        Ud, dslope_d, dec_saved = self.dec.forward(H.view(B, hid, T, V), self.ws)
+        w_rec = self.lambda_ if self.mode == 'ae' else self.phi
+        if dslope_d is None:
+            raise NotImplementedError("STSAETrainStep: a decoder ending in a wide layer")
+        loss_rec, dUd, _ = ops.rec_head(Ud, x, dslope_d, dslope=self.dec.last_slope_grad, upstream=w_rec)
+        out['rec'] = loss_rec
+        # ---- backward ----------------------------------------------------------------------------------------------------
+        dH = self.dec.backward(dec_saved, dUd, self.ws, need_dx=True).reshape(B, -1)
+        # rev_btlnk: dWr = dH^T z, dbr = sum dH (one reduction over the batch with a ones column), dz += dH Wr
+        zs1 = torch.cat([z_dec, torch.ones(B, 1, device=z_dec.device)], 1)
+        gw = torch.empty(dH.shape[1], zs1.shape[1], device=dH.device, dtype=torch.float32)
+        ops.gemm_rows_outer(dH, zs1, gw)
+        gv["rev_btlnk.weight"].copy_(gw[:, :-1])
+        gv["rev_btlnk.bias"].copy_(gw[:, -1])
+        if self.mode == 'ae':
+            ops.gemm(dH, Wr, out=dz, accumulate=True)                             # dz = d MSE(z, c) + dH Wr
+            dHd = dz
+        else:
+            Hd, zs, small = graph
+            dz_dec = ops.gemm(dH, Wr)
+            dHd, = torch.autograd.grad([zs, small], [Hd], [dz_dec, torch.ones_like(small)])
+            dHd = dHd.contiguous()
+        K = W.shape[1]
+        buf = self.ws.get(ops.btlnk_bwd_ws_bytes(B, K, W.shape[0]), x.device)
+        if self.mode == 'ae':
+            dU = ops.btlnk_bwd(U, W, dHd, slope, gv["btlnk.weight"], gv.get("btlnk.bias"), self.enc.last_slope_grad, buf)
+        else:
+            gW = torch.empty_like(W)
+            gb = torch.empty_like(b)
+            dU = ops.btlnk_bwd(U, W, dHd, slope, gW, gb, self.enc.last_slope_grad, buf)
+            L = m.latent_dim
+            gv["fc_mean.weight"].copy_(gW[:L]); gv["fc_var.weight"].copy_(gW[L:])
+            gv["fc_mean.bias"].copy_(gb[:L]); gv["fc_var.bias"].copy_(gb[L:])
+        self.enc.backward(enc_saved, dU, self.ws, need_dx=False)
+        if self.world > 1:
+            dist.all_reduce(self.fp.grad, group=self.pg)                          # SUM; the 1 / W is folded into Adam
+        ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,
+                     self.beta2, self.eps, gscale=1.0 / self.world, reg_coef=self.reg_coef)
+        self.last = out
+        return out
+
+
 class AutogradTrainStep:
     """Same interface as STSETrainStep for models the flat-buffer fast path does not take: the `mlp` projector (what 5
     of the reference's 7 yamls select), the plain-GCN encoders, wide stacks.  Forward / backward go through the module

@@ -60,6 +60,12 @@ int coskad_prelu_fwd_f32(const float* u, const float* slope, float* out, size_t 
 int coskad_prelu_bwd_f32(const float* u, const float* dout, const float* slope, float* du, float* dslope,
                          float* ws, int accumulate, size_t n, hipStream_t stream);
 
+/* Reconstruction head of the decoder models: x_rec = PReLU_slope(U) (the last decoder layer's activation, stsgcn.py:110),
+ * loss[0] = F.mse_loss(x_rec, x) (euclidean_autoencoder.py:111, spherical_vae.py:90); dU (optional) = upstream * dloss/dU,
+ * dslope (optional, needs dU) (+)= upstream * dloss/dslope, xrec (optional) = the reconstruction.  ws: >= 2048 floats. */
+int coskad_rec_head_f32(const float* U, const float* x, const float* slope, float* xrec, float* dU, float* loss, float* dslope,
+                        float upstream, float* ws, int accumulate, size_t n, hipStream_t stream);
+
 /* ---- train-mode BatchNorm statistics -------------------------------------------------- */
 
 /* Bytes of scratch `ws` that coskad_layer_train_stats_f32 needs for C_in = Ci. */
