@@ -131,12 +131,18 @@ def main(tag: str) -> None:
                    "1/2 of a wide coalesced stream; narrower accesses uncalibrated: upper bound)"}
     for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2,1>"), ("bwd_fused layer4", "k_layer_bwd_fused<2,4>"),
                           ("bwd_fused layer3", "k_layer_bwd_fused<1,2>"), ("bwd_fused layer2", "k_layer_bwd_fused<2,1>"),
-                          ("layer_apply layer4", "k_layer_apply_ring<2,4,1>"), ("fused_encoder", "k_fused_encoder")):
+                          ("layer_apply layer4", "k_layer_apply_ring<2,4,1>"), ("fused_encoder", "k_fused_encoder"),
+                          ("bwd_stats layer4", "k_bwd_reduce_z<12,17,4,2>"), ("apply_next layer1", "k_layer_apply_next<0,2>"),
+                          ("apply_next layer2", "k_layer_apply_next<2,1>"), ("apply_next layer3", "k_layer_apply_next<1,2>")):
         b = biggest(prefix)
         if b:
             (k, lds, wg), (fe, wr, hbm) = b
             out[label] = {"kernel": k, "launch_slot_in_step": lds, "FETCH_SIZE_KB": round(fe, 1), "WRITE_SIZE_KB": round(wr, 1),
                           "hbm_bytes_per_launch": int(hbm)}
+    if "bwd_fused layer4" in out and "bwd_stats layer4" in out:
+        # bench.py's layer-level roofline: the two kernels that move layer 4's backward bytes (folds / partial-row sums: < 1 MB)
+        out["layer4 backward"] = {"kernels": [out["bwd_stats layer4"]["kernel"], out["bwd_fused layer4"]["kernel"]],
+                                  "hbm_bytes_per_launch": out["bwd_stats layer4"]["hbm_bytes_per_launch"] + out["bwd_fused layer4"]["hbm_bytes_per_launch"]}
     with open(f"{dst}/{tag}_hbm_traffic.json", "w") as f:
         json.dump(out, f, indent=1)
     print(open(f"{dst}/{tag}_kernel_instances.csv").read())
