@@ -28,33 +28,6 @@ using namespace ff;
 //           14        dA[t = j][16][16]           (r == 0, q == 0, j < 12)
 //           [15, 32)  dT[v][4q + r][j]            (v = record - 15; 4q + r < 12, j < 12)
 constexpr int PR_A = 0, PR_XA = 12, PR_XB = 13, PR_C = 14, PR_T = 15, PR_N = 32, EROW = PR_N * 256;
-constexpr int SPAT_F4 = T * 3 * 64;                  // float4 records of one spatial section
-constexpr int BTAB_F4 = 2 * TEMP_F4 + SPAT_F4;       // [forward temporal][adjoint spatial][adjoint temporal]
-
-// operand streams of one layer from its A [T,V,V] and T [V,T,T] (lane l: j = l & 15, q = l >> 4):
-//   forward temporal  rec[v][l][s]      = T[v][4s+q][j]          (j < 12)
-//   adjoint spatial   rec[t][l][0..4]   = A[t][j][4s+q]          (4s+q < 17),  [5..9] = A[t][16][4s+q]
-//   adjoint temporal  rec[v][l][s]      = T[v][j][4s+q]          (j < 12)
-__global__ void k_build_btab(const float* __restrict__ Aw, const float* __restrict__ Tw, float* __restrict__ tab) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= BTAB_F4 * 4) return;
-  float val = 0.f;
-  if (e < TEMP_F4 * 4 || e >= (TEMP_F4 + SPAT_F4) * 4) {
-    const bool adj = e >= TEMP_F4 * 4;
-    const int r = adj ? e - (TEMP_F4 + SPAT_F4) * 4 : e;
-    const int v = r / 256, l = (r >> 2) & 63, s = r & 3, j = l & 15, q = l >> 4;
-    if (s < 3 && j < T) val = adj ? Tw[v * T * T + j * T + 4 * s + q] : Tw[v * T * T + (4 * s + q) * T + j];
-  } else {
-    const int r = e - TEMP_F4 * 4;
-    const int t = r / (3 * 256), c = (r / 256) % 3, l = (r >> 2) & 63, k = 4 * c + (r & 3), j = l & 15, q = l >> 4;
-    if (k < 10) {
-      const int s = k < 5 ? k : k - 5, w = 4 * s + q;
-      if (w < V) val = Aw[t * V * V + (k < 5 ? j : 16) * V + w];
-    }
-  }
-  tab[e] = val;
-}
-
 // dA, dT (+)= sum over the P lane-major partial rows (fp64, fixed order); one extra block sums the slope partials
 __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__ partials, int P, float* __restrict__ dA,
                                                        float* __restrict__ dT, const float* __restrict__ dap, int ndap,
@@ -498,9 +471,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
 int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
                            const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
                            float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out) {
-  hipLaunchKernelGGL(fb::k_build_btab, dim3(ceil_div(fb::BTAB_F4 * 4, 256)), dim3(256), 0, st, Aw, Tw, btab);
-  int rc;
-  if ((rc = check_launch("bwd_build_btab"))) return rc;
+  // (btab: built from Aw / Tw by the extra blocks of the fold launch, stsgcn_bwd.hip)
   const size_t lds = (size_t)4 * ff::WAVE_LDS_W * sizeof(float);
   const int nblk = (B + 3) / 4;
 #ifndef FB_GRID

@@ -233,5 +233,30 @@ __device__ __forceinline__ f32x4 tile_load(const float* img, int row0, int pos, 
   return f32x4{p[0], p[LD], p[2 * LD], p[3 * LD]};
 }
 
+// ---- operand tables of the fused layer backward (fused_bwd.hip) from a layer's A [T,V,V] and T [V,T,T] --------------------
+// (lane l: j = l & 15, q = l >> 4):
+//   forward temporal  rec[v][l][s]      = T[v][4s+q][j]          (j < 12)
+//   adjoint spatial   rec[t][l][0..4]   = A[t][j][4s+q]          (4s+q < 17),  [5..9] = A[t][16][4s+q]
+//   adjoint temporal  rec[v][l][s]      = T[v][j][4s+q]          (j < 12)
+constexpr int SPAT_F4 = T * 3 * 64;                  // float4 records of one spatial section
+constexpr int BTAB_F4 = 2 * TEMP_F4 + SPAT_F4;       // [forward temporal][adjoint spatial][adjoint temporal]
+__device__ __forceinline__ float btab_value(const float* __restrict__ Aw, const float* __restrict__ Tw, int e) {
+  float val = 0.f;
+  if (e < TEMP_F4 * 4 || e >= (TEMP_F4 + SPAT_F4) * 4) {
+    const bool adj = e >= TEMP_F4 * 4;
+    const int r = adj ? e - (TEMP_F4 + SPAT_F4) * 4 : e;
+    const int v = r / 256, l = (r >> 2) & 63, s = r & 3, j = l & 15, q = l >> 4;
+    if (s < 3 && j < T) val = adj ? Tw[v * T * T + j * T + 4 * s + q] : Tw[v * T * T + (4 * s + q) * T + j];
+  } else {
+    const int r = e - TEMP_F4 * 4;
+    const int t = r / (3 * 256), c = (r / 256) % 3, l = (r >> 2) & 63, k = 4 * c + (r & 3), j = l & 15, q = l >> 4;
+    if (k < 10) {
+      const int s = k < 5 ? k : k - 5, w = 4 * s + q;
+      if (w < V) val = Aw[t * V * V + (k < 5 ? j : 16) * V + w];
+    }
+  }
+  return val;
+}
+
 }  // namespace ff
 }  // namespace coskad

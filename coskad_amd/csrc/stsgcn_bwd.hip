@@ -22,6 +22,7 @@
 //  4. k_bwd_gcn_params : dA[t,v,w] = sum_rows Y[t,v] dZ[t,w],  dT[v,t,q] = sum_rows X[t,v] dY[q,v]
 //                    (GEMMs with K = rows (clip,channel) -> MFMA f32).
 #include "mfma_ops.h"
+#include "fused_ops.h"
 #include <cstdlib>
 
 namespace coskad {
@@ -284,116 +285,198 @@ __host__ __device__ inline int coef_floats(int Ci, int Co) {
 
 __device__ __forceinline__ void put(float* dst, float v, int accumulate) { *dst = accumulate ? *dst + v : v; }
 
+#ifdef COSKAD_FOLD_TIMING   // timing-only build (tools/time_fold.py): wall-clock stamps (100 MHz) of thread 0 at the fold's phase boundaries
+__device__ long long g_fold_stamps[16];
+#define FOLD_STAMP(k) do { if (threadIdx.x == 0) g_fold_stamps[k] = wall_clock64(); } while (0)
+#else
+#define FOLD_STAMP(k) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(1024) void k_bwd_fold(
     const double* __restrict__ red, double npos, const float* __restrict__ stat,
     const float* __restrict__ Wt, const float* __restrict__ gs, const float* __restrict__ Wr,
     const float* __restrict__ gr, float* __restrict__ dWt, float* __restrict__ dbt,
     float* __restrict__ dgs, float* __restrict__ dbs, float* __restrict__ dWr, float* __restrict__ dbr,
     float* __restrict__ dgr, float* __restrict__ dbr2, float* __restrict__ coef, int Ci, int Co,
-    int accumulate) {
-  // LDS: doubles k2[2][Co], g1[2][Co], h[2][Co] (h = g1 sdU/n - k2 (W.mu)), red[E]; floats W[2][Co*Ci], mu[2][Ci]
+    int accumulate, const float* __restrict__ Aw, const float* __restrict__ Tw, float* __restrict__ btab, int NF) {
+  // blocks NF..: the operand tables of the fused data kernel (fused_bwd.hip) from this layer's A / T -- parameter-only work
+  // that rides in this launch instead of standing between the fold and the data kernel as a launch of its own
+  if ((int)blockIdx.x >= NF) {
+    const int e0 = (blockIdx.x - NF) * blockDim.x + threadIdx.x;
+    for (int e = e0; e < ff::BTAB_F4 * 4; e += (gridDim.x - NF) * blockDim.x) btab[e] = ff::btab_value(Aw, Tw, e);
+    return;
+  }
+  // Blocks 0..NF-1: the fold.  One global round trip at the start (every input goes to LDS), then LDS-only phases.  Every
+  // block forms the per-channel quantities of ALL channels (the K matrices and constants sum over them), then writes its
+  // slice of the outputs: output channels [o_lo, o_hi) of the parameter gradients and coefficient rows, a slice of the
+  // (c, c') pairs of the K matrices (formed from W k2 kept as doubles: one DFMA per term; symmetric: c' >= c only).
+  // LDS: doubles k2[2][Co], g1[2][Co], h[2][Co], red[E] (its P / Q part becomes W k2 once the weight gradients are out);
+  //      floats W[2][Co*Ci], WC[2][Co*Ci], mu[2][Ci], istd[2][Co], gamma[2][Co]
   extern __shared__ double shd[];
   const bool ident = Wr == nullptr;
   const int CiP = round_up(Ci, 16);
   const int E = 2 * Co * Ci + Co;
-  const float* WCs = stat + 2 * Ci;
-  const float* WCr = WCs + Co * Ci;
-  const float* istd_s = WCr + Co * Ci + Co;
-  const float* istd_r = istd_s + 2 * Co;
+  const int CC = Co * Ci;
   double* k2 = shd;            // [2][Co]
   double* g1 = shd + 2 * Co;   // [2][Co]
   double* hh = shd + 4 * Co;   // [2][Co]
-  double* redl = shd + 6 * Co; // [E]: the fp64 batch reductions, staged once (the loops below walk them row-wise)
-  const double* P = redl;
-  const double* Q = redl + Co * Ci;
-  const double* sdU = redl + 2 * Co * Ci;
+  double* redl = shd + 6 * Co; // [E]
+  double* P = redl;
+  double* Q = redl + CC;
+  const double* sdU = redl + 2 * CC;
   float* Wl = reinterpret_cast<float*>(redl + E);      // [2][Co*Ci]
-  float* mul = Wl + 2 * Co * Ci;                       // [2][Ci]: muZ then muX
+  float* WCl = Wl + 2 * CC;                            // [2][Co*Ci]: Wt C_Z, Wr C_X (saved by the forward fold)
+  float* mul = WCl + 2 * CC;                           // [2][Ci]: muZ then muX
+  float* isl = mul + 2 * Ci;                           // [2][Co]: istd_s, istd_r
+  float* gml = isl + 2 * Co;                           // [2][Co]: gamma_s, gamma_r
   float* wDZ = coef;
   float* kt = wDZ + (Co + Ci) * CiP;
   float* wDX = kt + CiP;
   float* kr = wDX + (Co + Ci) * CiP;
+  const float* WCs = stat + 2 * Ci;
+  const float* istd_s = WCs + 2 * CC + Co;
+  const float* istd_r = istd_s + 2 * Co;
+  const int chunk = (Co + NF - 1) / NF;
+  const int o_lo = blockIdx.x * chunk, o_hi = min(Co, o_lo + chunk);
 
+  FOLD_STAMP(0);
   for (int i = threadIdx.x; i < E; i += blockDim.x) redl[i] = red[i];
-  for (int i = threadIdx.x; i < Co * Ci; i += blockDim.x) {
+  for (int i = threadIdx.x; i < CC; i += blockDim.x) {
     Wl[i] = Wt[i];
-    Wl[Co * Ci + i] = ident ? 0.f : Wr[i];
+    Wl[CC + i] = ident ? 0.f : Wr[i];
+    WCl[i] = WCs[i];
+    WCl[CC + i] = WCs[CC + i];
   }
   for (int i = threadIdx.x; i < Ci; i += blockDim.x) {
     mul[i] = stat[Ci + i];   // muZ (branch 0)
     mul[Ci + i] = stat[i];   // muX (branch 1)
   }
-  __syncthreads();
-  // per-channel BN gradients
-  for (int i = threadIdx.x; i < 2 * Co; i += blockDim.x) {
-    const int b = i / Co, o = i - b * Co;
-    if (b == 1 && ident) { k2[i] = 0.0; g1[i] = 1.0; hh[i] = 0.0; continue; }
-    const float* W = Wl + b * Co * Ci + o * Ci;
-    const double* M = (b ? Q : P) + o * Ci;
-    const float* mu = mul + b * Ci;
-    const double istd = (double)(b ? istd_r : istd_s)[o];
-    const double gamma = (double)(b ? gr : gs)[o];
-    double wp = 0.0, wmu = 0.0;
-    for (int c = 0; c < Ci; ++c) {
-      wp += (double)W[c] * M[c];
-      wmu += (double)W[c] * (double)mu[c];
-    }
-    const double sdus = wp - wmu * sdU[o];       // sum dU * (conv_out - mean)
-    const double dgamma = istd * sdus;
-    put((b ? dgr : dgs) + o, (float)dgamma, accumulate);
-    put((b ? dbr2 : dbs) + o, (float)sdU[o], accumulate);
-    float* dbias = b ? dbr : dbt;
-    if (dbias) put(dbias + o, 0.f, accumulate);  // conv bias in front of a train-mode BN: exactly 0
-    const double g = gamma * istd;
-    const double kk = g * dgamma * istd / npos;
-    g1[i] = g;
-    k2[i] = kk;
-    hh[i] = g * sdU[o] / npos - kk * wmu;
+  for (int i = threadIdx.x; i < Co; i += blockDim.x) {
+    isl[i] = istd_s[i];
+    isl[Co + i] = ident ? 1.f : istd_r[i];
+    gml[i] = gs[i];
+    gml[Co + i] = ident ? 1.f : gr[i];
   }
   __syncthreads();
+  FOLD_STAMP(1);
+  // per-channel BN gradients: 8 lanes per (branch, channel), each sums every 8th input channel, then a fixed-order tree
+  for (int i0 = 0; i0 < 2 * Co; i0 += blockDim.x / 8) {
+    const int i = i0 + (threadIdx.x >> 3), l8 = threadIdx.x & 7;
+    const bool live = i < 2 * Co;
+    const int b = live ? i / Co : 0, o = live ? i - b * Co : 0;
+    double wp = 0.0, wmu = 0.0;
+    if (live && !(b == 1 && ident)) {
+      const float* W = Wl + b * CC + o * Ci;
+      const double* M = (b ? Q : P) + o * Ci;
+      const float* mu = mul + b * Ci;
+      for (int c = l8; c < Ci; c += 8) {
+        const double w = (double)W[c];
+        wp += w * M[c];
+        wmu += w * (double)mu[c];
+      }
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+      wp += __shfl_xor(wp, off, 8);
+      wmu += __shfl_xor(wmu, off, 8);
+    }
+    if (live && l8 == 0) {
+      if (b == 1 && ident) { k2[i] = 0.0; g1[i] = 1.0; hh[i] = 0.0; }
+      else {
+        const double istd = (double)isl[i];
+        const double gamma = (double)gml[i];
+        const double sdus = wp - wmu * sdU[o];       // sum dU * (conv_out - mean)
+        const double dgamma = istd * sdus;
+        if (o >= o_lo && o < o_hi) {                 // (this block's output channels)
+          put((b ? dgr : dgs) + o, (float)dgamma, accumulate);
+          put((b ? dbr2 : dbs) + o, (float)sdU[o], accumulate);
+          float* dbias = b ? dbr : dbt;
+          if (dbias) put(dbias + o, 0.f, accumulate);  // conv bias in front of a train-mode BN: exactly 0
+        }
+        const double g = gamma * istd;
+        const double kk = g * dgamma * istd / npos;
+        g1[i] = g;
+        k2[i] = kk;
+        hh[i] = g * sdU[o] / npos - kk * wmu;
+      }
+    }
+  }
+  __syncthreads();
+  FOLD_STAMP(2);
   // conv weight gradients: dW[o,c] = g1 (M[o,c] - sdU[o] mu[c]) - k2 * n * WC[o,c]
-  for (int i = threadIdx.x; i < 2 * Co * Ci; i += blockDim.x) {
-    const int b = i / (Co * Ci);
+  const int no = max(0, o_hi - o_lo);
+  for (int ii = threadIdx.x; ii < 2 * no * Ci; ii += blockDim.x) {
+    const int b = ii / (no * Ci);
     if (b == 1 && ident) break;
-    const int j = i - b * Co * Ci, o = j / Ci, c = j - o * Ci;
+    const int j = o_lo * Ci + ii - b * no * Ci, o = j / Ci, c = j - o * Ci;
     const double* M = b ? Q : P;
-    const float* WC = b ? WCr : WCs;
-    const double v = g1[b * Co + o] * (M[j] - sdU[o] * (double)mul[b * Ci + c]) - k2[b * Co + o] * npos * (double)WC[j];
+    const double v = g1[b * Co + o] * (M[j] - sdU[o] * (double)mul[b * Ci + c]) - k2[b * Co + o] * npos * (double)WCl[b * CC + j];
     put((b ? dWr : dWt) + j, (float)v, accumulate);
   }
-  // data-path coefficients.  rows 0..Co-1: B[c][o] = g1[o] W[o,c];  rows Co..: K[c][c'] = -sum_o W[o,c] k2[o] W[o,c']
-  for (int i = threadIdx.x; i < 2 * (Co + Ci) * CiP; i += blockDim.x) {
-    const int b = i / ((Co + Ci) * CiP);
-    const int j = i - b * (Co + Ci) * CiP;
+  // data-path coefficients, rows 0..Co-1: B[c][o] = g1[o] W[o,c]
+  for (int ii = threadIdx.x; ii < 2 * no * CiP; ii += blockDim.x) {
+    const int b = ii / (no * CiP);
+    const int j = o_lo * CiP + ii - b * no * CiP;
     const int row = j / CiP, c = j - row * CiP;
-    const float* W = Wl + b * Co * Ci;
     float v = 0.f;
     if (c < Ci) {
-      if (b == 1 && ident) {
-        v = (row < Co && row == c) ? 1.f : 0.f;
-      } else if (row < Co) {
-        v = (float)(g1[b * Co + row] * (double)W[row * Ci + c]);
-      } else {
-        const int c2 = row - Co;
-        double acc = 0.0;
-        for (int o = 0; o < Co; ++o) acc += (double)W[o * Ci + c] * k2[b * Co + o] * (double)W[o * Ci + c2];
-        v = (float)(-acc);
-      }
+      if (b == 1 && ident) v = row == c ? 1.f : 0.f;
+      else v = (float)(g1[b * Co + row] * (double)Wl[b * CC + row * Ci + c]);
     }
     (b ? wDX : wDZ)[j] = v;
   }
-  // constants: k[c] = -sum_o W[o,c] (g1[o] sdU[o]/n - k2[o] (W[o] . mu)) = -sum_o W[o,c] h[o]
-  for (int i = threadIdx.x; i < 2 * CiP; i += blockDim.x) {
-    const int b = i / CiP, c = i - b * CiP;
+  __syncthreads();
+  FOLD_STAMP(3);
+  // W k2 as doubles over the dead P / Q sums
+  for (int i = threadIdx.x; i < 2 * CC; i += blockDim.x) {
+    const int b = i / CC, j = i - b * CC, o = j / Ci;
+    redl[i] = (double)Wl[i] * k2[b * Co + o];
+  }
+  __syncthreads();
+  // rows Co..: K[c][c'] = -sum_o W[o,c] k2[o] W[o,c'] (symmetric: formed for c' >= c, written to both places); padding columns 0
+  const int tri = Ci * (Ci + 1) / 2;
+  const int tchunk = (2 * tri + NF - 1) / NF;
+  const int t_hi = min(2 * tri, ((int)blockIdx.x + 1) * tchunk);
+  for (int i = blockIdx.x * tchunk + threadIdx.x; i < t_hi; i += blockDim.x) {
+    const int b = i / tri;
+    int r = i - b * tri, c = 0;
+    while (r >= Ci - c) { r -= Ci - c; ++c; }
+    const int c2 = c + r;
     float v = 0.f;
-    if (c < Ci && !(b == 1 && ident)) {
-      const float* W = Wl + b * Co * Ci;
+    if (!(b == 1 && ident)) {
+      const double* Wk = redl + b * CC;
+      const float* W = Wl + b * CC;
       double acc = 0.0;
-      for (int o = 0; o < Co; ++o) acc += (double)W[o * Ci + c] * hh[b * Co + o];
+      for (int o = 0; o < Co; ++o) acc += Wk[o * Ci + c] * (double)W[o * Ci + c2];
       v = (float)(-acc);
     }
-    (b ? kr : kt)[c] = v;
+    float* dst = b ? wDX : wDZ;
+    dst[(Co + c2) * CiP + c] = v;
+    dst[(Co + c) * CiP + c2] = v;
   }
+  if (CiP > Ci && blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < 2 * Ci * (CiP - Ci); i += blockDim.x) {
+      const int b = i / (Ci * (CiP - Ci)), j = i - b * Ci * (CiP - Ci);
+      const int row = j / (CiP - Ci), c = Ci + j - row * (CiP - Ci);
+      (b ? wDX : wDZ)[(Co + row) * CiP + c] = 0.f;
+    }
+  }
+  FOLD_STAMP(4);
+  // constants: k[c] = -sum_o W[o,c] (g1[o] sdU[o]/n - k2[o] (W[o] . mu)) = -sum_o W[o,c] h[o]   (the last fold block)
+  if ((int)blockIdx.x == NF - 1) {
+    for (int i = threadIdx.x; i < 2 * CiP; i += blockDim.x) {
+      const int b = i / CiP, c = i - b * CiP;
+      float v = 0.f;
+      if (c < Ci && !(b == 1 && ident)) {
+        const float* W = Wl + b * CC;
+        double acc = 0.0;
+        for (int o = 0; o < Co; ++o) acc += (double)W[o * Ci + c] * hh[b * Co + o];
+        v = (float)(-acc);
+      }
+      (b ? kr : kt)[c] = v;
+    }
+  }
+  FOLD_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1323,13 +1406,17 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     }
   }
   // 2. fold
-  const size_t fold_lds = (size_t)(6 * Co + 2 * Co * Ci + Co) * sizeof(double) + (size_t)(2 * Co * Ci + 2 * Ci) * sizeof(float);
+  const size_t fold_lds = (size_t)(6 * Co + 2 * Co * Ci + Co) * sizeof(double) + (size_t)(4 * Co * Ci + 2 * Ci + 4 * Co) * sizeof(float);
   if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_bwd_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
-  hipLaunchKernelGGL(k_bwd_fold, dim3(1), dim3(1024), fold_lds, st, w.red, (double)B * TV, stat,
-                     Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate);
+  const bool fused = Zg && dIn && in_slope && !dz_ext && layer_bwd_fused_ok(T, V, Ci, Co);
+  // the fused data kernel's operand tables are built by extra blocks of the fold launch (parameter-only work)
+  const int tab_blocks = fused ? ceil_div(ff::BTAB_F4 * 4, 1024) : 0;
+  const int NF = Co >= 32 ? 8 : (Co >= 16 ? 4 : 1);          // fold blocks (slices of the output channels / K pairs)
+  hipLaunchKernelGGL(k_bwd_fold, dim3(NF + tab_blocks), dim3(1024), fold_lds, st, w.red, (double)B * TV, stat,
+                     Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate, Aw, Tw, w.btab, NF);
   if ((rc = check_launch("bwd_fold"))) return rc;
   // 3 + 4 in one kernel (fused_bwd.hip) for the stored-Z path at the shapes it is built for: dZ never leaves the CU
-  if (Zg && dIn && in_slope && !dz_ext && layer_bwd_fused_ok(T, V, Ci, Co)) {
+  if (fused) {
     int rows = 0;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
     if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows)))
@@ -1565,5 +1652,9 @@ int coskad_layer_gcn_params_f32(const float* in, const float* in_slope, const fl
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }
+
+#ifdef COSKAD_FOLD_TIMING
+int coskad_debug_fold_stamps(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(coskad::g_fold_stamps), 16 * sizeof(long long)); }
+#endif
 
 }  // extern "C"

@@ -97,6 +97,13 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restric
 //   [muX Ci][muZ Ci][WCs Co*Ci = Wt C_Z][WCr Co*Ci = Wr C_X][mean_s Co][istd_s Co][mean_r Co][istd_r Co]
 __host__ __device__ inline int stat_floats(int Ci, int Co) { return 2 * Ci + 2 * Co * Ci + 4 * Co; }
 
+#ifdef COSKAD_FOLD_TIMING   // timing-only build (tools/time_fold.py)
+__device__ long long g_tfold_stamps[16];
+#define TFOLD_STAMP(k) do { if (threadIdx.x == 0) g_tfold_stamps[k] = wall_clock64(); } while (0)
+#else
+#define TFOLD_STAMP(k) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(1024) void k_train_fold(
     const double* __restrict__ red, double npos, const float* __restrict__ Wt,
     const float* __restrict__ bt, const float* __restrict__ gs, const float* __restrict__ bs,
@@ -105,13 +112,19 @@ __global__ __launch_bounds__(1024) void k_train_fold(
     const float* __restrict__ brr, float* __restrict__ rm_r, float* __restrict__ rv_r,
     long long* __restrict__ nbt_r, float momentum, float* __restrict__ wfold,
     float* __restrict__ bias, float* __restrict__ stat, int Ci, int Co, int CoP) {
-  // LDS: doubles C[2][Ci*Ci] (centred covariances: Z then X), mu[2][Ci]; floats W[2][Co*Ci], WC[2][Co*Ci]
+  // One block, VALU-bound on fp64 and latency-bound on its global round trips: every input is read once at the start, the
+  // phases exchange through LDS only (the stat block is written along the way, never read back), W C is register-blocked
+  // (4 columns per thread: one conversion of W[o][k] per four DFMAs), per-channel sums use 8 lanes per channel.
+  // LDS: doubles C[2][Ci*Ci] (centred covariances: Z then X), mu[2][Ci]; floats W[2][Co*Ci], WC[2][Co*Ci], mean[2][Co], istd[2][Co]
   extern __shared__ double shd[];
   const bool ident = Wr == nullptr;
+  const int CC = Co * Ci;
   double* Cl = shd;                       // [2][Ci*Ci]
   double* mul = shd + 2 * Ci * Ci;        // [2][Ci]
   float* Wl = reinterpret_cast<float*>(mul + 2 * Ci);   // [2][Co*Ci]
-  float* WCl = Wl + 2 * Co * Ci;                        // [2][Co*Ci]
+  float* WCl = Wl + 2 * CC;                             // [2][Co*Ci]
+  float* meanl = WCl + 2 * CC;                          // [2][Co]
+  float* istdl = meanl + 2 * Co;                        // [2][Co]
   const double* MX = red;
   const double* SX = red + Ci * Ci;
   const double* MZ = red + Ci * Ci + Ci;
@@ -119,23 +132,28 @@ __global__ __launch_bounds__(1024) void k_train_fold(
   float* muX = stat;
   float* muZ = stat + Ci;
   float* WCs = stat + 2 * Ci;
-  float* WCr = WCs + Co * Ci;
-  float* mean_s = WCr + Co * Ci;
+  float* WCr = WCs + CC;
+  float* mean_s = WCr + CC;
   float* istd_s = mean_s + Co;
   float* mean_r = istd_s + Co;
   float* istd_r = mean_r + Co;
   const double inv_n = 1.0 / npos;
+  // every block folds a contiguous slice of the output channels (everything the fold produces is per output channel once
+  // the Ci x Ci covariances are known, which each block forms for itself): the fp64 work spreads over several CUs
+  const int chunk = (Co + gridDim.x - 1) / gridDim.x;
+  const int o_lo = blockIdx.x * chunk, o_hi = min(Co, o_lo + chunk), no = max(0, o_hi - o_lo);
+  const bool first = blockIdx.x == 0;
 
+  TFOLD_STAMP(0);
   for (int c = threadIdx.x; c < Ci; c += blockDim.x) {
     const double mz = SZ[c] * inv_n, mx = SX[c] * inv_n;
     mul[c] = mz;
     mul[Ci + c] = mx;
-    muZ[c] = (float)mz;
-    muX[c] = (float)mx;
+    if (first) { muZ[c] = (float)mz; muX[c] = (float)mx; }
   }
-  for (int i = threadIdx.x; i < Co * Ci; i += blockDim.x) {
+  for (int i = threadIdx.x; i < CC; i += blockDim.x) {
     Wl[i] = Wt[i];
-    Wl[Co * Ci + i] = ident ? 0.f : Wr[i];
+    Wl[CC + i] = ident ? 0.f : Wr[i];
   }
   for (int i = threadIdx.x; i < Ci * Ci; i += blockDim.x) {
     const int k = i / Ci, c = i - k * Ci;
@@ -143,69 +161,116 @@ __global__ __launch_bounds__(1024) void k_train_fold(
     Cl[Ci * Ci + i] = ident ? 0.0 : MX[i] * inv_n - (SX[k] * inv_n) * (SX[c] * inv_n);
   }
   __syncthreads();
-  // WC[o][c] = sum_k W[o][k] C[k][c]   (fp64 accumulate)
-  for (int i = threadIdx.x; i < 2 * Co * Ci; i += blockDim.x) {
-    const int b = i / (Co * Ci);
-    const int j = i - b * Co * Ci;
-    const int o = j / Ci, c = j - o * Ci;
-    double acc = 0.0;
+  TFOLD_STAMP(1);
+  // WC[o][c] = sum_k W[o][k] C[k][c]   (fp64 accumulate), four consecutive columns per thread
+  const int Cq = (Ci + 3) / 4;
+  for (int i = threadIdx.x; i < 2 * no * Cq; i += blockDim.x) {
+    const int b = i / (no * Cq);
+    const int j = i - b * no * Cq;
+    const int o = o_lo + j / Cq, c0 = 4 * (j % Cq);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (!(b == 1 && ident)) {
-      const float* W = Wl + b * Co * Ci + o * Ci;
-      const double* C = Cl + b * Ci * Ci + c;
-      for (int k = 0; k < Ci; ++k) acc += (double)W[k] * C[k * Ci];
+      const float* W = Wl + b * CC + o * Ci;
+      const double* C = Cl + b * Ci * Ci + c0;
+      if (c0 + 3 < Ci) {
+        for (int k = 0; k < Ci; ++k) {
+          const double w = (double)W[k];
+          const double* r = C + k * Ci;
+          a0 += w * r[0]; a1 += w * r[1]; a2 += w * r[2]; a3 += w * r[3];
+        }
+      } else {
+        for (int k = 0; k < Ci; ++k) {
+          const double w = (double)W[k];
+          const double* r = C + k * Ci;
+          a0 += w * r[0];
+          if (c0 + 1 < Ci) a1 += w * r[1];
+          if (c0 + 2 < Ci) a2 += w * r[2];
+        }
+      }
     }
-    WCl[i] = (float)acc;
-    (b ? WCr : WCs)[j] = (float)acc;
+    const double acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c0 + u < Ci) {
+        const int e = b * CC + o * Ci + c0 + u;
+        WCl[e] = (float)acc[u];
+        (b ? WCr : WCs)[o * Ci + c0 + u] = (float)acc[u];
+      }
   }
   __syncthreads();
+  TFOLD_STAMP(2);
   const double unbias = npos > 1.0 ? npos / (npos - 1.0) : 1.0;
-  for (int i = threadIdx.x; i < 2 * Co; i += blockDim.x) {
-    const int b = i / Co, o = i - b * Co;
-    if (b == 1 && ident) { mean_r[o] = 0.f; istd_r[o] = 1.f; continue; }
-    const float* W = Wl + b * Co * Ci + o * Ci;
-    const float* WC = WCl + b * Co * Ci + o * Ci;
-    const float* bb = b ? br : bt;
-    double m = bb ? (double)bb[o] : 0.0, var = 0.0;
-    for (int k = 0; k < Ci; ++k) {
-      m += (double)W[k] * mul[b * Ci + k];
-      var += (double)W[k] * (double)WC[k];
+  // per-channel statistics: 8 lanes per (branch, channel), fixed-order tree
+  for (int i0 = 0; i0 < 2 * no; i0 += blockDim.x / 8) {
+    const int ii = i0 + (threadIdx.x >> 3), l8 = threadIdx.x & 7;
+    const bool live = ii < 2 * no;
+    const int b = live ? ii / no : 0, o = live ? o_lo + ii - b * no : 0;
+    const int i = b * Co + o;
+    double m = 0.0, var = 0.0;
+    if (live && !(b == 1 && ident)) {
+      const float* W = Wl + b * CC + o * Ci;
+      const float* WC = WCl + b * CC + o * Ci;
+      for (int k = l8; k < Ci; k += 8) {
+        const double w = (double)W[k];
+        m += w * mul[b * Ci + k];
+        var += w * (double)WC[k];
+      }
     }
-    var = var > 0.0 ? var : 0.0;
-    (b ? mean_r : mean_s)[o] = (float)m;
-    (b ? istd_r : istd_s)[o] = (float)(1.0 / sqrt(var + (double)kBnEps));
-    float* rm = b ? rm_r : rm_s;
-    float* rv = b ? rv_r : rv_s;
-    if (rm) {  // nn.BatchNorm2d: running = (1-m) running + m batch ; unbiased variance
-      rm[o] = (1.f - momentum) * rm[o] + momentum * (float)m;
-      rv[o] = (1.f - momentum) * rv[o] + momentum * (float)(var * unbias);
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+      m += __shfl_xor(m, off, 8);
+      var += __shfl_xor(var, off, 8);
+    }
+    if (live && l8 == 0) {
+      if (b == 1 && ident) { mean_r[o] = 0.f; istd_r[o] = 1.f; meanl[i] = 0.f; istdl[i] = 1.f; }
+      else {
+        const float* bb = b ? br : bt;
+        m += bb ? (double)bb[o] : 0.0;
+        var = var > 0.0 ? var : 0.0;
+        const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)kBnEps));
+        (b ? mean_r : mean_s)[o] = mf;
+        (b ? istd_r : istd_s)[o] = isf;
+        meanl[i] = mf;
+        istdl[i] = isf;
+        float* rm = b ? rm_r : rm_s;
+        float* rv = b ? rv_r : rv_s;
+        if (rm) {  // nn.BatchNorm2d: running = (1-m) running + m batch ; unbiased variance
+          rm[o] = (1.f - momentum) * rm[o] + momentum * (float)m;
+          rv[o] = (1.f - momentum) * rv[o] + momentum * (float)(var * unbias);
+        }
+      }
     }
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && first) {
     if (nbt_s) nbt_s[0] += 1;
     if (nbt_r && !ident) nbt_r[0] += 1;
   }
   __syncthreads();
-  // folded weights: U = Wz Z + Wx X + b
-  for (int i = threadIdx.x; i < 2 * Ci * CoP; i += blockDim.x) {
-    const int row = i / CoP, o = i - row * CoP;
+  TFOLD_STAMP(3);
+  // folded weights: U = Wz Z + Wx X + b   (this block's columns; the last block also zeroes the padding columns)
+  const bool last = blockIdx.x == gridDim.x - 1;
+  const int w_hi = last ? CoP : min(o_lo + chunk, CoP), nw = max(0, w_hi - o_lo);
+  for (int i = threadIdx.x; i < 2 * Ci * nw; i += blockDim.x) {
+    const int row = i / nw, o = o_lo + i - row * nw;
     float w = 0.f;
     if (o < Co) {
-      if (row < Ci) w = gs[o] * istd_s[o] * Wl[o * Ci + row];
+      if (row < Ci) w = gs[o] * istdl[o] * Wl[o * Ci + row];
       else {
         const int c = row - Ci;
-        w = ident ? (c == o ? 1.f : 0.f) : gr[o] * istd_r[o] * Wl[Co * Ci + o * Ci + c];
+        w = ident ? (c == o ? 1.f : 0.f) : gr[o] * istdl[Co + o] * Wl[CC + o * Ci + c];
       }
     }
-    wfold[i] = w;
+    wfold[row * CoP + o] = w;
   }
-  for (int o = threadIdx.x; o < CoP; o += blockDim.x) {
+  for (int o = o_lo + threadIdx.x; o < w_hi; o += blockDim.x) {
     float b = 0.f;
     if (o < Co) {
-      b = bs[o] + gs[o] * istd_s[o] * ((bt ? bt[o] : 0.f) - mean_s[o]);
-      if (!ident) b += brr[o] + gr[o] * istd_r[o] * ((br ? br[o] : 0.f) - mean_r[o]);
+      b = bs[o] + gs[o] * istdl[o] * ((bt ? bt[o] : 0.f) - meanl[o]);
+      if (!ident) b += brr[o] + gr[o] * istdl[Co + o] * ((br ? br[o] : 0.f) - meanl[Co + o]);
     }
     bias[o] = b;
   }
+  TFOLD_STAMP(4);
 }
 
 // rows of the tile kernels that keep ONE Ci-row image (+1024 floats scratch) in LDS
@@ -235,9 +300,10 @@ static int launch_reduce_fold(const float* partials, int rows, double* red, doub
   hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, rows, E, red);
   int rc = check_launch("reduce_partials");
   if (rc) return rc;
-  const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + 4 * (size_t)Co * Ci * sizeof(float);
+  const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + (4 * (size_t)Co * Ci + 4 * Co) * sizeof(float);
   if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_train_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
-  hipLaunchKernelGGL(k_train_fold, dim3(1), dim3(1024), fold_lds, st, red, npos, Wt, bt, gs, bs, rm_s,
+  const int fold_blocks = Co >= 32 ? 8 : (Co >= 16 ? 4 : 1);
+  hipLaunchKernelGGL(k_train_fold, dim3(fold_blocks), dim3(1024), fold_lds, st, red, npos, Wt, bt, gs, bs, rm_s,
                      rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r, nbt_r, momentum, wfold, bias, stat, Ci,
                      Co, round_up(Co, 16));
   return check_launch("train_fold");
@@ -369,5 +435,9 @@ int coskad_layer_train_fold_f32(const float* partials, int rows, const float* Wt
                             rvar_t, nbt_t, Wr, br, gamma_r, beta_r, rmean_r, rvar_r, nbt_r, momentum, wfold, bias, stat, Ci, Co,
                             stream);
 }
+
+#ifdef COSKAD_FOLD_TIMING
+int coskad_debug_tfold_stamps(long long* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(coskad::g_tfold_stamps), 16 * sizeof(long long)); }
+#endif
 
 }  // extern "C"
