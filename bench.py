@@ -128,7 +128,7 @@ def cpu_baseline(full_b: int, sample_b: int, fwd_b: int):
     return out
 
 
-def run_legs(B, rank, world, sync, steps, warmup):
+def run_legs(B, rank, world, sync, steps, warmup, only=None):
     """The other shapes the north_star names, each timed like the main loop (warm-up, sync, `steps` steps, sync)."""
     import torch
     from coskad_amd.models.sts.ae import STSE
@@ -149,6 +149,8 @@ def run_legs(B, rank, world, sync, steps, warmup):
     legs = {}
 
     def leg(name, build):
+        if only is not None and name != only:
+            return
         try:
             legs[name] = build()
         except Exception as e:            # a leg must never take the headline number down with it

@@ -135,17 +135,26 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_next(const float* __rest
   for (int i = 0; i < NACC; ++i) { gx[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gz[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int i = 0; i < OTP; ++i) { sx[i] = 0.f; sz[i] = 0.f; }
-  // Gram sums of the image: lane (j, q) reads positions 8 m + 2 q, + 1 of rows j and 16 + j; both MFMA operands are the
-  // same registers (A[i][k] and B[k][j] of a symmetric product)
-  auto gram = [&](f32x4 (&g)[NACC], float (&s)[OTP]) {
+  // Gram sums of the image with the image's rows leaving for HBM in the same loop: lane (j, q) reads positions 8 m + 2 q, + 1 of
+  // rows j and 16 + j as both MFMA operands (A[i][k] and B[k][j] of a symmetric product); step m also reads piece m of the rows
+  // in storage order and stores it (full 1 KB lines).  Both only READ the image, so the stores spread over the Gram's MFMAs
+  // instead of standing in front of them as a burst (the chip's 1024 waves run their clips in lockstep).  ACT: the image holds
+  // pre-activations U -- the rows leave as they are, the Gram operands get PReLU on the fly (no write-back pass).
+  auto gram_rows = [&](f32x4 (&g)[NACC], float (&s)[OTP], const BufRes& ores, bool act) {
     const Lane L = geo();
     const float* p0 = r1 + L.j * LD + 2 * L.q;
     const float* p1 = r1 + (16 + L.j) * LD + 2 * L.q;
     constexpr int NM = (TV + 7) / 8;                     // 26
+    constexpr int n4 = Co * (TV / 4), NI = (n4 + 63) / 64;   // row pieces: 13 (16 rows) / 26 (32 rows)
+    const int ln = olane();
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       float2 a0 = *reinterpret_cast<const float2*>(p0 + 8 * m);
       float2 a1 = OTP == 2 ? *reinterpret_cast<const float2*>(p1 + 8 * m) : float2{0.f, 0.f};
+      if (act) {
+        a0.x = prelu(a0.x, a_out); a0.y = prelu(a0.y, a_out);
+        a1.x = prelu(a1.x, a_out); a1.y = prelu(a1.y, a_out);
+      }
       if (8 * (m + 1) > TV) {                            // the last step's tail lies in the rows' padding
         const bool ok = 8 * m + 2 * L.q < TV;
         a0.x = ok ? a0.x : 0.f; a0.y = ok ? a0.y : 0.f;
@@ -165,25 +174,16 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_next(const float* __rest
         s[0] += a0.x + a0.y;
         s[OTP - 1] += a1.x + a1.y;
       }
-    }
-  };
-  // the image's Co rows -> HBM in full 1 KB lines; `act`: PReLU(row) goes back into the image behind the store
-  auto rows_out = [&](const BufRes& ores, bool act) {
-    constexpr int n4 = Co * (TV / 4);
-    const int ln = olane();
-#pragma unroll
-    for (int i = 0; i < (n4 + 63) / 64; ++i) {
-      if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-      const int e4 = ln + 64 * i;
-      const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
-      const bool full = 64 * (i + 1) <= n4;
-      const bool ok = full || e4 < n4;
-      float* ptr = r1 + (ok ? row * LD + col : PADCOL);
-      const float2 g0 = *reinterpret_cast<const float2*>(ptr), g1 = *reinterpret_cast<const float2*>(ptr + 2);
-      buf_store4(ores, ok ? l16 : 0x7ffffff0, 64 * i * 16, float4{g0.x, g0.y, g1.x, g1.y});
-      if (act && ok) {
-        *reinterpret_cast<float2*>(ptr) = float2{prelu(g0.x, a_out), prelu(g0.y, a_out)};
-        *reinterpret_cast<float2*>(ptr + 2) = float2{prelu(g1.x, a_out), prelu(g1.y, a_out)};
+      // the rows' piece of this step
+      const int i = OTP == 2 ? m : (m % 2 == 0 ? m / 2 : -1);
+      if (i >= 0 && i < NI && !(FN_ABLATE & 1)) {
+        const int e4 = ln + 64 * i;
+        const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
+        const bool full = 64 * (i + 1) <= n4;
+        const bool ok = full || e4 < n4;
+        const float* ptr = r1 + (ok ? row * LD + col : PADCOL);
+        const float2 g0 = *reinterpret_cast<const float2*>(ptr), g1 = *reinterpret_cast<const float2*>(ptr + 2);
+        buf_store4(ores, ok ? l16 : 0x7ffffff0, 64 * i * 16, float4{g0.x, g0.y, g1.x, g1.y});
       }
     }
   };
@@ -284,14 +284,15 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_next(const float* __rest
     // the next layer's temporal table travels while the rows leave and the first Gram multiplies
     TTab tt;
     load_ttab(tt, tabres, 0, l16);
-    // ---- U -> HBM; X_next = PReLU(U) back into the image; sum x x^T ---------------------------------------------------------
-    if (!(FN_ABLATE & 1)) rows_out(ores, true);
-    if (!(FN_ABLATE & 2)) gram(gx, sx);
-    // ---- Z_next = gcn_next(X_next) in place: temporal per joint, spatial per frame (operands of frame t+1 are read before
-    // the tiles of frame t are written) --------------------------------------------------------------------------------------
+    // ---- U -> HBM while sum x x^T multiplies (X_next = PReLU(U) on the fly); the image keeps U --------------------------------
+    if (!(FN_ABLATE & 2)) gram_rows(gx, sx, ores, true);
+    // ---- Z_next = gcn_next(X_next) in place: temporal per joint (PReLU on the operand reads), spatial per frame -----------------
     L = geo();
-    if (!(FN_ABLATE & 4)) temporal_phase<16, OTP>(r1, tt, L);
+    if (!(FN_ABLATE & 4)) temporal_phase<16, OTP, true>(r1, tt, L, a_out);
     L = geo();
+#ifndef FN_OLD_SPATIAL
+    if (!(FN_ABLATE & 8)) spatial_phase<OTP>(r1, tabres, 0, l16, L);
+#else
     if (!(FN_ABLATE & 8)) {
       SpatRec rec = load_spat(tabres, 0, 0, l16);
       SOp op[OTP];
@@ -315,9 +316,9 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_next(const float* __rest
         for (int rt = 0; rt < OTP; ++rt) op[rt] = opn[rt];
       }
     }
-    // ---- Z_next -> HBM; sum z z^T ------------------------------------------------------------------------------------------
-    if (!(FN_ABLATE & 16)) rows_out(zores, false);
-    if (!(FN_ABLATE & 32)) gram(gz, sz);
+#endif
+    // ---- Z_next -> HBM while sum z z^T multiplies ------------------------------------------------------------------------------
+    if (!(FN_ABLATE & 32)) gram_rows(gz, sz, zores, false);
   }
 
   // ---- block sum: the waves add their tiles into one LDS row one after another (fixed order), then the row leaves ------------

@@ -82,10 +82,11 @@ __device__ __forceinline__ void buf_store4(BufRes r, int voff, int soff, const f
 struct TOp {
   float a0, a1, a2;
 };
-template <int ROWS>
-__device__ __forceinline__ TOp temporal_read(const float* img, int rt, int v, const Lane& L) {
+template <int ROWS, bool ACT = false>
+__device__ __forceinline__ TOp temporal_read(const float* img, int rt, int v, const Lane& L, float slope = 0.f) {
   const float* p = img + (16 * rt + L.j) * LD + L.q * V + v;
   TOp o{p[0], p[4 * V], p[8 * V]};
+  if (ACT) { o.a0 = prelu(o.a0, slope); o.a1 = prelu(o.a1, slope); o.a2 = prelu(o.a2, slope); }
   if (ROWS < 16) {
     const bool ok = L.j < ROWS;
     o.a0 = ok ? o.a0 : 0.f; o.a1 = ok ? o.a1 : 0.f; o.a2 = ok ? o.a2 : 0.f;
@@ -124,8 +125,8 @@ __device__ __forceinline__ void load_ttab(TTab& t, BufRes tabres, int base4, int
   for (int v = 0; v < V; ++v) t.r[v] = buf_load4(tabres, l16, (base4 + v * 64) * 16);
 }
 
-template <int ROWS, int NRT>
-__device__ __forceinline__ void temporal_phase(float* img, const TTab& tt, const Lane& L) {
+template <int ROWS, int NRT, bool ACT = false>   // ACT: the image holds pre-activations, PReLU(slope) is applied to the operands as they are read
+__device__ __forceinline__ void temporal_phase(float* img, const TTab& tt, const Lane& L, float slope = 0.f) {
   constexpr int GV = NRT == 2 ? 2 : 4;          // joints per group: 4 independent chains in flight either way
   constexpr int NG = (V + GV - 1) / GV;
   // three stages in flight: operand reads of group g+1, MFMAs of group g, result writes of group g-1 -- a result is
@@ -135,7 +136,7 @@ __device__ __forceinline__ void temporal_phase(float* img, const TTab& tt, const
 #pragma unroll
   for (int u = 0; u < GV; ++u)
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) cur[u][rt] = temporal_read<ROWS>(img, rt, u, L);
+    for (int rt = 0; rt < NRT; ++rt) cur[u][rt] = temporal_read<ROWS, ACT>(img, rt, u, L, slope);
 #pragma unroll
   for (int g = 0; g <= NG; ++g) {
     const int v0 = g * GV;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void temporal_phase(float* img, const TTab& tt, const
       for (int u = 0; u < GV; ++u)
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
-          if (v0 + GV + u < V) nxt[u][rt] = temporal_read<ROWS>(img, rt, v0 + GV + u, L);
+          if (v0 + GV + u < V) nxt[u][rt] = temporal_read<ROWS, ACT>(img, rt, v0 + GV + u, L, slope);
 #pragma unroll
       for (int u = 0; u < GV; ++u)
 #pragma unroll
@@ -220,6 +221,100 @@ __device__ __forceinline__ void spatial_extra(float* img, int rt, int t, const S
   ex = quad_sum(ex);
   float* e = img + (16 * rt + L.j) * LD + ((L.q == 0 && (ROWS >= 16 || L.j < ROWS)) ? t * V + 16 : PADCOL);
   *e = ex;
+}
+
+// ---- spatial mixing of a whole image, in place, software-pipelined by hand ------------------------------------------------
+// One wave issues in order: an MFMA chain that is followed in program order by the stores of its own result stalls the wave
+// for the chain's whole latency, and the VALU / LDS work of the frame (joint 16, operand reads, tile stores) then runs with
+// the matrix pipe idle.  Here the frame loop is a three-stage pipeline -- MFMA chains of frame t (the NRT row tiles
+// interleaved step by step), joint 16 of frame t on the VALU, operand reads of frame t+1, stores of frame t-1 -- and
+// sched_group_barriers lay the stages out between the MFMAs (cdna_hip_programming.md T19).  Used with the forward tables
+// (fused_apply_next.hip) and the adjoint ones (fused_bwd.hip): the same code, `base4` selects the table.
+template <int NRT>
+__device__ __forceinline__ void spatial_phase(float* img, BufRes tabres, int base4, int l16, const Lane& L) {
+  constexpr int FP = NRT == 1 ? 2 : 1;      // frames per pipeline step: at least two independent MFMA chains in flight
+  constexpr int NC = NRT * FP;              // chains per step; chain c = frame f * NRT + row tile rt
+  constexpr int NS = T / FP;
+  static_assert(T % FP == 0, "frames per step divide the window");
+  SpatRec rec[FP];
+  SOp op[NC];
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    rec[f] = load_spat(tabres, base4, f, l16);
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) op[f * NRT + rt] = spatial_read<16>(img, rt, f, L);
+  }
+  f32x4 dprev[NC];
+  float exprev[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { dprev[c] = f32x4{0.f, 0.f, 0.f, 0.f}; exprev[c] = 0.f; }
+#pragma unroll
+  for (int st = 0; st <= NS; ++st) {
+    f32x4 d[NC];
+    float ex[NC];
+    SOp opn[NC];
+    SpatRec nxt[FP];
+    const bool live = st < NS, more = st + 1 < NS;
+    if (live) {
+#pragma unroll
+      for (int f = 0; f < FP; ++f) nxt[f] = more ? load_spat(tabres, base4, (st + 1) * FP + f, l16) : rec[f];
+      // stage 1: the MFMA chains of this step's frames, interleaved step by step (a chain's next MFMA is NC MFMAs away)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) d[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const SpatRec& R = rec[c / NRT];
+          const float bk = s == 0 ? R.c0.x : s == 1 ? R.c0.y : s == 2 ? R.c0.z : s == 3 ? R.c0.w : R.c1.x;
+          const float a = s == 0 ? op[c].a0 : s == 1 ? op[c].a1 : s == 2 ? op[c].a2 : s == 3 ? op[c].a3 : op[c].a4;
+          d[c] = mfma(a, bk, d[c]);
+        }
+      // stage 2: joint 16 of these frames (VALU)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const SpatRec& R = rec[c / NRT];
+        float e = op[c].a0 * R.c1.y;
+        e = fmaf(op[c].a1, R.c1.z, e);
+        e = fmaf(op[c].a2, R.c1.w, e);
+        e = fmaf(op[c].a3, R.c2.x, e);
+        e = fmaf(op[c].a4, R.c2.y, e);
+        ex[c] = quad_sum(e);
+      }
+      // stage 3: operands of the next step's frames
+      if (more) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) opn[c] = spatial_read<16>(img, c % NRT, (st + 1) * FP + c / NRT, L);
+      }
+    }
+    // stage 4: results of the previous step (their chains were issued a step ago)
+    if (st > 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int t = (st - 1) * FP + c / NRT, rt = c % NRT;
+        float* e = img + (16 * rt + L.j) * LD + (L.q == 0 ? t * V + 16 : PADCOL);
+        *e = exprev[c];
+        tile_store(img, 16 * rt, t * V + L.j, true, dprev[c], L);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NC, 0);          // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2 + 2 * NC, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x100, NC, 0);          // DS read
+        __builtin_amdgcn_sched_group_barrier(0x200, NC, 0);          // DS write
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        dprev[c] = d[c];
+        exprev[c] = ex[c];
+        if (more) op[c] = opn[c];
+      }
+#pragma unroll
+      for (int f = 0; f < FP; ++f) rec[f] = nxt[f];
+    }
+  }
 }
 
 // ---- accumulator-layout tiles in LDS -------------------------------------------------------------------------------

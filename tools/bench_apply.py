@@ -1,7 +1,8 @@
 """Times ops.layer_apply_z (training-mode apply from the stored Z) for the default stack's layers 2-4 at B = 4096."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from coskad_amd import ops
 B, T, V = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 12, 17
 torch.manual_seed(0)

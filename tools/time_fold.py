@@ -2,7 +2,8 @@
 fold launch of the step (layer 1's) and, with --layer4, of a single layer-4 backward call."""
 import ctypes, sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from coskad_amd import _lib, ops
 B, T, V = 4096, 12, 17
 torch.manual_seed(0)
