@@ -294,8 +294,12 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     for (int ct = 0; ct < CT; ++ct) tile_store(r1, 16 * ct, jc * V + 16, L.j < T, az[T][ct], L);
     FB_STAMP(3);
 
-    // ---- dY = spatial adjoint of dZ, in place (operand reads of frame t+1 before the stores of frame t) ----------------------
+    // ---- dY = spatial adjoint of dZ, in place: the hand-pipelined frame loop of fused_ops.h (MFMA chains of frame t, joint 16
+    // on the VALU, operand reads of frame t+1, stores of frame t-1, interleaved by sched_group_barriers) on the adjoint tables ------
     L = geo();
+#ifndef FB_OLD_SPATIAL
+    spatial_phase<CT>(r1, tabres, 0, l16, L);
+#else
     {
       SpatRec rec = load_spat(tabres, 0, 0, l16);
       SOp op[CT];
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         for (int ct = 0; ct < CT; ++ct) op[ct] = opn[ct];
       }
     }
+#endif
     FB_STAMP(5);
 
     // ---- dT[v] += X_v^T dY_v: X re-staged 16 rows at a time beside the image; the second K pass's group 0 follows ------------
