@@ -183,11 +183,13 @@ class _WideLayerFn(torch.autograd.Function):
         Co, P = Wt.shape[0], Tn * V
         Z = ops.gcn(X, A.contiguous(), T.contiguous(), adjoint=False)
         Wt2 = Wt.view(Co, Ci)
-        Ct = ops.gemm(Wt2, Z.view(B, Ci, P), bias=bt, bias_mode=1 if bt is not None else 0, bias_mod=Co)
-        st_t = ops.bn2_stats(Ct, bn_t, training)
+        # 1x1 convolutions: the layout-specialised MFMA kernel (csrc/conv1x1.hip) where the shape allows, with the train-mode
+        # BatchNorm sums formed in its epilogue (no statistics pass over the conv output); the strided GEMM otherwise
+        Ct, pt = ops.conv1x1(Wt2, Z.view(B, Ci, P), bias=bt, want_stats=training)
+        st_t = ops.bn2_stats_parts(pt, bn_t, B * P) if pt is not None else ops.bn2_stats(Ct, bn_t, training)
         if Wr is not None:
-            Cr = ops.gemm(Wr.view(Co, Ci), X.view(B, Ci, P), bias=br, bias_mode=1 if br is not None else 0, bias_mod=Co)
-            st_r = ops.bn2_stats(Cr, bn_r, training)
+            Cr, pr = ops.conv1x1(Wr.view(Co, Ci), X.view(B, Ci, P), bias=br, want_stats=training)
+            st_r = ops.bn2_stats_parts(pr, bn_r, B * P) if pr is not None else ops.bn2_stats(Cr, bn_r, training)
         else:
             Cr, st_r = X.view(B, Ci, P), None
         out = ops.bn2_apply_prelu(Ct, Cr, st_t, gt, bet, st_r, gr, ber, slope, drop_p, drop_seed)
@@ -206,14 +208,14 @@ class _WideLayerFn(torch.autograd.Function):
         dCt, dCr, dgt, dbet, dgr, dber, dslope = ops.bn2_bwd(Ct, Crv, dOut.contiguous().view(B, Co, P), st_t, gt, bet, st_r, gr, ber,
                                                              slope, ctx.training, *ctx.drop)
         Wt2 = Wt.view(Co, Ci)
-        dWt = ops.gemm_reduce(dCt, Z.view(B, Ci, P).transpose(1, 2), torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
-        dZ = ops.gemm(Wt2.t(), dCt).view(B, Ci, Tn, V)
+        dWt = ops.conv1x1_wgrad(dCt, Z.view(B, Ci, P), torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
+        dZ = ops.conv1x1(Wt2.t(), dCt)[0].view(B, Ci, Tn, V)
         dX = ops.gcn(dZ, A, T, adjoint=True)
         dA, dT = ops.gcn_bwd_params(X, dZ, A, T)
         dWr = dbr = None
         if Wr is not None:
-            dWr = ops.gemm_reduce(dCr, Xv.transpose(1, 2), torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
-            ops.gemm(Wr.view(Co, Ci).t(), dCr, out=dX.view(B, Ci, P), accumulate=True)
+            dWr = ops.conv1x1_wgrad(dCr, Xv, torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
+            ops.conv1x1(Wr.view(Co, Ci).t(), dCr, out=dX.view(B, Ci, P), accumulate=True)
             if ctx.has_br:      # a bias in front of a BatchNorm: its gradient is the sum of a mean-free tensor (exactly 0 in training)
                 dbr = dCr.sum((0, 2)) if not ctx.training else torch.zeros(Co, device=X.device, dtype=torch.float32)
         else:

@@ -468,6 +468,71 @@ def gemm_rows_outer(G: Tensor, S: Tensor, out: Tensor, rows_per_piece: int = 256
     return out
 
 
+def conv1x1_ok(M: int, K: int, P: int) -> bool:
+    fn = _lib.lib().coskad_conv1x1_ok
+    fn.restype = ctypes.c_int
+    return bool(fn(i32(M), i32(K), i32(P)))
+
+
+def conv1x1(W: Tensor, x: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False,
+            want_stats: bool = False):
+    """out[b] (+)= W @ x[b] (+ bias) for W [M, K] (any 2-D view contiguous along one axis: pass `w.t()` for the data gradient),
+    x [B, K, P] contiguous -> (out [B, M, P], stats partials or None).  Shapes outside csrc/conv1x1.hip go to the strided GEMM."""
+    M, K = W.shape
+    B, K2, P = x.shape
+    _cuda_f32(W, "W"); _chk(x, "x"); _chk(bias, "bias", (M,), optional=True)
+    if K != K2:
+        raise ValueError(f"conv1x1: weight has {K} input channels, x has {K2}")
+    sm, sk = W.stride(0), W.stride(1)
+    fast = conv1x1_ok(M, K, P) and (sk == 1 or sm == 1) and (sm % 4 == 0 if sk == 1 else sk % 4 == 0) and W.data_ptr() % 16 == 0 \
+        and x.data_ptr() % 16 == 0
+    if out is None:
+        out = torch.empty(B, M, P, device=x.device, dtype=torch.float32)
+    _chk(out, "out", (B, M, P))
+    if not fast or out.data_ptr() % 16 != 0:
+        gemm(W, x, out=out, bias=bias, bias_mode=1 if bias is not None else 0, bias_mod=M, accumulate=accumulate)
+        return out, None
+    parts = None
+    if want_stats:
+        fn = _lib.lib().coskad_conv1x1_stat_rows
+        fn.restype = ctypes.c_int
+        rows = fn(i32(M), i32(K), i32(P), i32(B))
+        parts = torch.empty(rows, M, 2, device=x.device, dtype=torch.float64)
+    ll = ctypes.c_longlong
+    call("coskad_conv1x1_f32", ptr(W), ll(sm), ll(sk), ptr(x), ptr(out), ptr(bias), ptr(parts), i32(M), i32(K), i32(P), i32(B),
+         i32(1 if accumulate else 0), _stream())
+    return out, parts
+
+
+def conv1x1_wgrad(G: Tensor, x: Tensor, out: Tensor, target_chunks: int = 64, accumulate: bool = False) -> Tensor:
+    """out[m, k] (+)= sum_b sum_p G[b, m, p] x[b, k, p]: the weight gradient of a 1x1 convolution (G [B, M, P], x [B, K, P]).
+    csrc/conv1x1.hip where the shape allows, the strided GEMM's chunked reduction otherwise; deterministic either way."""
+    B, M, P = G.shape
+    K = x.shape[1]
+    _chk(G, "G"); _chk(x, "x", (B, K, P)); _chk(out, "out", (M, K))
+    fn = _lib.lib().coskad_conv1x1_wgrad_ok
+    fn.restype = ctypes.c_int
+    if not fn(i32(M), i32(K), i32(P)) or G.data_ptr() % 16 or x.data_ptr() % 16:
+        return gemm_reduce(G, x.transpose(1, 2), out, target_chunks=target_chunks, accumulate=accumulate)
+    chunk = max(1, (B + target_chunks - 1) // target_chunks)
+    chunks = (B + chunk - 1) // chunk
+    part = torch.empty(chunks, M, K, device=G.device, dtype=torch.float32)
+    call("coskad_conv1x1_wgrad_f32", ptr(G), ptr(x), ptr(part), i32(M), i32(K), i32(P), i32(B), i32(chunk), _stream())
+    call("coskad_gemm_sum_f32", ptr(part), i32(chunks), ctypes.c_size_t(M * K), ptr(out), i32(1 if accumulate else 0), _stream())
+    return out
+
+
+def bn2_stats_parts(parts: Tensor, bn, count: int) -> Tensor:
+    """Train-mode statistics of nn.BatchNorm2d `bn` from the partial sums a conv1x1 epilogue wrote (+ running update)."""
+    rows, C, _ = parts.shape
+    _chk(parts, "parts", (rows, C, 2), dtype=torch.float64)
+    stat = torch.empty(2 * C, device=parts.device, dtype=torch.float32)
+    call("coskad_bn2_stats_parts_f32", ptr(parts), i32(rows), ptr(stat), ptr(bn.running_mean), ptr(bn.running_var),
+         ptr(bn.num_batches_tracked), ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps),
+         ctypes.c_double(float(count)), i32(C), _stream())
+    return stat
+
+
 def relu_bwd(out: Tensor, dout: Tensor, dbias: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     """g = dout * (out > 0) on [N, C, P]; dbias[c] (+)= sum of g over (n, p)."""
     Nb, C, P = out.shape

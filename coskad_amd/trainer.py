@@ -30,18 +30,23 @@ class FlatParams:
     def __init__(self, module: torch.nn.Module) -> None:
         named = [(n, p) for n, p in module.named_parameters()]
         self.names = [n for n, _ in named]
-        total = sum(p.numel() for _, p in named)
+        # every tensor starts on a 16-byte boundary (the layout-specialised kernels load weights as float4); the padding floats
+        # stay 0 in the parameter, gradient and Adam buffers
+        al = lambda k: (k + 3) // 4 * 4
+        total = sum(al(p.numel()) for _, p in named)
         dev = named[0][1].device
-        self.flat = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
         # regulariser mask: calc_reg_loss skips tensors whose NAME contains 'bias' (model_utils.py:92)
         self.reg_mask = torch.zeros(total, device=dev, dtype=torch.float32)
         self.views: Dict[str, Tensor] = {}
         self.gviews: Dict[str, Tensor] = {}
         self.n_reg_tensors = 0
+        self.offsets: Dict[str, int] = {}
         off = 0
         for n, p in named:
             k = p.numel()
+            self.offsets[n] = off
             self.flat[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.flat[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
@@ -49,7 +54,7 @@ class FlatParams:
             if 'bias' not in n:
                 self.reg_mask[off:off + k] = 1.0
                 self.n_reg_tensors += 1
-            off += k
+            off += al(k)
 
 
 def inv_cov_from_moments(gram: Tensor, acc: Tensor, mu: Tensor, L: int) -> Tensor:
@@ -108,7 +113,7 @@ class STSETrainStep:
         first_tail = next((i for i, n in enumerate(names) if n.startswith("btlnk.")), None)
         self.tail_off = None
         if first_tail is not None and all(n.startswith("btlnk.") for n in names[first_tail:]):
-            self.tail_off = sum(self.fp.views[n].numel() for n in names[:first_tail])
+            self.tail_off = self.fp.offsets[names[first_tail]]
         self.use_graph = use_graph
         self._graph = None
         self._x_static: Optional[Tensor] = None

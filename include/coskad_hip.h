@@ -157,6 +157,26 @@ int coskad_relu_bwd_f32(const float* out, const float* dout, float* g, float* pa
 int coskad_softmax_rows_f32(const float* x, float* y, int n, hipStream_t stream);
 int coskad_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, int n, hipStream_t stream);
 
+/* ---- 1x1 convolution in NCHW for wide layers (nn.Conv2d(C_in, C_out, 1) of stsgcn.py:57-63,71-75; csrc/conv1x1.hip) -----------
+ * Out[b][m][p] (+)= sum_k A(m,k) In[b][k][p] (+ bias[m]) with In [batch][K][P], Out [batch][M][P] contiguous; A(m,k) = A[m sa_m + k sa_k],
+ * sa_k == 1 (forward: W [M][K]) or sa_m == 1 (data gradient: W^T of W [K][M]).  Layout-specialised MFMA kernel (float4 loads, K tiles
+ * double-buffered through registers, 16-byte stores) for P in {204, 300}, K % 16 == 0, M % 32 == 0 (coskad_conv1x1_ok); other shapes:
+ * coskad_gemm_f32.  stats (optional): [coskad_conv1x1_stat_rows()][M][2] doubles receive the per-channel sum / sum of squares of Out --
+ * the train-mode BatchNorm statistics without another pass over the tensor; coskad_bn2_stats_parts_f32 turns them into
+ * stat [2C] = (mean, 1 / sqrt(var + eps)) and updates the running statistics like coskad_bn2_stats_f32. */
+int coskad_conv1x1_ok(int M, int K, int P);
+int coskad_conv1x1_stat_rows(int M, int K, int P, int batch);
+int coskad_conv1x1_f32(const float* A, long long sa_m, long long sa_k, const float* In, float* Out, const float* bias, double* stats,
+                       int M, int K, int P, int batch, int accumulate, hipStream_t stream);
+int coskad_bn2_stats_parts_f32(const double* parts, int rows, float* stat, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, float momentum, float eps, double count, int C, hipStream_t stream);
+/* weight gradient of the 1x1 convolution: partials [ceil(batch / chunk)][M][K] of dW[m][k] = sum_b sum_p G[b][m][p] X[b][k][p]
+ * (G = gradient of the conv output [batch][M][P], X = conv input [batch][K][P]); P in {204, 300}, M and K multiples of 64
+ * (coskad_conv1x1_wgrad_ok); sum the partials with coskad_gemm_sum_f32 (fp64, fixed order: deterministic) */
+int coskad_conv1x1_wgrad_ok(int M, int K, int P);
+int coskad_conv1x1_wgrad_f32(const float* G, const float* X, float* partials, int M, int K, int P, int batch, int chunk,
+                             hipStream_t stream);
+
 /* ---- BatchNorm2d + residual add + PReLU of an ST_GCNN layer on [Nb, C, P] tensors (stsgcn.py:56-80,106-110), for layers
  * beyond the LDS-resident tile kernels (their 1x1 convolutions are coskad_gemm_f32, their mixing coskad_gcn_f32).
  * stat [2C] = (mean, 1/sqrt(var + eps)); stat_r == NULL: identity residual.  ws: coskad_bn2_ws_bytes / _bwd_ws_bytes. */

@@ -79,3 +79,56 @@ def test_relu_bwd_and_softmax():
     xr = x.cpu().double().requires_grad_(True)
     (torch.softmax(xr, 1) * dy.cpu().double()).sum().backward()
     np.testing.assert_allclose(ops.softmax_rows_bwd(y, dy).cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,K,P,B", [(256, 256, 204, 5), (128, 64, 204, 7), (64, 128, 204, 3), (32, 64, 204, 9), (32, 64, 300, 6),
+                                     (64, 32, 300, 5), (128, 256, 204, 1)])
+def test_conv1x1_vs_torch(M, K, P, B):
+    """csrc/conv1x1.hip (layout-specialised 1x1 convolution of the wide layers, stsgcn.py:57-63,71-75): forward with bias, the
+    data-gradient form (transposed weight view, accumulate into the output), ragged clip groups, guarded output, and the
+    BatchNorm sums of its epilogue against a float64 reference."""
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(M + K + P + B)
+    W = (torch.randn(M, K, generator=g) / K ** 0.5).cuda()
+    x = torch.randn(B, K, P, generator=g).cuda()
+    bias = torch.randn(M, generator=g).cuda()
+    assert ops.conv1x1_ok(M, K, P)
+    n, guard = B * M * P, 4096
+    buf = torch.full((n + 2 * guard,), 777.0, device="cuda")
+    out = buf[guard:guard + n].view(B, M, P)
+    _, parts = ops.conv1x1(W, x, bias=bias, out=out, want_stats=True)
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 777.0).all()) and bool((buf[guard + n:] == 777.0).all()), "wrote outside the output"
+    ref = torch.einsum("mk,bkp->bmp", W.double(), x.double()) + bias.double()[None, :, None]
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    s = parts.sum(0)
+    np.testing.assert_allclose(s[:, 0].cpu().numpy(), ref.sum((0, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].cpu().numpy(), (ref ** 2).sum((0, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # data gradient: dX[b] += W^T dC[b] through a transposed view of W [M, K] (M of the forward is the contraction axis here)
+    if ops.conv1x1_ok(K, M, P):
+        dC = torch.randn(B, M, P, generator=g).cuda()
+        dX0 = torch.randn(B, K, P, generator=g).cuda()
+        dX = dX0.clone()
+        ops.conv1x1(W.t(), dC, out=dX, accumulate=True)
+        refd = dX0.double() + torch.einsum("mk,bmp->bkp", W.double(), dC.double())
+        np.testing.assert_allclose(dX.cpu().numpy(), refd.float().cpu().numpy(), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,K,P,B,chunks", [(256, 256, 204, 9, 4), (128, 256, 204, 5, 64), (64, 64, 204, 7, 3), (64, 128, 300, 6, 2),
+                                            (128, 128, 300, 3, 64), (32, 64, 300, 4, 2)])
+def test_conv1x1_weight_gradient_vs_torch(M, K, P, B, chunks):
+    """dW[m][k] = sum_b sum_p G[b][m][p] X[b][k][p] (autograd of the 1x1 convolution, csrc/conv1x1.hip: contraction over positions
+    from LDS row images, chunked deterministic reduction) against float64; the last shape falls to the strided GEMM; accumulate."""
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(M * 3 + K + P + B)
+    G = torch.randn(B, M, P, generator=g).cuda()
+    X = torch.randn(B, K, P, generator=g).cuda()
+    ref = torch.einsum("bmp,bkp->mk", G.double(), X.double())
+    out = torch.empty(M, K, device="cuda")
+    ops.conv1x1_wgrad(G, X, out, target_chunks=chunks)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+    again = torch.empty(M, K, device="cuda")
+    ops.conv1x1_wgrad(G, X, again, target_chunks=chunks)
+    assert torch.equal(out, again), "the chunked reduction is deterministic"
+    ops.conv1x1_wgrad(G, X, out, target_chunks=chunks, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), (2 * ref).float().cpu().numpy(), rtol=2e-5, atol=4e-4)
