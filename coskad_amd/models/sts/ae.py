@@ -42,6 +42,25 @@ class _BottleneckFn(torch.autograd.Function):
         return dU, dslope, dW, db, None
 
 
+class _RevBtlnkFn(torch.autograd.Function):
+    """H = Linear(latent -> hidden*T*V)(Z)  (reference ae.py:223-227) and its autograd on csrc/rev_btlnk.hip."""
+
+    @staticmethod
+    def forward(ctx, Z, W, b):
+        Z = Z.contiguous()
+        ctx.save_for_backward(Z, W)
+        ctx.has_bias = b is not None
+        return ops.rev_btlnk_fwd(Z, W.contiguous(), b)
+
+    @staticmethod
+    def backward(ctx, dH):
+        Z, W = ctx.saved_tensors
+        dW = torch.empty_like(W)
+        db = torch.empty(W.shape[0], device=W.device, dtype=W.dtype) if ctx.has_bias else None
+        dz = ops.rev_btlnk_bwd(dH.contiguous(), Z, W.contiguous(), dW, db)
+        return dz, dW, db
+
+
 def _legacy(kw: dict, new: str, old: str, default=None):
     if new in kw and kw[new] is not None:
         return kw[new]
@@ -189,7 +208,10 @@ class STSAE(STSE):
 
     def decode(self, Z: Tensor, input_shape: Tuple[int]) -> Tensor:
         B, C, T, V, M = input_shape
-        H = self.rev_btlnk(Z)            # latent -> hid*T*V (tiny GEMM, torch/rocBLAS)
+        if Z.is_cuda and Z.dtype == torch.float32 and ops.rev_btlnk_ok(self.rev_btlnk.out_features, self.latent_dim):
+            H = _RevBtlnkFn.apply(Z, self.rev_btlnk.weight, self.rev_btlnk.bias)   # streaming kernels of csrc/rev_btlnk.hip
+        else:
+            H = self.rev_btlnk(Z)        # other latent sizes: torch
         H = H.view(B * M, C, T, V)
         return self.decoder(H)
 

@@ -766,6 +766,55 @@ def rec_head(U: Tensor, x: Tensor, slope: Tensor, need_grad: bool = True, need_x
     return loss, dU, xrec
 
 
+def rev_btlnk_ok(N: int, L: int) -> bool:
+    return L in (8, 16) and N % 4 == 0
+
+
+def rev_btlnk_fwd(z: Tensor, W: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """H = z W^T + bias (rev_btlnk, ae.py:223-227) as one streaming pass (csrc/rev_btlnk.hip); other latent sizes: the strided GEMM."""
+    B, L = z.shape
+    N = W.shape[0]
+    _chk(z, "z"); _chk(W, "W", (N, L)); _chk(bias, "bias", (N,), optional=True)
+    if not rev_btlnk_ok(N, L):
+        return gemm(z, W.t(), bias=bias, bias_mode=2 if bias is not None else 0)
+    H = torch.empty(B, N, device=z.device, dtype=torch.float32)
+    call("coskad_rev_btlnk_fwd_f32", ptr(z), ptr(W), ptr(bias), ptr(H), i32(B), i32(N), i32(L), _stream())
+    return H
+
+
+def rev_btlnk_bwd(dH: Tensor, z: Tensor, W: Tensor, dW: Tensor, db: Optional[Tensor], dz: Optional[Tensor] = None,
+                  accumulate: bool = False) -> Tensor:
+    """-> dz [B, L] (added to the given `dz` when one is passed); fills dW [N, L] and db [N] ((+)= with `accumulate`)."""
+    B, N = dH.shape
+    L = z.shape[1]
+    _chk(dH, "dH"); _chk(z, "z", (B, L)); _chk(W, "W", (N, L)); _chk(dW, "dW", (N, L)); _chk(db, "db", (N,), optional=True)
+    _chk(dz, "dz", (B, L), optional=True)
+    if not rev_btlnk_ok(N, L) or dH.data_ptr() % 16:
+        zs1 = torch.cat([z, torch.ones(B, 1, device=z.device)], 1)
+        gw = torch.empty(N, L + 1, device=dH.device, dtype=torch.float32)
+        gemm_rows_outer(dH, zs1, gw)
+        if accumulate:
+            dW.add_(gw[:, :-1])
+            if db is not None:
+                db.add_(gw[:, -1])
+        else:
+            dW.copy_(gw[:, :-1])
+            if db is not None:
+                db.copy_(gw[:, -1])
+        if dz is None:
+            return gemm(dH, W)
+        return gemm(dH, W, out=dz, accumulate=True)
+    fn = _lib.lib().coskad_rev_btlnk_ws_floats
+    fn.restype = ctypes.c_size_t
+    ws = torch.empty(fn(i32(B), i32(N), i32(L)), device=dH.device, dtype=torch.float32)
+    acc_dz = dz is not None
+    if dz is None:
+        dz = torch.empty(B, L, device=dH.device, dtype=torch.float32)
+    call("coskad_rev_btlnk_bwd_f32", ptr(dH), ptr(z), ptr(W), ptr(dz), i32(1 if acc_dz else 0), ptr(dW), ptr(db),
+         i32(1 if accumulate else 0), ptr(ws), i32(B), i32(N), i32(L), _stream())
+    return dz
+
+
 def gcn_bwd_params(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor):
     """(dA, dT) of ConvTemporalGraphical given its input and output gradient."""
     N, C, T, V = x.shape

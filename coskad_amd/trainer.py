@@ -397,7 +397,7 @@ class STSAETrainStep:
         out['z'] = z_dec
         # rev_btlnk (ae.py:223-227): H = z Wr^T + br on the strided MFMA GEMM, straight into the decoder's [B, hid, T, V] view
         Wr, br = m.rev_btlnk.weight, m.rev_btlnk.bias
-        H = ops.gemm(z_dec, Wr.t(), bias=br, bias_mode=2)
+        H = ops.rev_btlnk_fwd(z_dec, Wr, br)
         Ud, dslope_d, dec_saved = self.dec.forward(H.view(B, hid, T, V), self.ws)
         w_rec = self.lambda_ if self.mode == 'ae' else self.phi
         if dslope_d is None:
@@ -406,18 +406,12 @@ class STSAETrainStep:
         out['rec'] = loss_rec
         # ---- backward ----------------------------------------------------------------------------------------------------
         dH = self.dec.backward(dec_saved, dUd, self.ws, need_dx=True).reshape(B, -1)
-        # rev_btlnk: dWr = dH^T z, dbr = sum dH (one reduction over the batch with a ones column), dz += dH Wr
-        zs1 = torch.cat([z_dec, torch.ones(B, 1, device=z_dec.device)], 1)
-        gw = torch.empty(dH.shape[1], zs1.shape[1], device=dH.device, dtype=torch.float32)
-        ops.gemm_rows_outer(dH, zs1, gw)
-        gv["rev_btlnk.weight"].copy_(gw[:, :-1])
-        gv["rev_btlnk.bias"].copy_(gw[:, -1])
+        # rev_btlnk: dWr = dH^T z, dbr = sum dH, dz (+)= dH Wr: streaming kernels over dH (csrc/rev_btlnk.hip)
         if self.mode == 'ae':
-            ops.gemm(dH, Wr, out=dz, accumulate=True)                             # dz = d MSE(z, c) + dH Wr
-            dHd = dz
+            dHd = ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"], dz=dz)   # dz = d MSE(z, c) + dH Wr
         else:
             Hd, zs, small = graph
-            dz_dec = ops.gemm(dH, Wr)
+            dz_dec = ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"])
             dHd, = torch.autograd.grad([zs, small], [Hd], [dz_dec, torch.ones_like(small)])
             dHd = dHd.contiguous()
         K = W.shape[1]

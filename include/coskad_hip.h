@@ -66,6 +66,16 @@ int coskad_prelu_bwd_f32(const float* u, const float* dout, const float* slope, 
 int coskad_rec_head_f32(const float* U, const float* x, const float* slope, float* xrec, float* dU, float* loss, float* dslope,
                         float upstream, float* ws, int accumulate, size_t n, hipStream_t stream);
 
+/* `rev_btlnk` of the decoder models (models/sts/ae.py:223-227: nn.Linear(latent_dim -> hidden * T * V)) and its autograd as
+ * streaming kernels over the one large tensor (csrc/rev_btlnk.hip); latent_dim L in {8, 16}, N % 4 == 0:
+ *   fwd: H [B, N] = z [B, L] W^T + bias        (W [N, L])
+ *   bwd: dz [B, L] (+)= dH W (dz_accumulate);  dW [N, L], db [N] (may be NULL) (+)= their batch sums (accumulate);
+ *        ws: coskad_rev_btlnk_ws_floats(B, N, L) floats; two-stage fixed-order reductions (deterministic) */
+size_t coskad_rev_btlnk_ws_floats(int B, int N, int L);
+int coskad_rev_btlnk_fwd_f32(const float* z, const float* W, const float* bias, float* H, int B, int N, int L, hipStream_t stream);
+int coskad_rev_btlnk_bwd_f32(const float* dH, const float* z, const float* W, float* dz, int dz_accumulate, float* dW, float* db,
+                             int accumulate, float* ws, int B, int N, int L, hipStream_t stream);
+
 /* ---- train-mode BatchNorm statistics -------------------------------------------------- */
 
 /* Bytes of scratch `ws` that coskad_layer_train_stats_f32 needs for C_in = Ci. */

@@ -132,3 +132,26 @@ def test_conv1x1_weight_gradient_vs_torch(M, K, P, B, chunks):
     assert torch.equal(out, again), "the chunked reduction is deterministic"
     ops.conv1x1_wgrad(G, X, out, target_chunks=chunks, accumulate=True)
     np.testing.assert_allclose(out.cpu().numpy(), (2 * ref).float().cpu().numpy(), rtol=2e-5, atol=4e-4)
+
+
+@pytest.mark.parametrize("B,N,L", [(37, 13056, 16), (5, 19200, 8), (1030, 13056, 8), (3, 13056, 12)])
+def test_rev_btlnk_kernels_vs_torch(B, N, L):
+    """rev_btlnk = nn.Linear(latent -> hidden*T*V) of the decoder models (ae.py:223-227) and its autograd on csrc/rev_btlnk.hip
+    (L = 12 falls to the strided GEMM): forward, dz (plain and added to an existing gradient), dW, db against float64."""
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(B + N + L)
+    z = torch.randn(B, L, generator=g).cuda()
+    W = (torch.randn(N, L, generator=g) / L ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    H = ops.rev_btlnk_fwd(z, W, b)
+    ref = z.double() @ W.double().t() + b.double()
+    np.testing.assert_allclose(H.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    dH = torch.randn(B, N, generator=g).cuda()
+    dW, db = torch.empty_like(W), torch.empty_like(b)
+    dz = ops.rev_btlnk_bwd(dH, z, W, dW, db)
+    np.testing.assert_allclose(dz.cpu().numpy(), (dH.double() @ W.double()).float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(dW.cpu().numpy(), (dH.double().t() @ z.double()).float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), dH.double().sum(0).float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+    dz0 = torch.randn(B, L, generator=g).cuda()
+    dz1 = ops.rev_btlnk_bwd(dH, z, W, dW, db, dz=dz0.clone())
+    np.testing.assert_allclose(dz1.cpu().numpy(), (dz0.double() + dH.double() @ W.double()).float().cpu().numpy(), rtol=2e-5, atol=2e-4)
