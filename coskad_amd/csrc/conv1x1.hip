@@ -429,8 +429,8 @@ int coskad_bn2_stats_parts_f32(const double* parts, int rows, float* stat, float
   return check_launch("bn2_stats_parts");
 }
 
-/* 1 when coskad_conv1x1_wgrad_f32 takes the shape: P in {204, 300}, M and K multiples of 64 */
-int coskad_conv1x1_wgrad_ok(int M, int K, int P) { return (P == 204 || P == 300) && M > 0 && K > 0 && M % 64 == 0 && K % 64 == 0 ? 1 : 0; }
+/* 1 when coskad_conv1x1_wgrad_f32 takes the shape: P in {204, 300}, M a multiple of 32, K of 64 */
+int coskad_conv1x1_wgrad_ok(int M, int K, int P) { return (P == 204 || P == 300) && M > 0 && K > 0 && M % 32 == 0 && K % 64 == 0 ? 1 : 0; }
 
 /* partials [chunks][M][K] of dW[m][k] = sum_b sum_p G[b][m][p] X[b][k][p] (G [batch][M][P], X [batch][K][P] contiguous); chunks =
  * ceil(batch / chunk); add them with coskad_gemm_sum_f32 (fp64, fixed order). */
@@ -451,12 +451,15 @@ int coskad_conv1x1_wgrad_f32(const float* G, const float* X, float* partials, in
     hipLaunchKernelGGL(k, dim3(K / (16 * TK * WKR), M / (16 * TM * WMR), chunks), dim3(64 * WMR * WKR), lds, stream, G, X,   \
                        partials, M, K, P, batch, chunk);                                                         \
   } while (0)
+  const bool mid = M % 64 == 0;
   if (P == 204) {
     if (big) LAUNCH_WG(4, 2, 2, 4, 68);
-    else LAUNCH_WG(2, 2, 2, 2, 68);
+    else if (mid) LAUNCH_WG(2, 2, 2, 2, 68);
+    else LAUNCH_WG(2, 2, 1, 2, 68);
   } else {
     if (big) LAUNCH_WG(4, 2, 2, 4, 60);
-    else LAUNCH_WG(2, 2, 2, 2, 60);
+    else if (mid) LAUNCH_WG(2, 2, 2, 2, 60);
+    else LAUNCH_WG(2, 2, 1, 2, 60);
   }
 #undef LAUNCH_WG
   return check_launch("conv1x1_wgrad");

@@ -181,7 +181,7 @@ int coskad_conv1x1_f32(const float* A, long long sa_m, long long sa_k, const flo
 int coskad_bn2_stats_parts_f32(const double* parts, int rows, float* stat, float* running_mean, float* running_var,
                                long long* num_batches_tracked, float momentum, float eps, double count, int C, hipStream_t stream);
 /* weight gradient of the 1x1 convolution: partials [ceil(batch / chunk)][M][K] of dW[m][k] = sum_b sum_p G[b][m][p] X[b][k][p]
- * (G = gradient of the conv output [batch][M][P], X = conv input [batch][K][P]); P in {204, 300}, M and K multiples of 64
+ * (G = gradient of the conv output [batch][M][P], X = conv input [batch][K][P]); P in {204, 300}, M a multiple of 32, K of 64
  * (coskad_conv1x1_wgrad_ok); sum the partials with coskad_gemm_sum_f32 (fp64, fixed order: deterministic) */
 int coskad_conv1x1_wgrad_ok(int M, int K, int P);
 int coskad_conv1x1_wgrad_f32(const float* G, const float* X, float* partials, int M, int K, int P, int batch, int chunk,

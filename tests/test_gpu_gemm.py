@@ -115,7 +115,7 @@ def test_conv1x1_vs_torch(M, K, P, B):
 
 
 @pytest.mark.parametrize("M,K,P,B,chunks", [(256, 256, 204, 9, 4), (128, 256, 204, 5, 64), (64, 64, 204, 7, 3), (64, 128, 300, 6, 2),
-                                            (128, 128, 300, 3, 64), (32, 64, 300, 4, 2)])
+                                            (128, 128, 300, 3, 64), (32, 64, 300, 4, 2), (32, 48, 204, 4, 2)])
 def test_conv1x1_weight_gradient_vs_torch(M, K, P, B, chunks):
     """dW[m][k] = sum_b sum_p G[b][m][p] X[b][k][p] (autograd of the 1x1 convolution, csrc/conv1x1.hip: contraction over positions
     from LDS row images, chunked deterministic reduction) against float64; the last shape falls to the strided GEMM; accumulate."""

@@ -68,7 +68,9 @@ def test_flat_params_and_reg_mask():
     m = STSE(2, [8, 4, 8], 8, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
     before = {k: v.clone() for k, v in m.state_dict().items()}
     fp = FlatParams(m)
-    assert fp.flat.numel() == sum(p.numel() for p in m.parameters())
+    # every tensor starts on a 16-byte boundary of the flat buffer (float4 weight loads): padded to multiples of 4 floats
+    assert fp.flat.numel() == sum((p.numel() + 3) // 4 * 4 for p in m.parameters())
+    assert all(off % 4 == 0 for off in fp.offsets.values()) and all(v.data_ptr() % 16 == 0 for v in fp.views.values())
     for k, v in m.state_dict().items():
         assert torch.equal(v, before[k]), k
     # parameters are views of the flat buffer: writing the buffer changes the module
