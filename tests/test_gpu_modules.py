@@ -518,3 +518,30 @@ def test_train_mode_dropout_matches_oracle_with_the_same_mask(Ci, Co):
         e = layer(x.cuda())
         ref_e = R.st_gcnn_layer(x, {k: v.cpu() for k, v in {"l." + k: v for k, v in layer.state_dict().items()}.items()}, "l", training=False)
     np.testing.assert_allclose(e.cpu().numpy(), ref_e.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_train_step_captured_in_a_hip_graph_equals_the_eager_step(golden):
+    """STSETrainStep(use_graph=True): the whole step (apply + next-layer statistics kernels, folds with their table-building
+    blocks, fused backward, Adam) captured once in a hipGraph and replayed -- same parameters as the eager step after three steps
+    on changing inputs (every kernel argument that changes between steps lives in device memory)."""
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import STSETrainStep
+    from oracle import ref_cpu as R
+    g = golden("stse_default.npz")
+    st = state_from(g)
+    xs = [R.synthetic_clips(64, seed=20 + i).cuda() for i in range(3)]
+    res = []
+    for use_graph in (False, True):
+        m = STSE(2, [32, 16, 32], 64, 16, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+        m.load_state_dict(st, strict=True)
+        m.c.fill_(0.05)
+        eng = STSETrainStep(m.cuda().train(), lr=1e-3, alpha=1e-4, head='euclidean', use_graph=use_graph)
+        # the first graph-mode call takes the step twice on its input (an eager warm-up outside the capture, then the replay)
+        seq = xs if use_graph else [xs[0]] + xs
+        losses = [float(eng.step(x)[0]) for x in seq]
+        torch.cuda.synchronize()
+        res.append((losses[-2:], {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
+    (l0, s0), (l1, s1) = res
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    for k in s0:
+        np.testing.assert_allclose(s1[k].numpy(), s0[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
