@@ -190,7 +190,7 @@ def run_legs(B, rank, world, sync, steps, warmup, only=None):
 
     def vae_leg():
         torch.manual_seed(0)
-        m = STSVAE(C_IN, CHANNELS, HID, 8, T, 25, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='ps')
+        m = STSVAE(C_IN, CHANNELS, HID, 8, T, 25, 'sts_gcn', 'mlp', 'euclidean', 0.0, distribution='ps')   # projector: spherical_vae.yaml:37
         eng = STSAETrainStep(m.cuda().train(), mode='vae', lr=1e-4, alpha=1e-6, phi=1.0, beta=1.0, gamma=1.0)
         x = synthetic_clips(B, C_IN, T, 25, seed=400 + rank).cuda()
         dt = timed(lambda: eng.step(x))
@@ -200,8 +200,8 @@ def run_legs(B, rank, world, sync, steps, warmup, only=None):
         fd = sum(4 * T * 25 * (ci + co) for ci, co in zip(dchans[:-1], dchans[1:]))
         bd = sum(4 * T * 25 * (co + 2 * ci) for ci, co in zip(dchans[:-1], dchans[1:]))
         total = fb + bb + fd + bd
-        return {"workload": f"spherical_vae train step (BASELINE config 4's model: STSVAE, PowerSpherical latent 8, decoder; phi MSE + beta KL + "
-                            f"gamma mean(1/kappa) + alpha reg), B={B}/GPU T={T} V=25, default widths", "engine": "STSAETrainStep",
+        return {"workload": f"spherical_vae train step (BASELINE config 4's model: STSVAE, projector 'mlp', PowerSpherical latent 8, decoder; phi MSE + "
+                            f"beta KL + gamma mean(1/kappa) + alpha reg), B={B}/GPU T={T} V=25, default widths", "engine": "STSAETrainStep",
                 "ms_per_step": round(dt * 1e3, 4), "clips_per_s": round(world * B / dt, 1),
                 "roofline": {"bound": "hbm", "frac": hbm(B / dt, total), "algorithmic_bytes_per_clip": total, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
 

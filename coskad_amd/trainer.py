@@ -348,7 +348,10 @@ class STSAETrainStep:
     @staticmethod
     def supports(model) -> bool:
         from .models.sts.vae import STSVAE
+        from .models.common.components import MLP
         if isinstance(model, STSVAE):
+            if isinstance(model.btlnk, MLP):              # `projector: 'mlp'` (spherical_vae.yaml:37): MLP, then the heads on its output
+                return model.btlnk.hip_ok and model.latent_dim <= 16
             return isinstance(model.btlnk, torch.nn.Identity) and model.latent_dim + model.fc_var.out_features <= 16
         return isinstance(model.btlnk, torch.nn.Linear) and model.latent_dim <= 16
 
@@ -377,12 +380,35 @@ class STSAETrainStep:
             z_dec, graph = z, None
         else:
             from .models.sts.vae import kl_ps_uniform
+            from .models.common.components import MLP
             L = m.latent_dim
-            W = torch.cat([m.fc_mean.weight, m.fc_var.weight], 0)                 # heads stacked: one pass over U
-            b = torch.cat([m.fc_mean.bias, m.fc_var.bias], 0)
-            Hd = ops.btlnk_fwd(U, W, b, slope, ws=self.ws).requires_grad_(True)
+            mlp = isinstance(m.btlnk, MLP)
+            mlp_saved, head_params = None, []
+            if mlp:
+                # `mlp` projector (vae.py:141-146): wide Linear on the bottleneck kernel, [BatchNorm1d, ReLU, Linear] blocks on
+                # csrc/mlp_head.hip; the two small heads act on its [B, latent] output inside the local autograd graph
+                if B == 1:
+                    raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d of the mlp projector)")
+                first = m.btlnk.net[0]
+                W, b = first.weight, first.bias
+                y = ops.btlnk_fwd(U, W, b, slope, ws=self.ws)
+                mlp_saved = []
+                for i, (bn, lin) in enumerate(m.btlnk.blocks()):
+                    zz, stat = ops.mlp_head_fwd(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                lin.weight, lin.bias, True, momentum=bn.momentum, eps=bn.eps)
+                    mlp_saved.append((y, stat, bn, lin, f"btlnk.net.{3 * i + 1}.", f"btlnk.net.{3 * i + 3}."))
+                    y = zz
+                Hd = y.requires_grad_(True)
+                head_params = [m.fc_mean.weight, m.fc_mean.bias, m.fc_var.weight, m.fc_var.bias]
+            else:
+                W = torch.cat([m.fc_mean.weight, m.fc_var.weight], 0)             # heads stacked: one pass over U
+                b = torch.cat([m.fc_mean.bias, m.fc_var.bias], 0)
+                Hd = ops.btlnk_fwd(U, W, b, slope, ws=self.ws).requires_grad_(True)
             with torch.enable_grad():                                             # [B, latent] tensors: vae.py:79-91,104-118
-                Z_mean, Z_var = m._finish_heads(Hd[:, :L], Hd[:, L:], None, False)
+                if mlp:
+                    Z_mean, Z_var = m._finish_heads(m.fc_mean(Hd), m.fc_var(Hd), None, False)
+                else:
+                    Z_mean, Z_var = m._finish_heads(Hd[:, :L], Hd[:, L:], None, False)
                 q, p = m.reparameterize(Z_mean, Z_var)
                 zs = q.rsample()
                 if m.distribution == 'normal':
@@ -392,7 +418,7 @@ class STSAETrainStep:
                 loss_exp = (1 / Z_var).mean()
                 small = self.beta * loss_kl + self.gamma * loss_exp
             out['head'], out['exp'] = loss_kl.detach().reshape(1), loss_exp.detach().reshape(1)
-            z_dec, graph = zs.detach().contiguous(), (Hd, zs, small)
+            z_dec, graph = zs.detach().contiguous(), (Hd, zs, small, head_params, mlp_saved)
             dz = None
         out['z'] = z_dec
         # rev_btlnk (ae.py:223-227): H = z Wr^T + br on the strided MFMA GEMM, straight into the decoder's [B, hid, T, V] view
@@ -410,14 +436,22 @@ class STSAETrainStep:
         if self.mode == 'ae':
             dHd = ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"], dz=dz)   # dz = d MSE(z, c) + dH Wr
         else:
-            Hd, zs, small = graph
+            Hd, zs, small, head_params, mlp_saved = graph
             dz_dec = ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"])
-            dHd, = torch.autograd.grad([zs, small], [Hd], [dz_dec, torch.ones_like(small)])
-            dHd = dHd.contiguous()
+            res = torch.autograd.grad([zs, small], [Hd] + head_params, [dz_dec, torch.ones_like(small)])
+            dHd = res[0].contiguous()
+            if mlp_saved is not None:
+                for n, g_ in zip(("fc_mean.weight", "fc_mean.bias", "fc_var.weight", "fc_var.bias"), res[1:]):
+                    gv[n].copy_(g_)
+                for y_in, stat, bn, lin, bname, lname in reversed(mlp_saved):
+                    g = {"gamma": gv[bname + "weight"], "beta": gv[bname + "bias"], "W2": gv[lname + "weight"], "b2": gv.get(lname + "bias")}
+                    dHd = ops.mlp_head_bwd(y_in, stat, bn.weight, bn.bias, lin.weight, dHd, g, True)
         K = W.shape[1]
         buf = self.ws.get(ops.btlnk_bwd_ws_bytes(B, K, W.shape[0]), x.device)
         if self.mode == 'ae':
             dU = ops.btlnk_bwd(U, W, dHd, slope, gv["btlnk.weight"], gv.get("btlnk.bias"), self.enc.last_slope_grad, buf)
+        elif graph[4] is not None:          # mlp projector: the wide first Linear of the MLP
+            dU = ops.btlnk_bwd(U, W, dHd, slope, gv["btlnk.net.0.weight"], gv.get("btlnk.net.0.bias"), self.enc.last_slope_grad, buf)
         else:
             gW = torch.empty_like(W)
             gb = torch.empty_like(b)

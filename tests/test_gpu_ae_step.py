@@ -91,8 +91,8 @@ def test_flat_autoencoder_step_equals_torch_adam_on_the_module_surface(golden):
         np.testing.assert_allclose(res[0][k].numpy(), res[1][k].numpy(), rtol=2e-3, atol=3e-4, err_msg=k)
 
 
-@pytest.mark.parametrize("V", [17, 25])
-def test_flat_vae_step_matches_module_autograd(V):
+@pytest.mark.parametrize("V,projector", [(17, 'linear'), (25, 'linear'), (25, 'mlp')])
+def test_flat_vae_step_matches_module_autograd(V, projector):
     """spherical VAE (spherical_vae.py:81-107): phi * MSE + beta * KL + gamma * mean(1 / kappa).  The flat step and the
     module-surface autograd path draw the same PowerSpherical sample under the same torch seed; losses and every gradient
     must agree (the encoder / decoder themselves are pinned by the reference goldens in the test above)."""
@@ -100,18 +100,18 @@ def test_flat_vae_step_matches_module_autograd(V):
     from coskad_amd.trainer import STSAETrainStep
     from oracle import ref_cpu as R
     torch.manual_seed(3)
-    proto = STSVAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='ps')
+    proto = STSVAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', projector, 'euclidean', 0.0, distribution='ps')
     st = {k: v.detach().clone() for k, v in proto.state_dict().items()}
     x = R.synthetic_clips(24, 2, 12, V, seed=4).cuda()
     phi, beta, gamma = 0.7, 0.3, 0.2
-    m1 = STSVAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='ps')
+    m1 = STSVAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', projector, 'euclidean', 0.0, distribution='ps')
     m1.load_state_dict(st)
     m1.cuda().train()
     torch.manual_seed(11)
     z, xr, (q, p, kappa) = m1(x)
     l_rec, l_kl, l_exp = ((xr - x) ** 2).mean(), kl_ps_uniform(q, p).mean(), (1 / kappa).mean()
     (phi * l_rec + beta * l_kl + gamma * l_exp).backward()
-    m2 = STSVAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', 'linear', 'euclidean', 0.0, distribution='ps')
+    m2 = STSVAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', projector, 'euclidean', 0.0, distribution='ps')
     m2.load_state_dict(st)
     m2.cuda().train()
     eng = STSAETrainStep(m2, mode='vae', lr=0.0, alpha=0.0, phi=phi, beta=beta, gamma=gamma)
@@ -122,6 +122,10 @@ def test_flat_vae_step_matches_module_autograd(V):
     np.testing.assert_allclose(float(out['rec']), float(l_rec), rtol=1e-4)
     np.testing.assert_allclose(float(out['head']), float(l_kl), rtol=1e-4)
     np.testing.assert_allclose(float(out['exp']), float(l_exp), rtol=1e-4)
+    if projector == 'mlp':                           # (spherical_vae.yaml:37 selects the mlp projector) running statistics of its BatchNorm1d
+        for (k1, b1), (k2, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+            if "btlnk" in k1:
+                np.testing.assert_allclose(b2.cpu().numpy(), b1.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k1)
     grads = {n: p.grad for n, p in m1.named_parameters()}
     gmax = max(float(v.abs().max()) for v in grads.values() if v is not None)
     for n, ref in grads.items():
