@@ -133,3 +133,37 @@ def test_flat_vae_step_matches_module_autograd(V, projector):
             continue
         r = ref.cpu().numpy()
         np.testing.assert_allclose(eng.fp.gviews[n].cpu().numpy(), r, rtol=2e-3, atol=2e-4 * np.abs(r).max() + 5e-5 * gmax, err_msg=n)
+
+
+def test_flat_autoencoder_step_default_widths_vs_oracle():
+    """The reference's DEFAULT widths (32-16-32, hidden 64, latent 16) on 17 joints: the decoder 64 -> 32 -> 16 -> 32 -> 2 runs on
+    the tile kernels with the apply + next-layer-statistics fusion for its middle layers; losses, every gradient and the
+    BatchNorm running statistics of one flat step against the CPU oracle's autograd (oracle/ref_cpu.py, pinned by the goldens)."""
+    from coskad_amd.models.sts.ae import STSAE
+    from coskad_amd.trainer import STSAETrainStep
+    from oracle import ref_cpu as R
+    st = R.init_stse_state(seed=7, decoder=True)
+    st["c"] = torch.linspace(-0.1, 0.1, 16)
+    x = R.synthetic_clips(10, seed=8)
+    m = STSAE(2, [32, 16, 32], 64, 16, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    m.load_state_dict(st, strict=True)
+    eng = STSAETrainStep(m.cuda().train(), mode='ae', lr=0.0, alpha=0.0, lambda_=0.3)
+    out = eng.step(x.cuda())
+    torch.cuda.synchronize()
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
+    so = {k: v.clone() for k, v in st.items()}
+    so.update(params)
+    z = R.stse_encode(x, so, training=True)
+    xr = R.stsae_decode(z, so, 64, 12, 17, training=True)
+    l_rec, l_h = ((xr - x) ** 2).mean(), R.mse_to_center(z, st["c"])
+    (0.3 * l_rec + l_h).backward()
+    np.testing.assert_allclose(float(out['rec']), float(l_rec), rtol=1e-4)
+    np.testing.assert_allclose(float(out['head']), float(l_h), rtol=1e-4)
+    gmax = max(float(p.grad.abs().max()) for p in params.values())
+    for n, p in params.items():
+        r = p.grad.numpy()
+        np.testing.assert_allclose(eng.fp.gviews[n].cpu().numpy(), r, rtol=2e-3, atol=2e-4 * np.abs(r).max() + 5e-5 * gmax, err_msg=n)
+    sd = m.state_dict()
+    for k, v in so.items():
+        if "running" in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
