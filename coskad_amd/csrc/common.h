@@ -24,8 +24,7 @@ int check_launch(const char* what);
 #ifndef COSKAD_BLOCK
 #define COSKAD_BLOCK 512
 #endif
-constexpr int kBlock = COSKAD_BLOCK;   // threads per block of every tile kernel
-constexpr int kScratchFloats = (kBlock / 64) * 256;
+constexpr int kFlatBlock = COSKAD_BLOCK;   // threads per block of the element-wise kernels (heads.hip)
 #ifndef COSKAD_MINWAVES
 #define COSKAD_MINWAVES 4
 #endif
@@ -39,6 +38,12 @@ struct Geo {
   // LDS row stride in floats: odd, so that lanes<->rows (stride LD) and lanes<->positions
   // (stride 1) are both bank-conflict-free for ds_read_b32/ds_write_b32 (32 banks).
   static constexpr int LD = (TV % 2 == 0) ? TV + 1 : TV;
+  // Threads per block of the LDS-tile kernels (block per tile of clips).  A clip of more than 256 positions (25 joints) has more
+  // than eight 32-position strips and an LDS footprint (image + mixing tables) that leaves room for ONE block per CU: that block
+  // is then 16 waves, so that the CU still runs four waves per SIMD and every strip has its own wave (measured, round 3: the
+  // 25-joint encoder step 4.36 -> 3.31 ms; at 17 joints two 8-wave blocks per CU are faster: 1.67 vs 1.71 ms).
+  static constexpr int Block = TV > 256 ? 2 * COSKAD_BLOCK : COSKAD_BLOCK;
+  static constexpr int Scratch = (Block / 64) * 256;   // floats of LDS scratch of the cross-wave reductions (tile_ops.h)
 };
 
 // kernel ids of the timing probe (api.hip)

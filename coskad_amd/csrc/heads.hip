@@ -138,7 +138,7 @@ __device__ __forceinline__ Vec hyp_embed_bwd(const Vec& u, const Embed& em, cons
 constexpr int kHeadSlots = LMAX + 3;
 
 __device__ __forceinline__ void block_partials(const float (&vals)[kHeadSlots], float* partials) {
-  __shared__ float sh[kBlock / 64][kHeadSlots];
+  __shared__ float sh[kFlatBlock / 64][kHeadSlots];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < kHeadSlots; ++k) {
@@ -148,18 +148,18 @@ __device__ __forceinline__ void block_partials(const float (&vals)[kHeadSlots], 
   __syncthreads();
   if (threadIdx.x < kHeadSlots) {
     float s = 0.f;
-    for (int w = 0; w < kBlock / 64; ++w) s += sh[w][threadIdx.x];
+    for (int w = 0; w < kFlatBlock / 64; ++w) s += sh[w][threadIdx.x];
     partials[blockIdx.x * kHeadSlots + threadIdx.x] = s;
   }
 }
 
 // Euclidean head.  slots: [0] sum (z-c)^2, [1..L] sum z, [17] #clips, [18] sum |z|
-__global__ __launch_bounds__(kBlock) void k_mse_head(const float* __restrict__ z,
+__global__ __launch_bounds__(kFlatBlock) void k_mse_head(const float* __restrict__ z,
                                                     const float* __restrict__ cvec,
                                                     float* __restrict__ dz, float* __restrict__ score,
                                                     float* __restrict__ partials, int B, int L,
                                                     float gscale) {
-  const int n = blockIdx.x * kBlock + threadIdx.x;
+  const int n = blockIdx.x * kFlatBlock + threadIdx.x;
   float vals[kHeadSlots];
 #pragma unroll
   for (int k = 0; k < kHeadSlots; ++k) vals[k] = 0.f;
@@ -185,19 +185,19 @@ __global__ __launch_bounds__(kBlock) void k_mse_head(const float* __restrict__ z
 
 // Mahalanobis head (eval_utils.py:28-38; staticCenter.py:178-181).  slots: [0] sum dist, [1..L] sum z, [17] #clips,
 // [18] sum |z|.  dist = sqrt(d^T VI d), d = z - c;  d dist / dz = (VI + VI^T) d / (2 dist).
-__global__ __launch_bounds__(kBlock) void k_mahalanobis_head(const float* __restrict__ z,
+__global__ __launch_bounds__(kFlatBlock) void k_mahalanobis_head(const float* __restrict__ z,
                                                             const float* __restrict__ cvec,
                                                             const float* __restrict__ VI,
                                                             float* __restrict__ dz, float* __restrict__ score,
                                                             float* __restrict__ partials, int B, int L,
                                                             float gscale) {
   __shared__ float vi[LMAX * LMAX];
-  for (int e = threadIdx.x; e < LMAX * LMAX; e += kBlock) {
+  for (int e = threadIdx.x; e < LMAX * LMAX; e += kFlatBlock) {
     const int r = e / LMAX, q = e - r * LMAX;
     vi[e] = (r < L && q < L) ? VI[r * L + q] : 0.f;
   }
   __syncthreads();
-  const int n = blockIdx.x * kBlock + threadIdx.x;
+  const int n = blockIdx.x * kFlatBlock + threadIdx.x;
   float vals[kHeadSlots];
 #pragma unroll
   for (int k = 0; k < kHeadSlots; ++k) vals[k] = 0.f;
@@ -255,13 +255,13 @@ __global__ __launch_bounds__(LMAX * LMAX) void k_gram(const float* __restrict__ 
 }
 
 // Poincare head.  slots: [0] sum dist, [1..L] sum gamma*zh, [17] sum (gamma-1), [18] sum |zh|
-__global__ __launch_bounds__(kBlock) void k_poincare_head(const float* __restrict__ z,
+__global__ __launch_bounds__(kFlatBlock) void k_poincare_head(const float* __restrict__ z,
                                                          const float* __restrict__ cvec,
                                                          float* __restrict__ dz, float* __restrict__ zh,
                                                          float* __restrict__ score,
                                                          float* __restrict__ partials, int B, int L,
                                                          float gscale) {
-  const int n = blockIdx.x * kBlock + threadIdx.x;
+  const int n = blockIdx.x * kFlatBlock + threadIdx.x;
   float vals[kHeadSlots];
 #pragma unroll
   for (int k = 0; k < kHeadSlots; ++k) vals[k] = 0.f;
@@ -304,10 +304,10 @@ __global__ __launch_bounds__(64) void k_head_finalize(const float* __restrict__ 
 }
 
 // dist(c, zh) per row for points already on the ball (eval scoring, eval_utils.py:66-67)
-__global__ __launch_bounds__(kBlock) void k_poincare_dist(const float* __restrict__ zh,
+__global__ __launch_bounds__(kFlatBlock) void k_poincare_dist(const float* __restrict__ zh,
                                                          const float* __restrict__ cvec,
                                                          float* __restrict__ score, int B, int L) {
-  const int n = blockIdx.x * kBlock + threadIdx.x;
+  const int n = blockIdx.x * kFlatBlock + threadIdx.x;
   if (n >= B) return;
   const Vec p = load_vec(zh + (size_t)n * L, L), c = load_vec(cvec, L);
   score[n] = poincare_dist(c, p, nullptr);
@@ -423,7 +423,7 @@ using namespace coskad;
 extern "C" {
 
 int coskad_head_slots(void) { return kHeadSlots; }
-size_t coskad_head_ws_floats(int B) { return (size_t)ceil_div(B, kBlock) * kHeadSlots; }
+size_t coskad_head_ws_floats(int B) { return (size_t)ceil_div(B, kFlatBlock) * kHeadSlots; }
 
 /* Euclidean one-class head on z [B,L] (staticCenter.py:187, dynamicCenter.py:116, eval_utils.py:63-64).
  *   stats[19]: [0] = mean_{n,j} (z-c)^2 (the loss), [1..L] = sum_n z, [17] = B, [18] = sum_n |z_n|
@@ -433,8 +433,8 @@ int coskad_mse_head_f32(const float* z, const float* c, float* dz, float* score,
                         float upstream, float* ws, int B, int L, hipStream_t stream) {
   if (!z || !c || !ws) return fail(COSKAD_ERR_ARG, "mse_head: null pointer");
   if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "mse_head: B=%d latent=%d (max %d)", B, L, LMAX);
-  const int P = ceil_div(B, kBlock);
-  hipLaunchKernelGGL(k_mse_head, dim3(P), dim3(kBlock), 0, stream, z, c, dz, score, ws, B, L,
+  const int P = ceil_div(B, kFlatBlock);
+  hipLaunchKernelGGL(k_mse_head, dim3(P), dim3(kFlatBlock), 0, stream, z, c, dz, score, ws, B, L,
                      upstream / ((float)B * (float)L));
   if (stats || acc)
     hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(64), 0, stream, ws, P, 1.f / ((float)B * (float)L), stats, acc);
@@ -449,8 +449,8 @@ int coskad_mahalanobis_head_f32(const float* z, const float* c, const float* VI,
                                 float* ws, int B, int L, hipStream_t stream) {
   if (!z || !c || !VI || !ws) return fail(COSKAD_ERR_ARG, "mahalanobis_head: null pointer");
   if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "mahalanobis_head: B=%d latent=%d (max %d)", B, L, LMAX);
-  const int P = ceil_div(B, kBlock);
-  hipLaunchKernelGGL(k_mahalanobis_head, dim3(P), dim3(kBlock), 0, stream, z, c, VI, dz, score, ws, B, L,
+  const int P = ceil_div(B, kFlatBlock);
+  hipLaunchKernelGGL(k_mahalanobis_head, dim3(P), dim3(kFlatBlock), 0, stream, z, c, VI, dz, score, ws, B, L,
                      upstream / (float)B);
   if (stats || acc)
     hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(64), 0, stream, ws, P, 1.f / (float)B, stats, acc);
@@ -468,8 +468,8 @@ int coskad_poincare_head_f32(const float* z, const float* c, float* dz, float* z
                              hipStream_t stream) {
   if (!z || !ws) return fail(COSKAD_ERR_ARG, "poincare_head: null pointer");
   if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "poincare_head: B=%d latent=%d (max %d)", B, L, LMAX);
-  const int P = ceil_div(B, kBlock);
-  hipLaunchKernelGGL(k_poincare_head, dim3(P), dim3(kBlock), 0, stream, z, c, dz, zh, score, ws, B, L,
+  const int P = ceil_div(B, kFlatBlock);
+  hipLaunchKernelGGL(k_poincare_head, dim3(P), dim3(kFlatBlock), 0, stream, z, c, dz, zh, score, ws, B, L,
                      upstream / (float)B);
   if (stats || acc)
     hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(64), 0, stream, ws, P, 1.f / (float)B, stats, acc);
@@ -480,7 +480,7 @@ int coskad_poincare_head_f32(const float* z, const float* c, float* dz, float* z
 int coskad_poincare_dist_f32(const float* zh, const float* c, float* score, int B, int L, hipStream_t stream) {
   if (!zh || !c || !score) return fail(COSKAD_ERR_ARG, "poincare_dist: null pointer");
   if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "poincare_dist: B=%d latent=%d", B, L);
-  hipLaunchKernelGGL(k_poincare_dist, dim3(ceil_div(B, kBlock)), dim3(kBlock), 0, stream, zh, c, score, B, L);
+  hipLaunchKernelGGL(k_poincare_dist, dim3(ceil_div(B, kFlatBlock)), dim3(kFlatBlock), 0, stream, zh, c, score, B, L);
   return check_launch("poincare_dist");
 }
 

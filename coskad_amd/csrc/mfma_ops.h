@@ -31,7 +31,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n) {
-  for (int i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
 // ---- separable mixing on the LDS row image, in place -----------------------------------
@@ -41,6 +41,7 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict_
 // a strip phase use TV + 2: conflict-free (row, k) operand reads, see RedGeo in stsgcn_bwd.hip)
 template <int T, int V, bool ADJ, int LDX = 0>
 __device__ __forceinline__ void temporal_mfma(float* img, int rows, const float* TwL, int tid = -1) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = LDX ? LDX : Geo<T, V>::LD;
   constexpr int KS = (T + 3) / 4;
   constexpr int RP = COSKAD_RP;   // row tiles per item: they share the B operand and give independent MFMA chains
@@ -90,6 +91,7 @@ __device__ __forceinline__ void temporal_mfma(float* img, int rows, const float*
 
 template <int T, int V, bool ADJ, int LDX = 0>
 __device__ __forceinline__ void spatial_mfma(float* img, int rows, const float* AwL, int tid = -1) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = LDX ? LDX : Geo<T, V>::LD;
   constexpr int KS = (V + 3) / 4;
   constexpr int RP = COSKAD_RP;   // row tiles per item (share B, independent chains)
@@ -206,7 +208,7 @@ namespace coskad {
 // src: [(2*Ci)][CoP] (rows 0..Ci-1: Z part, Ci..2Ci-1: X part)
 __device__ __forceinline__ void load_wfold_padded(float* Wl, const float* __restrict__ src, int Ci, int KZ,
                                                   int CoP, int nsrc) {
-  for (int e = threadIdx.x; e < nsrc * KZ * CoP; e += kBlock) {
+  for (int e = threadIdx.x; e < nsrc * KZ * CoP; e += blockDim.x) {
     const int k = e / CoP, o = e - k * CoP;
     const int part = k / KZ, c = k - part * KZ;
     Wl[e] = c < Ci ? src[(part * Ci + c) * CoP + o] : 0.f;

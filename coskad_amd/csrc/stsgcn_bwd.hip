@@ -57,7 +57,7 @@ __device__ __forceinline__ void outer_accum2(const float* ldsA, int ldA, int off
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
   const int i = lane & 15, k = lane >> 4;
-  for (int p0 = 4 * wave; p0 < npos; p0 += 4 * (kBlock / 64)) {
+  for (int p0 = 4 * wave; p0 < npos; p0 += 4 * (int)(blockDim.x >> 6)) {
     const bool pok = p0 + k < npos;
     float a[NTA], b[NTB];
 #pragma unroll
@@ -83,6 +83,7 @@ __device__ __forceinline__ void outer_accum2(const float* ldsA, int ldA, int off
 // stage rows x [pbeg, pbeg+npos) of a [rows][TV] global tile into a chunk image with stride LDC
 template <int T, int V, int LDCX = 0>
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ g, float* lds, int rows, int pbeg, int npos) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int TV = T * V, LDC = LDCX ? LDCX : RedGeo<T, V>::LDC;
   const int n4 = npos >> 2;               // pbeg and npos are multiples of 4, TV % 4 == 0
   constexpr int UB = 3;   // HBM loads in flight per thread (64 rows x 17 float4 = 2.1 per thread)
@@ -108,13 +109,14 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ g, float* 
 }
 
 template <int T, int V, int NTO, int NTC>
-__global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce(const float* __restrict__ in,
+__global__ __launch_bounds__((Geo<T, V>::Block), (Geo<T, V>::Block <= 512 && NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce(const float* __restrict__ in,
                                                       const float* __restrict__ dU,
                                                       const float* __restrict__ Aw,
                                                       const float* __restrict__ Tw,
                                                       const float* __restrict__ in_slope,
                                                       float* __restrict__ partials, int B, int Ci,
                                                       int Co, int NB, int need_q, const float* __restrict__ Zg) {
+  constexpr int kScratchFloats = Geo<T, V>::Scratch;
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   constexpr int NCH = RedGeo<T, V>::NCH, CH = RedGeo<T, V>::CH, LDC = RedGeo<T, V>::LDC;
   static_assert(TV % 4 == 0, "chunked staging uses float4");
@@ -178,7 +180,7 @@ __device__ __forceinline__ void outer_accum_pq(const float* ldsA, int ldA, int v
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
   const int i = lane & 15, k = lane >> 4;
-  for (int p0 = 4 * wave; p0 < npos; p0 += 4 * (kBlock / 64)) {
+  for (int p0 = 4 * wave; p0 < npos; p0 += 4 * (int)(blockDim.x >> 6)) {
     const bool pok = p0 + k < npos;
     float a[NTA], bz[NTB], bx[NTB];
 #pragma unroll
@@ -206,7 +208,7 @@ __device__ __forceinline__ void outer_accum_pq(const float* ldsA, int ldA, int v
 }
 
 template <int T, int V, int NTO, int NTC>
-__global__ __launch_bounds__(kBlock, (NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce_z(
+__global__ __launch_bounds__((Geo<T, V>::Block), (Geo<T, V>::Block <= 512 && NTO * NTC <= 2 ? 6 : 4)) void k_bwd_reduce_z(
     const float* __restrict__ in, const float* __restrict__ Zg, const float* __restrict__ dU,
     const float* __restrict__ in_slope, float* __restrict__ partials, int B, int Ci, int Co, int NB, int need_q) {
   constexpr int TV = Geo<T, V>::TV, LD = RedGeo<T, V>::LDZ;
@@ -484,11 +486,12 @@ __global__ __launch_bounds__(1024) void k_bwd_fold(
 //    power of two (register arrays need static bounds).
 // ---------------------------------------------------------------------------------------
 template <int T, int V, int OTI>
-__global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
+__global__ __launch_bounds__((Geo<T, V>::Block), kMinWaves) void k_bwd_data(
     const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
     float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
     int Co, int NB, const float* __restrict__ Zg) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sred[kBlock / 64];
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data(
 // ---------------------------------------------------------------------------------------
 // NBF clips per tile (NBF * C_in = 32 rows: 1 clip of 32 channels or 2 clips of 16); a wave owns its strip in every clip.
 template <int T, int V, int OTI, int NBF>
-__global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
+__global__ __launch_bounds__((Geo<T, V>::Block), kMinWaves) void k_bwd_data_f(
     const float* __restrict__ in, const float* __restrict__ dU, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ coef, const float* __restrict__ in_slope,
     float* __restrict__ dIn, float* __restrict__ dZout, float* __restrict__ da_partials, int B, int Ci,
@@ -613,6 +616,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void k_bwd_data_f(
     , int abl
 #endif
     ) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
 #ifndef COSKAD_ABLATE
   constexpr int abl = 0;
 #endif
@@ -877,7 +881,7 @@ __device__ __forceinline__ void rowk_accum(const float* img1, int a0, int na, co
 }
 
 template <int T, int V>
-__global__ __launch_bounds__(kBlock, (V <= 17 ? 6 : 4)) void k_bwd_gcn_params(const float* __restrict__ in,
+__global__ __launch_bounds__((Geo<T, V>::Block), (V <= 17 ? 6 : 4)) void k_bwd_gcn_params(const float* __restrict__ in,
                                                           const float* __restrict__ dZ,
                                                           const float* __restrict__ Aw,
                                                           const float* __restrict__ Tw,
@@ -888,6 +892,7 @@ __global__ __launch_bounds__(kBlock, (V <= 17 ? 6 : 4)) void k_bwd_gcn_params(co
                                                           , int abl
 #endif
                                                           ) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
 #ifndef COSKAD_ABLATE
   constexpr int abl = 0;
 #endif
@@ -1251,6 +1256,7 @@ static int launch_layer_gcn_params(const float* in, const float* in_slope, const
                                    const float* Tw, float* dA, float* dT, float* partials, int accumulate, int B,
                                    int Ci, int Co_tag, hipStream_t st, const float* dap = nullptr, int ndap = 0,
                                    float* dslope = nullptr) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = Geo<T, V>::LD;
   const int E = T * V * V + V * T * T;
   // Both products sum over rows = (clip, channel) and the mixing is per row, so a tile is ANY run of consecutive rows
@@ -1291,6 +1297,8 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
                             float* dbr2, float* dslope_in, void* ws, size_t ws_bytes, int accumulate,
                             int B, int Ci, int Co, hipStream_t st, float* dz_ext = nullptr,
                             const float* Zg = nullptr) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
+  constexpr int kScratchFloats = Geo<T, V>::Scratch;
   // dz_ext != NULL: dZ goes to the caller's buffer and stage 4 (dA, dT) is left to coskad_layer_gcn_params_f32
   constexpr int LD = Geo<T, V>::LD, TV = Geo<T, V>::TV;
   if (Ci > 64 || Co > 64) return fail(COSKAD_ERR_SHAPE, "layer_bwd: channels (%d,%d) > 64 not supported", Ci, Co);
@@ -1332,7 +1340,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
       hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, w.red);
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
     } else if (Zg && zlds(1) <= (size_t)kMaxLdsBytes) {
-      const bool three_z = nto * ntc <= 2;
+      const bool three_z = nto * ntc <= 2 && kBlock <= 512;   // (16-wave blocks: at most two per CU)
       const size_t cap = three_z ? (size_t)52 * 1024 : (size_t)76 * 1024;
       int NBz = NB;
       while (NBz > 1 && zlds(NBz) > cap) --NBz;
@@ -1369,7 +1377,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     } else {
     // blocks per CU: three when the accumulators are small enough for 6 waves/SIMD and the images fit a third of
     // the LDS (fewer clips per tile if need be), else two
-    const bool three = nto * ntc <= 2;
+    const bool three = nto * ntc <= 2 && kBlock <= 512;
     const size_t lds_cap = three ? (size_t)52 * 1024 : (size_t)76 * 1024;   // (LDS is allocated in coarse granules)
     while (NB > 1 && red_lds(NB) > lds_cap) --NB;
     const size_t lds = red_lds(NB);
@@ -1442,7 +1450,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "layer_bwd: LDS %zu too large", lds);
     const int ntl = ceil_div(B, NB);
     const int per_cu = (int)((size_t)kMaxLdsBytes / lds);
-    grid_d = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    grid_d = 256 * (per_cu < 1 ? 1 : (per_cu > 2048 / kBlock ? 2048 / kBlock : per_cu));   // (a CU holds 32 waves)
     if (grid_d > ntl) grid_d = ntl;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
 #define LAUNCH_D(OTI)                                                                                   \
@@ -1513,6 +1521,7 @@ namespace coskad {
 template <int T, int V>
 static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* Aw, const float* Tw, float* dA,
                                  float* dT, void* ws, int accumulate, int rows, hipStream_t st) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = Geo<T, V>::LD;
   const int E = T * V * V + V * T * T;
   const int NB = rows < 32 ? rows : 32;

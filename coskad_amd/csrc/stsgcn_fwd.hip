@@ -22,11 +22,12 @@ namespace coskad {
 //           rounded up to 16, pad columns zero.
 // --------------------------------------------------------------------------------------
 template <int T, int V, int CB>
-__global__ __launch_bounds__(kBlock) void k_layer_apply(
+__global__ __launch_bounds__((Geo<T, V>::Block)) void k_layer_apply(
     const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ wfold, const float* __restrict__ bias,
     const float* __restrict__ in_slope, const float* __restrict__ out_slope, int B, int Ci, int Co,
     int CoP, int NB) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int clip0 = blockIdx.x * NB;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_layer_apply(
 // module mirror of that class.  rows = N*C rows of TV floats, 64 rows per tile.
 // --------------------------------------------------------------------------------------
 template <int T, int V, bool ADJ>
-__global__ __launch_bounds__(kBlock) void k_gcn(const float* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__((Geo<T, V>::Block)) void k_gcn(const float* __restrict__ in, float* __restrict__ out,
                                                 const float* __restrict__ Aw,
                                                 const float* __restrict__ Tw, int total_rows) {
   constexpr int TV = Geo<T, V>::TV;
@@ -275,6 +276,7 @@ template <int T, int V>
 static int launch_layer_apply(const float* in, float* out, const float* Aw, const float* Tw,
                               const float* wfold, const float* bias, const float* in_slope,
                               const float* out_slope, int B, int Ci, int Co, hipStream_t st) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = Geo<T, V>::LD;
   if (use_mfma()) {
     const int rc = launch_layer_apply_m<T, V>(in, out, Aw, Tw, wfold, bias, in_slope, out_slope, B, Ci, Co, st, nullptr);
@@ -304,6 +306,7 @@ static int launch_layer_apply(const float* in, float* out, const float* Aw, cons
 template <int T, int V>
 static int launch_gcn(const float* in, float* out, const float* Aw, const float* Tw, int rows,
                       int adjoint, hipStream_t st) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = Geo<T, V>::LD;
   const size_t lds = (size_t)64 * LD * sizeof(float);
   const int grid = ceil_div(rows, 64);

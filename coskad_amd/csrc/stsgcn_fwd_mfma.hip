@@ -8,11 +8,12 @@
 namespace coskad {
 
 template <int T, int V, int OTI>
-__global__ __launch_bounds__(kBlock) void k_layer_apply_m(
+__global__ __launch_bounds__((Geo<T, V>::Block)) void k_layer_apply_m(
     const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ Aw,
     const float* __restrict__ Tw, const float* __restrict__ wfold, const float* __restrict__ bias,
     const float* __restrict__ in_slope, const float* __restrict__ out_slope, int B, int Ci, int Co,
     int CoP, int NB, int dbg, const float* __restrict__ Zg) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
 #ifndef COSKAD_ABLATE
   dbg = 0;   // product build: every `dbg &` test below folds away (phase ablation needs -DCOSKAD_ABLATE)
@@ -202,6 +203,7 @@ template <int T, int V>
 int launch_layer_apply_m(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold,
                          const float* bias, const float* in_slope, const float* out_slope, int B, int Ci,
                          int Co, hipStream_t st, const float* Zg) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   const int CoP = round_up(Co, 16);
   int NB = Ci >= 32 ? 1 : 32 / Ci;   // 32 rows per tile: 2 row tiles of 16
   if (NB > B) NB = B;
@@ -209,7 +211,7 @@ int launch_layer_apply_m(const float* in, float* out, const float* Aw, const flo
   if (lds > (size_t)kMaxLdsBytes) return 1;  // caller falls back to the VALU kernel
   const int ntiles = ceil_div(B, NB);
   const int per_cu = (int)((size_t)kMaxLdsBytes / lds);
-  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 2048 / kBlock ? 2048 / kBlock : per_cu));   // (a CU holds 32 waves)
   if (grid > ntiles) grid = ntiles;
 #define LAUNCH_OTI(OTI)                                                                             \
   do {                                                                                              \

@@ -20,12 +20,13 @@ namespace coskad {
 constexpr int kMaxGrid = 768;  // persistent blocks of the reduction kernels (= partials to sum)
 
 template <int T, int V, int NTC>
-__global__ __launch_bounds__(kBlock, (NTC <= 2 ? 6 : 4)) void k_fwd_moments(const float* __restrict__ in,
+__global__ __launch_bounds__((Geo<T, V>::Block), (Geo<T, V>::Block <= 512 && NTC <= 2 ? 6 : 4)) void k_fwd_moments(const float* __restrict__ in,
                                                        const float* __restrict__ Aw,
                                                        const float* __restrict__ Tw,
                                                        const float* __restrict__ in_slope,
                                                        float* __restrict__ partials, int B, int Ci,
                                                        int NB, int need_x, float* __restrict__ Zout) {
+  constexpr int kScratchFloats = Geo<T, V>::Scratch;
   constexpr int TV = Geo<T, V>::TV, LD = TV + 2;   // even stride == 2 (mod 4): no strip phase here, conflict-free (row, k) reads
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* scratch = lds;                 // kScratchFloats, aliased onto the row image (only used after the tile loop)
@@ -317,6 +318,8 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
                               float* rv_r, long long* nbt_r, float momentum, float* wfold, float* bias,
                               float* stat, void* ws, size_t ws_bytes, int B, int Ci, int Co,
                               hipStream_t st, float* Zout = nullptr) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
+  constexpr int kScratchFloats = Geo<T, V>::Scratch;
   constexpr int TV = Geo<T, V>::TV, LD = TV + 2;   // k_fwd_moments' row stride
   static_assert(TV % 4 == 0, "the moments kernel stages with float4 and needs TV + 2 == 2 (mod 4)");
   if (Ci > 64) return fail(COSKAD_ERR_SHAPE, "train_stats: C_in=%d > 64 not supported", Ci);
@@ -330,7 +333,7 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   if (lds > (size_t)kMaxLdsBytes) return fail(COSKAD_ERR_SHAPE, "train_stats: LDS %zu too large", lds);
   const int ntiles = ceil_div(B, NB);
   // persistent blocks: as many 512-thread blocks per CU as LDS (coarse granules: keep a margin) and VGPRs allow
-  const int per_cu = lds <= (size_t)52 * 1024 && Ci <= 32 ? 3 : (lds <= (size_t)80 * 1024 ? 2 : 1);
+  const int per_cu = lds <= (size_t)52 * 1024 && Ci <= 32 && kBlock <= 512 ? 3 : (lds <= (size_t)80 * 1024 ? 2 : 1);
   const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
   float* partials = reinterpret_cast<float*>(ws);
   double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + round_up((int)(kMaxGrid * (size_t)E * sizeof(float)), 256));

@@ -25,6 +25,7 @@ namespace coskad {
 template <int T, int V, int LDX = 0>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* lds, int nfloats,
                                            bool do_prelu, float slope, int tid = -1) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   if (tid < 0) tid = threadIdx.x;
   constexpr int TV = Geo<T, V>::TV, LD = LDX ? LDX : Geo<T, V>::LD;
   if constexpr (TV % 4 == 0) {
@@ -68,6 +69,7 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* l
 // Write the LDS row image back to a contiguous HBM tile.
 template <int T, int V, int LDX = 0>
 __device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* lds, int nfloats, int tid = -1) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   if (tid < 0) tid = threadIdx.x;
   constexpr int TV = Geo<T, V>::TV, LD = LDX ? LDX : Geo<T, V>::LD;
   if constexpr (TV % 4 == 0) {
@@ -156,6 +158,7 @@ __device__ __forceinline__ void spatial_row(float* r, int t, const float* __rest
 // Work split: lane <-> row (64 rows per batch), wave <-> slice of v (or t).
 template <int T, int V, bool TEMPORAL, bool ADJ>
 __device__ __forceinline__ void mix_rows(float* lds, int rows, const float* __restrict__ W) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = Geo<T, V>::LD;
   constexpr int NPART = kBlock / 64;
   constexpr int EXT = TEMPORAL ? V : T;
@@ -212,6 +215,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 template <int T, int V, int NTA, int NTB, bool SUMS>
 __device__ __forceinline__ void outer_accum(const float* ldsA, int va, const float* ldsB, int vb,
                                             f32x4 (&acc)[NTA][NTB], f32x4 (&sacc)[NTA]) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int TV = Geo<T, V>::TV, LD = Geo<T, V>::LD;
   static_assert(TV % 4 == 0, "positions must be a multiple of the MFMA K step");
   const int lane = threadIdx.x & 63;
@@ -246,6 +250,7 @@ __device__ __forceinline__ void outer_accum(const float* ldsA, int va, const flo
 // Row sums ride along on the VALU (one add per tile and k-step) instead of an extra MFMA against ones.
 template <int T, int V, int NT, int LDX = 0>
 __device__ __forceinline__ void moment_accum(const float* img, int valid, f32x4 (&acc)[NT][NT], float (&rs)[NT]) {
+  constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int TV = Geo<T, V>::TV, LD = LDX ? LDX : Geo<T, V>::LD;
   static_assert(TV % 4 == 0, "positions must be a multiple of the MFMA K step");
   const int lane = threadIdx.x & 63;
@@ -273,7 +278,7 @@ template <int NT>
 __device__ __forceinline__ void store_moments(const f32x4 (&acc)[NT][NT], const float (&rs)[NT], float* scratch,
                                               float* dst, int ldd, float* sums, int valid) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = kBlock / 64;
+  const int NW = blockDim.x >> 6;
 #pragma unroll
   for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
@@ -333,7 +338,7 @@ __device__ __forceinline__ void store_outer(const f32x4 (&acc)[NTA][NTB], float*
         const int row = e >> 4, col = e & 15;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) s += scratch[w * 256 + e];
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += scratch[w * 256 + e];
         if (16 * ta + row < va && 16 * tb + col < vb) dst[(16 * ta + row) * ldd + 16 * tb + col] = s;
       }
     }
@@ -355,7 +360,7 @@ __device__ __forceinline__ void store_sums(const f32x4 (&sacc)[NTA], float* scra
     if (e < 16 && 16 * ta + e < va) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w) s += scratch[w * 16 + e];
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += scratch[w * 16 + e];
       dst[16 * ta + e] = s;
     }
   }
@@ -378,7 +383,7 @@ __device__ __forceinline__ void store_rowsums(const float (&rs)[NT], float* scra
     if (e < 16 && 16 * t + e < valid) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w) s += scratch[w * 16 + e];
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += scratch[w * 16 + e];
       sums[16 * t + e] = s;
     }
   }
