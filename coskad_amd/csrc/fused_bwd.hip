@@ -72,12 +72,16 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
 #define FB_STAMP(k) do {} while (0)
 #endif
 
-template <int CT, int OT>
+// NS = 1: the layer BELOW is a first layer (two input channels, raw input): its batch reductions P = sum dU.Z^T, Q = sum dU.X^T,
+// sdU (stage 1 of ITS backward, k_first_stats) are formed here, from the dU rows this kernel has just produced in its image
+// (one re-read of 107 MB and a launch fewer); `below_z` / `below_x` [B,2,T,V], `below_stats` [grid][2 Ci 2 + Ci] partial rows.
+template <int CT, int OT, int NS = 0>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restrict__ in, const float* __restrict__ Zg,
                                                            const float* __restrict__ dU, const float* __restrict__ coef,
                                                            const float* __restrict__ btab, const float* __restrict__ in_slope,
                                                            float* __restrict__ dIn, float* __restrict__ partials,
-                                                           float* __restrict__ dap, int B) {
+                                                           float* __restrict__ dap, int B, const float* __restrict__ below_z,
+                                                           const float* __restrict__ below_x, float* __restrict__ below_stats) {
   constexpr int Ci = 16 * CT, Co = 16 * OT, CiP = Ci, NG = OT + CT;
   constexpr int KT0 = (Co + Ci) * CiP, DX0 = KT0 + CiP, KR0 = DX0 + (Co + Ci) * CiP;
   static_assert(CT <= 2, "dT stages one 16-row half of X at a time");
@@ -113,6 +117,11 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
   // column t of exB collects dA[t][0..15][16] (B operand masked to column t); the corner element is a plain sum.
   f32x4 dAacc[T], dTacc[V], exA = {0.f, 0.f, 0.f, 0.f}, exB = {0.f, 0.f, 0.f, 0.f};
   float corner = 0.f;
+  // (NS) the layer below: rows of [P | Q] for its output channels 16 ct + 4q + r against (Z0 Z1 X0 X1) in columns j < 4, row sums
+  f32x4 nsacc[CT][2];
+  float nss[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) { nsacc[ct][0] = nsacc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f}; nss[ct] = 0.f; }
 #pragma unroll
   for (int t = 0; t < T; ++t) dAacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -402,13 +411,19 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
 #pragma unroll
         for (int i = UH; i < XL; ++i) u[i] = buf_load4(xres, l16, 64 * i * 16);
       }
+      float4 pg[4];                                      // (NS) the layer below: Z rows 0, 1 and X rows 0, 1, two pieces each
+      if constexpr (NS == 1) {
+        const BufRes zp = clip_res(below_z, clip, 2), xp = clip_res(below_x, clip, 2);
+        pg[0] = buf_load4(zp, l16, 0); pg[1] = buf_load4(zp, l16, 1024);
+        pg[2] = buf_load4(xp, l16, 0); pg[3] = buf_load4(xp, l16, 1024);
+      }
       gload(dun, 0);
       const int ln = olane();
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
         const int e4 = ln + 64 * i;
         const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
-        const float* p = r1 + (e4 < N4 ? row * LD + col : PADCOL);
+        float* p = r1 + (e4 < N4 ? row * LD + col : PADCOL);
         const float2 g0 = *reinterpret_cast<const float2*>(p), g1 = *reinterpret_cast<const float2*>(p + 2);
         float g[4] = {g0.x, g0.y, g1.x, g1.y};
         if (pre && e4 < N4) {
@@ -420,7 +435,42 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
           }
         }
         buf_store4(ores, l16, 64 * i * 16, float4{g[0], g[1], g[2], g[3]});    // beyond the clip: dropped (bounds check)
+        if constexpr (NS != 0) {                         // the image keeps dU_prev for the reductions below
+          *reinterpret_cast<float2*>(p) = float2{g[0], g[1]};
+          *reinterpret_cast<float2*>(p + 2) = float2{g[2], g[3]};
+        }
         xs[i] = buf_load4(xn, l16, 64 * i * 16);
+      }
+      if constexpr (NS == 1) {
+        // ---- the layer below: [P | Q] += dU_prev (image rows) x (Z0 Z1 X0 X1)^T (window rows 0..3), (row, position) operands -----
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = ln + 64 * (c & 1);
+          const int row = e / (TV / 4), col = 4 * (e - row * (TV / 4));
+          if (e < 2 * (TV / 4)) *reinterpret_cast<float4*>(r2 + (2 * (c >> 1) + row) * LDW + col) = pg[c];
+        }
+        L = geo();
+        const float* pb = r2 + (L.j & 3) * LDW + 2 * L.q;
+        const bool bok = L.j < 4;
+        constexpr int NM = (TV + 7) / 8;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          float2 b = *reinterpret_cast<const float2*>(pb + 8 * m);
+          bool ok = bok;
+          if (8 * (m + 1) > TV) ok = ok && 8 * m + 2 * L.q < TV;   // the last step's tail lies in the rows' padding
+          b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            float2 a = *reinterpret_cast<const float2*>(r1 + (16 * ct + L.j) * LD + 2 * L.q + 8 * m);
+            if (8 * (m + 1) > TV) {
+              const bool aok = 8 * m + 2 * L.q < TV;
+              a.x = aok ? a.x : 0.f; a.y = aok ? a.y : 0.f;
+            }
+            nsacc[ct][0] = mfma(a.x, b.x, nsacc[ct][0]);
+            nsacc[ct][1] = mfma(a.y, b.y, nsacc[ct][1]);
+            nss[ct] += a.x + a.y;
+          }
+        }
       }
     }
   }
@@ -437,7 +487,30 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
     for (int v = 0; v < V; ++v) mine[(PR_T + v) * 64] = float4{dTacc[v][0], dTacc[v][1], dTacc[v][2], dTacc[v][3]};
     da = wave_sum(da);
     if (lane == 0) lds[PR_N * 256] = da;                 // behind the records
+    if constexpr (NS == 1) {                             // the layer below's sums: [o][Z0 Z1 X0 X1] and the row sums, behind that
+      float* S = lds + PR_N * 256 + 64;
+      L = geo();
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (L.j < 4) S[(16 * ct + 4 * L.q + r) * 4 + L.j] = nsacc[ct][0][r] + nsacc[ct][1][r];
+        const float t = quad_sum(nss[ct]);
+        if (L.q == 0) S[64 * CT + 16 * ct + L.j] = t;
+      }
+    }
     __syncthreads();
+    if constexpr (NS == 1) {                             // one partial row per block: [P Ci x 2][Q Ci x 2][sdU Ci], waves in fixed order
+      constexpr int NSE = 5 * Ci;
+      const int e = threadIdx.x;
+      if (e < NSE) {
+        const int off = PR_N * 256 + 64 + e;
+        const float v = ((lds_all[off] + lds_all[WAVE_LDS_W + off]) + lds_all[2 * WAVE_LDS_W + off]) + lds_all[3 * WAVE_LDS_W + off];
+        int dst = e;                                     // sums: 4 Ci + o
+        if (e < 4 * Ci) { const int o = e >> 2, jj = e & 3; dst = jj < 2 ? o * 2 + jj : 2 * Ci + o * 2 + (jj - 2); }
+        below_stats[(size_t)blockIdx.x * NSE + dst] = v;
+      }
+    }
     constexpr int RPW = PR_N / 4;                        // records per wave (8)
     static_assert(PR_N % 4 == 0, "records split evenly over the four waves");
 #pragma unroll
@@ -475,7 +548,8 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
 // stage 3 + 4 of launch_layer_bwd for the shapes this kernel is built for; partials: >= grid rows of EROW floats, dap: >= grid floats
 int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
                            const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
-                           float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out) {
+                           float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out, const float* below_z,
+                           const float* below_x, float* below_stats) {
   // (btab: built from Aw / Tw by the extra blocks of the fold launch, stsgcn_bwd.hip)
   const size_t lds = (size_t)4 * ff::WAVE_LDS_W * sizeof(float);
   const int nblk = (B + 3) / 4;
@@ -488,11 +562,21 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
   do {                                                                                                                 \
     auto k = fb::k_layer_bwd_fused<CT, OT>;                                                                            \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, B); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, B, \
+                       below_z, below_x, below_stats);                                                                 \
+  } while (0)
+#define LAUNCH_FB_NS(CT, OT)                                                                                           \
+  do {                                                                                                                 \
+    auto k = fb::k_layer_bwd_fused<CT, OT, 1>;                                                                         \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, B, \
+                       below_z, below_x, below_stats);                                                                 \
   } while (0)
   {
     ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
-    if (Ci == 16 && Co == 16) LAUNCH_FB(1, 1);
+    if (below_stats && Ci == 32 && Co == 16) LAUNCH_FB_NS(2, 1);
+    else if (below_stats) return fail(COSKAD_ERR_SHAPE, "bwd_fused: the reductions of the layer below are built into the 32 -> 16 kernel only");
+    else if (Ci == 16 && Co == 16) LAUNCH_FB(1, 1);
     else if (Ci == 16 && Co == 32) LAUNCH_FB(1, 2);
     else if (Ci == 16 && Co == 64) LAUNCH_FB(1, 4);
     else if (Ci == 32 && Co == 16) LAUNCH_FB(2, 1);
@@ -501,6 +585,7 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
     else return fail(COSKAD_ERR_SHAPE, "bwd_fused: unsupported channels (%d, %d)", Ci, Co);
   }
 #undef LAUNCH_FB
+#undef LAUNCH_FB_NS
   return check_launch("bwd_fused");
 }
 
@@ -509,6 +594,13 @@ int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, c
   hipLaunchKernelGGL(fb::k_reduce_fused, dim3(fb::EROW / 64 + (dap ? 1 : 0)), dim3(1024), 0, st, partials, rows, dA, dT, dap, rows,
                      dslope, accumulate);
   return check_launch("bwd_reduce_fused");
+}
+
+// rows of [2 Ci below_Ci + Ci] floats the data kernel of a (Ci -> Co) layer writes for the layer below it (0: it cannot)
+int layer_bwd_below_rows(int T_, int V_, int B, int Ci, int Co, int below_Ci) {
+  if (!(T_ == ff::T && V_ == ff::V && Ci == 32 && Co == 16 && below_Ci == 2) || B <= 0) return 0;
+  const int nblk = (B + 3) / 4;
+  return nblk < FB_GRID ? nblk : FB_GRID;
 }
 
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co) {

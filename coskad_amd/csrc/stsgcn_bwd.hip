@@ -1201,7 +1201,9 @@ struct BwdWs {
 // fused_bwd.hip
 int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
                            const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
-                           float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out);
+                           float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out, const float* below_z,
+                           const float* below_x, float* below_stats);
+int layer_bwd_below_rows(int T_, int V_, int B, int Ci, int Co, int below_Ci);
 constexpr size_t kXscrFloats = (size_t)kMaxGridBwd * 13 * 2 * 256;   // fused_bwd.hip: one tile-major dXres slab per wave
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
 // fused_stats.hip
@@ -1296,7 +1298,10 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
                             float* dbt, float* dgs, float* dbs, float* dWr, float* dbr, float* dgr,
                             float* dbr2, float* dslope_in, void* ws, size_t ws_bytes, int accumulate,
                             int B, int Ci, int Co, hipStream_t st, float* dz_ext = nullptr,
-                            const float* Zg = nullptr) {
+                            const float* Zg = nullptr, const float* stats_in = nullptr, int stats_in_rows = 0,
+                            const float* below_in = nullptr, const float* below_z = nullptr, float* below_stats = nullptr) {
+  // stats_in: this layer's stage-1 partial rows, written by the call for the layer above (stage 1 is then skipped);
+  // below_*: the layer below's input / stored Z and the buffer its partial rows go to (fused data kernel only)
   constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int kScratchFloats = Geo<T, V>::Scratch;
   // dz_ext != NULL: dZ goes to the caller's buffer and stage 4 (dA, dT) is left to coskad_layer_gcn_params_f32
@@ -1327,7 +1332,10 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     // stored Z: one dU pass with X and Z both resident, no mixing tables in LDS.  When one clip's X + Z images exceed
     // the LDS (64 input channels at 25 joints: the default-width decoder on the NTU layout) the two-pass kernel below
     // runs instead; it takes the stored Z as well.
-    if (Zg && first_layer_ok(T, V, Ci, Co)) {
+    if (stats_in) {
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, stats_in, stats_in_rows, E, w.red);
+      if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+    } else if (Zg && first_layer_ok(T, V, Ci, Co)) {
       // a handful of input channels (the first layer): plain FMAs on full-line loads (first_layer.hip)
       int rows = 0;
       if ((rc = launch_first_stats(in, Zg, dU, in_slope, w.partials, B, Ci, Co, TV, need_q, kMaxGridBwd, st, &rows))) return rc;
@@ -1417,6 +1425,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   const size_t fold_lds = (size_t)(6 * Co + 2 * Co * Ci + Co) * sizeof(double) + (size_t)(4 * Co * Ci + 2 * Ci + 4 * Co) * sizeof(float);
   if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_bwd_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
   const bool fused = Zg && dIn && in_slope && !dz_ext && layer_bwd_fused_ok(T, V, Ci, Co);
+  if (below_stats && !fused) return fail(COSKAD_ERR_SHAPE, "layer_bwd_chain: the layer below's reductions need the fused data kernel");
   // the fused data kernel's operand tables are built by extra blocks of the fold launch (parameter-only work)
   const int tab_blocks = fused ? ceil_div(ff::BTAB_F4 * 4, 1024) : 0;
   const int NF = Co >= 32 ? 8 : (Co >= 16 ? 4 : 1);          // fold blocks (slices of the output channels / K pairs)
@@ -1427,7 +1436,8 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   if (fused) {
     int rows = 0;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
-    if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows)))
+    if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows,
+                                     below_z, below_in, below_stats)))
       return rc;
     return launch_reduce_fused(w.partials, rows, dA, dT, dap, dslope_in, accumulate, st);
   }
@@ -1622,6 +1632,46 @@ int coskad_layer_bwd_z_f32(const float* in, const float* dU, const float* A, con
   return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
                                   dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
                                   ws_bytes, accumulate, B, Ci, Co, stream, nullptr, Z)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+/* coskad_layer_bwd_z_f32 inside a chain of layers.  The batch reductions of a layer's backward (stage 1: P = sum dU.Z^T,
+ * Q = sum dU.X^T, sdU) read the dU the layer ABOVE has just produced; where that layer's data kernel can, it forms them itself:
+ *   stats_in [stats_in_rows][2 Co Ci + Co] : this layer's partial rows from the call for the layer above (NULL: stage 1 runs here)
+ *   below_in / below_Z [B, below_Ci, T, V], below_stats [coskad_layer_bwd_below_rows(...)][2 Ci below_Ci + Ci] : the layer
+ *     below's input (raw network input: no activation), stored Z and the buffer for ITS partial rows (NULL: not formed) */
+int coskad_layer_bwd_below_rows(int B, int Ci, int Co, int below_Ci, int T, int V) {
+  return layer_bwd_below_rows(T, V, B, Ci, Co, below_Ci);
+}
+
+int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A, const float* Tm,
+                               const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
+                               const float* Wr, const float* gamma_r, float* dIn, float* dA, float* dT, float* dWt,
+                               float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
+                               float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
+                               int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z,
+                               const float* stats_in, int stats_in_rows, const float* below_in, const float* below_Z,
+                               int below_Ci, float* below_stats, size_t below_stats_bytes) {
+  if (!in || !dU || !A || !Tm || !stat || !Wt || !gamma_t || !dA || !dT || !dWt || !dgamma_t || !dbeta_t || !ws || !Z)
+    return fail(COSKAD_ERR_ARG, "layer_bwd_chain: null pointer");
+  if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: residual grads missing");
+  if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: identity residual needs Ci == Co");
+  if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: B=%d Ci=%d Co=%d", B, Ci, Co);
+  if (stats_in && stats_in_rows <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: stats_in_rows=%d", stats_in_rows);
+  if (below_stats) {
+    if (!below_in || !below_Z) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: below_in / below_Z missing");
+    const int rows = layer_bwd_below_rows(T, V, B, Ci, Co, below_Ci);
+    if (rows == 0) return fail(COSKAD_ERR_SHAPE, "layer_bwd_chain: (%d -> %d) cannot form the reductions of a layer with %d input channels", Ci, Co, below_Ci);
+    const size_t need = (size_t)rows * (2 * (size_t)Ci * below_Ci + Ci) * sizeof(float);
+    if (below_stats_bytes < need) return fail(COSKAD_ERR_WORKSPACE, "layer_bwd_chain: below_stats %zu < %zu bytes", below_stats_bytes, need);
+  }
+  ProbeScope layer_probe(KID_LAYER_BWD, Ci, Co, stream);
+#define CALL(T_, V_)                                                                                       \
+  return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
+                                  dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
+                                  ws_bytes, accumulate, B, Ci, Co, stream, nullptr, Z, stats_in, stats_in_rows, \
+                                  below_stats ? below_in : nullptr, below_stats ? below_Z : nullptr, below_stats)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

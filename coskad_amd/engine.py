@@ -183,6 +183,8 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
 # training forward keeps Z = gcn(X) of every layer (82 channels x 816 B per clip) instead of recomputing the mixing in the
 # apply and backward kernels.  A module constant, not an environment switch: tests flip it to cover the recompute path.
 STORE_Z = True
+# backward: the data kernel of layer 2 also forms the batch reductions of layer 1 (csrc/fused_bwd.hip, NS = 1) where the shapes allow
+FUSE_BELOW = True
 # with the stored-Z path: layer i's apply kernel also produces layer i+1's Z and BatchNorm moment partials where
 # csrc/fused_apply_next.hip takes the shape (tests flip it to cover the separate statistics pass)
 FUSE_NEXT = True
@@ -221,6 +223,7 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
     main = torch.cuda.current_stream() if side is not None else None
     if side is not None:
         side.done = [None, None]     # the previous call joined the side stream: nothing of it is still in flight
+    stats_in = None          # (partial rows, rows) of layer i's batch reductions, formed by layer i + 1's data kernel
     for i in range(n - 1, -1, -1):
         L = layers[i]
         x_in = ctx.inputs[i]
@@ -234,7 +237,15 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
         buf = ws.get(ops.layer_bwd_ws_bytes(B, Ci, L.Co, T, V), x_in.device)
         args = (x_in, dU, L.A, L.T, in_slope, ctx.stats[i], L.w2(L.Wt), L.gt, L.w2(L.Wr), L.gr, _as2d(g), buf)
         if side is None:
-            dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate, Z=ctx.zs[i] if ctx.zs else None)
+            below = None
+            if FUSE_BELOW and ctx.zs and i == 1 and ctx.in_slope is None and in_slope is not None:
+                cb = ctx.inputs[0].shape[1]
+                rows = ops.layer_bwd_below_rows(B, Ci, L.Co, cb, T, V)
+                if rows:
+                    below = (ctx.inputs[0], ctx.zs[0], torch.empty(rows * (2 * Ci * cb + Ci), device=x_in.device, dtype=torch.float32))
+            dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate, Z=ctx.zs[i] if ctx.zs else None,
+                                stats_in=stats_in, below=below)
+            stats_in = (below[2], rows) if below is not None else None
         else:
             k = i & 1
             side.ensure(max(x.numel() for x in ctx.inputs), ops.layer_gcn_params_ws_bytes(T, V), x_in.device)

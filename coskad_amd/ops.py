@@ -261,10 +261,19 @@ def layer_bwd_ws_bytes(B, Ci, Co, T, V) -> int:
     return fn(i32(B), i32(Ci), i32(Co), i32(T), i32(V))
 
 
+def layer_bwd_below_rows(B: int, Ci: int, Co: int, below_Ci: int, T: int, V: int) -> int:
+    """Partial rows the (Ci -> Co) backward data kernel writes for the layer below it (0: that kernel cannot form them)."""
+    fn = _lib.lib().coskad_layer_bwd_below_rows
+    fn.restype = ctypes.c_int
+    return fn(i32(B), i32(Ci), i32(Co), i32(below_Ci), i32(T), i32(V))
+
+
 def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, need_dx=True,
-              dIn=None, accumulate=False, Z=None):
+              dIn=None, accumulate=False, Z=None, stats_in=None, below=None):
     """Backward of one layer.  `grads` maps names -> preallocated gradient tensors:
-    A, T, Wt, bt (opt), gt, bet, Wr, br (opt), gr, ber, slope_in (opt).  Returns dIn (or None)."""
+    A, T, Wt, bt (opt), gt, bet, Wr, br (opt), gr, ber, slope_in (opt).  Returns dIn (or None).
+    Chain mode (csrc: coskad_layer_bwd_chain_f32, needs Z): `stats_in` = (partial rows tensor, rows) the call for the layer above
+    wrote for this layer; `below` = (x_below, Z_below, below_stats) makes this call write the layer below's partial rows."""
     B, Ci, T, V = x_in.shape
     Co = Wt.shape[0]
     _chk(x_in, "x_in"); _chk(dU, "dU", (B, Co, T, V)); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
@@ -286,7 +295,19 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
             ptr(grads.get("bt")), ptr(grads["gt"]), ptr(grads["bet"]), ptr(grads.get("Wr")), ptr(grads.get("br")),
             ptr(grads.get("gr")), ptr(grads.get("ber")), ptr(grads.get("slope_in")), ptr(ws),
             ctypes.c_size_t(_bytes(ws)), i32(1 if accumulate else 0), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream())
-    if Z is None:
+    if stats_in is not None or below is not None:
+        if Z is None:
+            raise ValueError("layer_bwd: chain mode needs the stored Z")
+        sp, srows = stats_in if stats_in is not None else (None, 0)
+        _chk(sp, "stats_in", optional=True)
+        if sp is not None and sp.numel() < srows * (2 * Co * Ci + Co):
+            raise ValueError("layer_bwd: stats_in smaller than rows x (2 Co Ci + Co)")
+        xb, zb, bs = below if below is not None else (None, None, None)
+        cb = xb.shape[1] if xb is not None else 0
+        _chk(xb, "below x", (B, cb, T, V), optional=True); _chk(zb, "below Z", (B, cb, T, V), optional=True); _chk(bs, "below_stats", optional=True)
+        call("coskad_layer_bwd_chain_f32", *args, ptr(Z), ptr(sp), i32(srows), ptr(xb), ptr(zb), i32(cb), ptr(bs),
+             ctypes.c_size_t(_bytes(bs) if bs is not None else 0))
+    elif Z is None:
         call("coskad_layer_bwd_f32", *args)
     else:       # stored gcn(PReLU(x_in)) from layer_train_stats(..., Z=...): no mixing recompute in the backward kernels
         call("coskad_layer_bwd_z_f32", *args, ptr(Z))

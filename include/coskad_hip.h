@@ -233,6 +233,25 @@ size_t coskad_layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V);
  * from coskad_gcn_f32 + GEMMs. */
 int coskad_layer_fits(int Ci, int Co, int T, int V);
 
+/* coskad_layer_bwd_z_f32 inside a chain of layers (reference: autograd walks stsgcn.py:94-116 layer by layer, last to first).
+ * Stage 1 of a layer's backward (the batch reductions P = sum dU.Z^T, Q = sum dU.X^T, sdU) reads the dU the layer ABOVE has
+ * just produced; where that layer's data kernel holds it on chip, it forms the reductions itself:
+ *   stats_in [stats_in_rows][2 Co Ci + Co] : this layer's partial rows, written by the call for the layer above (NULL: stage 1
+ *                                            runs here, as in coskad_layer_bwd_z_f32)
+ *   below_in, below_Z [B,below_Ci,T,V]     : input (raw network input, no activation) and stored Z of the layer below
+ *   below_stats [coskad_layer_bwd_below_rows(B,Ci,Co,below_Ci,T,V)][2 Ci below_Ci + Ci] : receives ITS partial rows (NULL: not formed)
+ * coskad_layer_bwd_below_rows returns 0 when the (Ci -> Co) data kernel cannot form them (built: 32 -> 16 above a 2-channel layer,
+ * T = 12, V = 17). */
+int coskad_layer_bwd_below_rows(int B, int Ci, int Co, int below_Ci, int T, int V);
+int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A, const float* Tm,
+                               const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
+                               const float* Wr, const float* gamma_r, float* dIn, float* dA, float* dT, float* dWt,
+                               float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
+                               float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
+                               int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z,
+                               const float* stats_in, int stats_in_rows, const float* below_in, const float* below_Z,
+                               int below_Ci, float* below_stats, size_t below_stats_bytes);
+
 /* in   : the layer's input as stored by the producer (pre-activation; in_slope = its PReLU weight,
  *        NULL when `in` is the raw network input)
  * dU   : gradient w.r.t. this layer's pre-activation output [B,Co,T,V]
