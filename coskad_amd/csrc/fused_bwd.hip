@@ -72,16 +72,20 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
 #define FB_STAMP(k) do {} while (0)
 #endif
 
-// NS = 1: the layer BELOW is a first layer (two input channels, raw input): its batch reductions P = sum dU.Z^T, Q = sum dU.X^T,
-// sdU (stage 1 of ITS backward, k_first_stats) are formed here, from the dU rows this kernel has just produced in its image
-// (one re-read of 107 MB and a launch fewer); `below_z` / `below_x` [B,2,T,V], `below_stats` [grid][2 Ci 2 + Ci] partial rows.
-template <int CT, int OT, int NS = 0>
+// NS != 0: the batch reductions of the layer BELOW (stage 1 of ITS backward: P = sum dU.Z^T, Q = sum dU.X^T, sdU -- k_first_stats /
+// k_bwd_stats_ring) are formed here, from the dU rows this kernel has just produced in its image: a re-read of dU_prev and a
+// launch fewer.  `below_z` / `below_x` [B, Cb, T, V] (X = PReLU(below_x) with `below_slope`, NULL: raw input), `below_stats`
+// [grid][2 Ci Cb + Ci] partial rows as k_bwd_fold reads them.
+//   NS = 1: Cb = 2 (a first layer): Z0 Z1 X0 X1 are ONE 4-row operand group
+//   NS = 2: Cb = 16 CB: 2 CB groups of 16 rows through the K window, (row, position) operands on both sides
+template <int CT, int OT, int NS = 0, int CB = 0>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restrict__ in, const float* __restrict__ Zg,
                                                            const float* __restrict__ dU, const float* __restrict__ coef,
                                                            const float* __restrict__ btab, const float* __restrict__ in_slope,
                                                            float* __restrict__ dIn, float* __restrict__ partials,
                                                            float* __restrict__ dap, int B, const float* __restrict__ below_z,
-                                                           const float* __restrict__ below_x, float* __restrict__ below_stats) {
+                                                           const float* __restrict__ below_x, const float* __restrict__ below_slope,
+                                                           float* __restrict__ below_stats) {
   constexpr int Ci = 16 * CT, Co = 16 * OT, CiP = Ci, NG = OT + CT;
   constexpr int KT0 = (Co + Ci) * CiP, DX0 = KT0 + CiP, KR0 = DX0 + (Co + Ci) * CiP;
   static_assert(CT <= 2, "dT stages one 16-row half of X at a time");
@@ -122,6 +126,17 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
   float nss[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) { nsacc[ct][0] = nsacc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f}; nss[ct] = 0.f; }
+  // (NS = 2) group g of the layer below (Z groups, then X groups) against row tile ct: NCH chains per tile keep two MFMAs apart
+  constexpr int NGB = NS == 2 ? 2 * CB : 1, NCH = CT == 1 ? 2 : 1, NBUF = (NS == 2 && CB == 2) ? 2 : 1;
+  f32x4 nsb[NGB][CT][NCH];
+#pragma unroll
+  for (int g = 0; g < NGB; ++g)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) nsb[g][ct][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool bpre = NS != 0 && below_slope != nullptr;
+  const float a_b = bpre ? below_slope[0] : 0.f;
 #pragma unroll
   for (int t = 0; t < T; ++t) dAacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -164,6 +179,40 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
   auto gload = [&](const BufRes& res, int row0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) qload(res, row0, q);
+  };
+  // (NS = 2, two buffers) the same through a second set of registers
+  float4 gc[NBUF == 2 ? 16 : 1];
+  auto qload2 = [&](const BufRes& res, int row0, int q) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gc[(4 * q + c) % (NBUF == 2 ? 16 : 1)] = buf_load4(res, c < 3 ? l16 : l16t, ((row0 + 4 * q) * (TV / 4) + 64 * c) * 16);
+  };
+  auto qstore2 = [&](int q, bool act, float slope) {
+    const int ln = olane();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e = ln + 64 * c;
+      float4 v = gc[(4 * q + c) % (NBUF == 2 ? 16 : 1)];
+      if (act) { v.x = prelu(v.x, slope); v.y = prelu(v.y, slope); v.z = prelu(v.z, slope); v.w = prelu(v.w, slope); }
+      const int row = e / (TV / 4), col = 4 * (e - row * (TV / 4));
+      float* p = r2 + ((c < 3 || lane < QTAIL) ? (4 * q + row) * LD + col : 15 * LD + PADCOL);
+      *reinterpret_cast<float2*>(p) = float2{v.x, v.y};
+      *reinterpret_cast<float2*>(p + 2) = float2{v.z, v.w};
+    }
+  };
+  // (the statistics phase reads the window as (row, position) operands: its rows then lie LD apart like the image's -- the K
+  // window's own 208-float stride puts every other row on the same banks for that pattern -- at two 8-byte stores per float4)
+  auto qstore_b = [&](int q, bool act, float slope) {     // gb with another layer's slope
+    const int ln = olane();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e = ln + 64 * c;
+      float4 v = gb[4 * q + c];
+      if (act) { v.x = prelu(v.x, slope); v.y = prelu(v.y, slope); v.z = prelu(v.z, slope); v.w = prelu(v.w, slope); }
+      const int row = e / (TV / 4), col = 4 * (e - row * (TV / 4));
+      float* p = r2 + ((c < 3 || lane < QTAIL) ? (4 * q + row) * LD + col : 15 * LD + PADCOL);
+      *reinterpret_cast<float2*>(p) = float2{v.x, v.y};
+      *reinterpret_cast<float2*>(p + 2) = float2{v.z, v.w};
+    }
   };
   {
     const BufRes x0 = clip_res(in, clip, Ci), du0 = clip_res(dU, clip, Co);
@@ -391,6 +440,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
 #pragma unroll
           for (int i = 0; i < UH; ++i) u[i] = buf_load4(xres, l16, 64 * i * 16);
         }
+        if constexpr (NS == 2) gload(clip_res(below_z, clip, 16 * CB), 0);   // the layer below: its first Z group
         __builtin_amdgcn_sched_barrier(0);
       });
 #pragma unroll
@@ -417,7 +467,17 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         pg[0] = buf_load4(zp, l16, 0); pg[1] = buf_load4(zp, l16, 1024);
         pg[2] = buf_load4(xp, l16, 0); pg[3] = buf_load4(xp, l16, 1024);
       }
-      gload(dun, 0);
+      // group g of the layer below: Z rows 16 g .. (g < CB), then X rows
+      auto bres = [&](int g) { return g < CB ? clip_res(below_z, clip, 16 * CB) : clip_res(below_x, clip, 16 * CB); };
+      auto brow = [&](int g) { return 16 * (g < CB ? g : g - CB); };
+      if constexpr (NS == 2) {
+        if constexpr (NBUF == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) qload2(bres(1), brow(1), q);
+        }
+      } else {
+        gload(dun, 0);
+      }
       const int ln = olane();
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
@@ -441,37 +501,145 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         }
         xs[i] = buf_load4(xn, l16, 64 * i * 16);
       }
+      FB_STAMP(9);
+      if constexpr (NS == 2) {
+        // ---- the layer below: [P | Q] += dU_prev (image rows) x group^T (16 window rows), (row, position) operands on both sides.
+        // Group g is stored from its registers, which take group g + NBUF (at the end: the next clip's first dU group) at once ----
+        L = geo();
+        constexpr int NM = (TV + 7) / 8;
+#pragma unroll
+        for (int g = 0; g < NGB; ++g) {
+          const bool second = NBUF == 2 && (g & 1);
+          const bool act = g >= CB && bpre;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (second) {
+              qstore2(q, act, a_b);
+              if (g + NBUF < NGB) qload2(bres(g + NBUF), brow(g + NBUF), q);
+            } else {
+              qstore_b(q, act, a_b);
+              if (g + NBUF < NGB) qload(bres(g + NBUF), brow(g + NBUF), q);
+              else qload(dun, 0, q);                     // this buffer's last group: the next clip's first dU group takes off
+            }
+          }
+          // operands of step m + PF are read before step m multiplies: with two MFMAs per pair of LDS reads the loop is
+          // LDS-latency bound otherwise (measured: 9.5 us per clip for 208 MFMAs)
+          const float* pb = r2 + L.j * LD + 2 * L.q;
+          const float* pa = r1 + L.j * LD + 2 * L.q;
+          // (the 32 -> 64 kernel has no registers to spare: there the pipelined form costs spills in the row pass, 355 vs 325 us)
+          constexpr int PF = CT == 1 ? 6 : 0;
+          float2 bq[PF ? PF : 1], aq[PF ? PF : 1][CT];
+          if constexpr (PF == 0) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+              float2 b = *reinterpret_cast<const float2*>(pb + 8 * m);
+              const bool tail = 8 * (m + 1) > TV;
+              const bool ok = 8 * m + 2 * L.q < TV;
+              if (tail) { b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f; }
+              float2 a[CT];
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) {
+                a[ct] = *reinterpret_cast<const float2*>(pa + 16 * ct * LD + 8 * m);
+                if (tail) { a[ct].x = ok ? a[ct].x : 0.f; a[ct].y = ok ? a[ct].y : 0.f; }
+                if (g == 0) nss[ct] += a[ct].x + a[ct].y;
+              }
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) nsb[g][ct][0] = mfma(a[ct].x, b.x, nsb[g][ct][0]);
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) nsb[g][ct][NCH - 1] = mfma(a[ct].y, b.y, nsb[g][ct][NCH - 1]);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < PF; ++m) {
+            bq[m] = *reinterpret_cast<const float2*>(pb + 8 * m);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) aq[m][ct] = *reinterpret_cast<const float2*>(pa + 16 * ct * LD + 8 * m);
+          }
+#pragma unroll
+          for (int m = 0; m < (PF ? NM : 0); ++m) {
+            constexpr int PFD = PF ? PF : 1;
+            float2 b = bq[m % PFD];
+            float2 a[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) a[ct] = aq[m % PFD][ct];
+            if (m + PF < NM) {
+              bq[m % PFD] = *reinterpret_cast<const float2*>(pb + 8 * (m + PF));
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) aq[m % PFD][ct] = *reinterpret_cast<const float2*>(pa + 16 * ct * LD + 8 * (m + PF));
+            }
+            if (8 * (m + 1) > TV) {                      // the last step's tail lies in the rows' padding
+              const bool ok = 8 * m + 2 * L.q < TV;
+              b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) { a[ct].x = ok ? a[ct].x : 0.f; a[ct].y = ok ? a[ct].y : 0.f; }
+            }
+            if (g == 0) {
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) nss[ct] += a[ct].x + a[ct].y;
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) nsb[g][ct][0] = mfma(a[ct].x, b.x, nsb[g][ct][0]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) nsb[g][ct][NCH - 1] = mfma(a[ct].y, b.y, nsb[g][ct][NCH - 1]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + CT, 0);   // this step's reads (of step m + PF) ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * CT, 0);   // ... then its MFMAs
+          }
+        }
+      }
       if constexpr (NS == 1) {
         // ---- the layer below: [P | Q] += dU_prev (image rows) x (Z0 Z1 X0 X1)^T (window rows 0..3), (row, position) operands -----
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int e = ln + 64 * (c & 1);
           const int row = e / (TV / 4), col = 4 * (e - row * (TV / 4));
-          if (e < 2 * (TV / 4)) *reinterpret_cast<float4*>(r2 + (2 * (c >> 1) + row) * LDW + col) = pg[c];
+          float4 v = pg[c];
+          if (c >= 2 && bpre) { v.x = prelu(v.x, a_b); v.y = prelu(v.y, a_b); v.z = prelu(v.z, a_b); v.w = prelu(v.w, a_b); }
+          float* pw = r2 + (e < 2 * (TV / 4) ? (2 * (c >> 1) + row) * LD + col : 3 * LD + PADCOL);
+          *reinterpret_cast<float2*>(pw) = float2{v.x, v.y};
+          *reinterpret_cast<float2*>(pw + 2) = float2{v.z, v.w};
         }
         L = geo();
-        const float* pb = r2 + (L.j & 3) * LDW + 2 * L.q;
+        const float* pb = r2 + (L.j & 3) * LD + 2 * L.q;
+        const float* pa = r1 + L.j * LD + 2 * L.q;
         const bool bok = L.j < 4;
-        constexpr int NM = (TV + 7) / 8;
+        constexpr int NM = (TV + 7) / 8, PF = 6;
+        float2 bq[PF], aq[PF][CT];
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {
+          bq[m] = *reinterpret_cast<const float2*>(pb + 8 * m);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) aq[m][ct] = *reinterpret_cast<const float2*>(pa + 16 * ct * LD + 8 * m);
+        }
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-          float2 b = *reinterpret_cast<const float2*>(pb + 8 * m);
+          float2 b = bq[m % PF];
+          float2 a[CT];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) a[ct] = aq[m % PF][ct];
+          if (m + PF < NM) {
+            bq[m % PF] = *reinterpret_cast<const float2*>(pb + 8 * (m + PF));
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) aq[m % PF][ct] = *reinterpret_cast<const float2*>(pa + 16 * ct * LD + 8 * (m + PF));
+          }
           bool ok = bok;
-          if (8 * (m + 1) > TV) ok = ok && 8 * m + 2 * L.q < TV;   // the last step's tail lies in the rows' padding
+          if (8 * (m + 1) > TV) {                        // the last step's tail lies in the rows' padding
+            const bool aok = 8 * m + 2 * L.q < TV;
+            ok = ok && aok;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) { a[ct].x = aok ? a[ct].x : 0.f; a[ct].y = aok ? a[ct].y : 0.f; }
+          }
           b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
-            float2 a = *reinterpret_cast<const float2*>(r1 + (16 * ct + L.j) * LD + 2 * L.q + 8 * m);
-            if (8 * (m + 1) > TV) {
-              const bool aok = 8 * m + 2 * L.q < TV;
-              a.x = aok ? a.x : 0.f; a.y = aok ? a.y : 0.f;
-            }
-            nsacc[ct][0] = mfma(a.x, b.x, nsacc[ct][0]);
-            nsacc[ct][1] = mfma(a.y, b.y, nsacc[ct][1]);
-            nss[ct] += a.x + a.y;
+            nsacc[ct][0] = mfma(a[ct].x, b.x, nsacc[ct][0]);
+            nsacc[ct][1] = mfma(a[ct].y, b.y, nsacc[ct][1]);
+            nss[ct] += a[ct].x + a[ct].y;
           }
+          __builtin_amdgcn_sched_group_barrier(0x100, 1 + CT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * CT, 0);
         }
       }
+      FB_STAMP(10);
     }
   }
   // ---- the block's dA / dT sums: the four waves park their 32 records in their own LDS images, then each wave adds a
@@ -499,7 +667,35 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         if (L.q == 0) S[64 * CT + 16 * ct + L.j] = t;
       }
     }
+    if constexpr (NS == 2) {                             // the layer below's sums in the partial row's own layout, behind that
+      constexpr int Cb = 16 * CB;
+      float* S = lds + PR_N * 256 + 64;
+      L = geo();
+#pragma unroll
+      for (int g = 0; g < NGB; ++g)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 16 * ct + 4 * L.q + r;
+            const float v = NCH == 2 ? nsb[g][ct][0][r] + nsb[g][ct][NCH - 1][r] : nsb[g][ct][0][r];
+            S[(g < CB ? 0 : Ci * Cb) + o * Cb + 16 * (g < CB ? g : g - CB) + L.j] = v;
+          }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const float t = quad_sum(nss[ct]);
+        if (L.q == 0) S[2 * Ci * Cb + 16 * ct + L.j] = t;
+      }
+    }
     __syncthreads();
+    if constexpr (NS == 2) {                             // one partial row per block: [P Ci x Cb][Q Ci x Cb][sdU Ci], waves in fixed order
+      constexpr int NSE = 2 * Ci * 16 * CB + Ci;
+      for (int e = threadIdx.x; e < NSE; e += 256) {
+        const int off = PR_N * 256 + 64 + e;
+        below_stats[(size_t)blockIdx.x * NSE + e] =
+            ((lds_all[off] + lds_all[WAVE_LDS_W + off]) + lds_all[2 * WAVE_LDS_W + off]) + lds_all[3 * WAVE_LDS_W + off];
+      }
+    }
     if constexpr (NS == 1) {                             // one partial row per block: [P Ci x 2][Q Ci x 2][sdU Ci], waves in fixed order
       constexpr int NSE = 5 * Ci;
       const int e = threadIdx.x;
@@ -549,7 +745,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
 int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
                            const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
                            float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out, const float* below_z,
-                           const float* below_x, float* below_stats) {
+                           const float* below_x, const float* below_slope, int below_Ci, float* below_stats) {
   // (btab: built from Aw / Tw by the extra blocks of the fold launch, stsgcn_bwd.hip)
   const size_t lds = (size_t)4 * ff::WAVE_LDS_W * sizeof(float);
   const int nblk = (B + 3) / 4;
@@ -563,19 +759,21 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
     auto k = fb::k_layer_bwd_fused<CT, OT>;                                                                            \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, B, \
-                       below_z, below_x, below_stats);                                                                 \
+                       below_z, below_x, below_slope, below_stats);                                                    \
   } while (0)
-#define LAUNCH_FB_NS(CT, OT)                                                                                           \
+#define LAUNCH_FB_NS(CT, OT, NS, CB)                                                                                   \
   do {                                                                                                                 \
-    auto k = fb::k_layer_bwd_fused<CT, OT, 1>;                                                                         \
+    auto k = fb::k_layer_bwd_fused<CT, OT, NS, CB>;                                                                    \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, coef, btab, in_slope, dIn, partials, dap, B, \
-                       below_z, below_x, below_stats);                                                                 \
+                       below_z, below_x, below_slope, below_stats);                                                    \
   } while (0)
   {
     ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
-    if (below_stats && Ci == 32 && Co == 16) LAUNCH_FB_NS(2, 1);
-    else if (below_stats) return fail(COSKAD_ERR_SHAPE, "bwd_fused: the reductions of the layer below are built into the 32 -> 16 kernel only");
+    if (below_stats && Ci == 32 && Co == 16 && below_Ci == 2) LAUNCH_FB_NS(2, 1, 1, 0);
+    else if (below_stats && Ci == 16 && Co == 32 && below_Ci == 32) LAUNCH_FB_NS(1, 2, 2, 2);
+    else if (below_stats && Ci == 32 && Co == 64 && below_Ci == 16) LAUNCH_FB_NS(2, 4, 2, 1);
+    else if (below_stats) return fail(COSKAD_ERR_SHAPE, "bwd_fused: no kernel forms the reductions of a %d-channel layer below (%d -> %d)", below_Ci, Ci, Co);
     else if (Ci == 16 && Co == 16) LAUNCH_FB(1, 1);
     else if (Ci == 16 && Co == 32) LAUNCH_FB(1, 2);
     else if (Ci == 16 && Co == 64) LAUNCH_FB(1, 4);
@@ -598,7 +796,9 @@ int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, c
 
 // rows of [2 Ci below_Ci + Ci] floats the data kernel of a (Ci -> Co) layer writes for the layer below it (0: it cannot)
 int layer_bwd_below_rows(int T_, int V_, int B, int Ci, int Co, int below_Ci) {
-  if (!(T_ == ff::T && V_ == ff::V && Ci == 32 && Co == 16 && below_Ci == 2) || B <= 0) return 0;
+  const bool built = (Ci == 32 && Co == 16 && below_Ci == 2) || (Ci == 16 && Co == 32 && below_Ci == 32) ||
+                     (Ci == 32 && Co == 64 && below_Ci == 16);
+  if (!(T_ == ff::T && V_ == ff::V && built) || B <= 0) return 0;
   const int nblk = (B + 3) / 4;
   return nblk < FB_GRID ? nblk : FB_GRID;
 }

@@ -1202,7 +1202,7 @@ struct BwdWs {
 int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
                            const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
                            float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out, const float* below_z,
-                           const float* below_x, float* below_stats);
+                           const float* below_x, const float* below_slope, int below_Ci, float* below_stats);
 int layer_bwd_below_rows(int T_, int V_, int B, int Ci, int Co, int below_Ci);
 constexpr size_t kXscrFloats = (size_t)kMaxGridBwd * 13 * 2 * 256;   // fused_bwd.hip: one tile-major dXres slab per wave
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
@@ -1299,7 +1299,8 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
                             float* dbr2, float* dslope_in, void* ws, size_t ws_bytes, int accumulate,
                             int B, int Ci, int Co, hipStream_t st, float* dz_ext = nullptr,
                             const float* Zg = nullptr, const float* stats_in = nullptr, int stats_in_rows = 0,
-                            const float* below_in = nullptr, const float* below_z = nullptr, float* below_stats = nullptr) {
+                            const float* below_in = nullptr, const float* below_z = nullptr, const float* below_slope = nullptr,
+                            int below_Ci = 0, float* below_stats = nullptr) {
   // stats_in: this layer's stage-1 partial rows, written by the call for the layer above (stage 1 is then skipped);
   // below_*: the layer below's input / stored Z and the buffer its partial rows go to (fused data kernel only)
   constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
@@ -1437,7 +1438,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     int rows = 0;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
     if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows,
-                                     below_z, below_in, below_stats)))
+                                     below_z, below_in, below_slope, below_Ci, below_stats)))
       return rc;
     return launch_reduce_fused(w.partials, rows, dA, dT, dap, dslope_in, accumulate, st);
   }
@@ -1639,8 +1640,9 @@ int coskad_layer_bwd_z_f32(const float* in, const float* dU, const float* A, con
 /* coskad_layer_bwd_z_f32 inside a chain of layers.  The batch reductions of a layer's backward (stage 1: P = sum dU.Z^T,
  * Q = sum dU.X^T, sdU) read the dU the layer ABOVE has just produced; where that layer's data kernel can, it forms them itself:
  *   stats_in [stats_in_rows][2 Co Ci + Co] : this layer's partial rows from the call for the layer above (NULL: stage 1 runs here)
- *   below_in / below_Z [B, below_Ci, T, V], below_stats [coskad_layer_bwd_below_rows(...)][2 Ci below_Ci + Ci] : the layer
- *     below's input (raw network input: no activation), stored Z and the buffer for ITS partial rows (NULL: not formed) */
+ *   below_in / below_Z [B, below_Ci, T, V], below_in_slope, below_stats [coskad_layer_bwd_below_rows(...)][2 Ci below_Ci + Ci] :
+ *     the layer below's input as stored (pre-activation + its producer's PReLU weight, NULL for the raw network input), its
+ *     stored Z and the buffer for ITS partial rows (NULL: not formed) */
 int coskad_layer_bwd_below_rows(int B, int Ci, int Co, int below_Ci, int T, int V) {
   return layer_bwd_below_rows(T, V, B, Ci, Co, below_Ci);
 }
@@ -1652,7 +1654,7 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
                                float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                                int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z,
                                const float* stats_in, int stats_in_rows, const float* below_in, const float* below_Z,
-                               int below_Ci, float* below_stats, size_t below_stats_bytes) {
+                               const float* below_in_slope, int below_Ci, float* below_stats, size_t below_stats_bytes) {
   if (!in || !dU || !A || !Tm || !stat || !Wt || !gamma_t || !dA || !dT || !dWt || !dgamma_t || !dbeta_t || !ws || !Z)
     return fail(COSKAD_ERR_ARG, "layer_bwd_chain: null pointer");
   if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: residual grads missing");
@@ -1671,7 +1673,8 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
   return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, stat, Wt, gamma_t, Wr, gamma_r, dIn, dA, dT, dWt, \
                                   dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
                                   ws_bytes, accumulate, B, Ci, Co, stream, nullptr, Z, stats_in, stats_in_rows, \
-                                  below_stats ? below_in : nullptr, below_stats ? below_Z : nullptr, below_stats)
+                                  below_stats ? below_in : nullptr, below_stats ? below_Z : nullptr,                  \
+                                  below_stats ? below_in_slope : nullptr, below_Ci, below_stats)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

@@ -238,14 +238,15 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
         args = (x_in, dU, L.A, L.T, in_slope, ctx.stats[i], L.w2(L.Wt), L.gt, L.w2(L.Wr), L.gr, _as2d(g), buf)
         if side is None:
             below = None
-            if FUSE_BELOW and ctx.zs and i == 1 and ctx.in_slope is None and in_slope is not None:
-                cb = ctx.inputs[0].shape[1]
+            if FUSE_BELOW and ctx.zs and i > 0 and in_slope is not None and layers[i - 1].Wr is not None:
+                cb = ctx.inputs[i - 1].shape[1]
                 rows = ops.layer_bwd_below_rows(B, Ci, L.Co, cb, T, V)
                 if rows:
-                    below = (ctx.inputs[0], ctx.zs[0], torch.empty(rows * (2 * Ci * cb + Ci), device=x_in.device, dtype=torch.float32))
+                    below = (ctx.inputs[i - 1], ctx.zs[i - 1], layers[i - 2].slope if i > 1 else ctx.in_slope,
+                             torch.empty(rows * (2 * Ci * cb + Ci), device=x_in.device, dtype=torch.float32))
             dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate, Z=ctx.zs[i] if ctx.zs else None,
                                 stats_in=stats_in, below=below)
-            stats_in = (below[2], rows) if below is not None else None
+            stats_in = (below[3], rows) if below is not None else None
         else:
             k = i & 1
             side.ensure(max(x.numel() for x in ctx.inputs), ops.layer_gcn_params_ws_bytes(T, V), x_in.device)

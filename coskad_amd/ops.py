@@ -273,7 +273,7 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
     """Backward of one layer.  `grads` maps names -> preallocated gradient tensors:
     A, T, Wt, bt (opt), gt, bet, Wr, br (opt), gr, ber, slope_in (opt).  Returns dIn (or None).
     Chain mode (csrc: coskad_layer_bwd_chain_f32, needs Z): `stats_in` = (partial rows tensor, rows) the call for the layer above
-    wrote for this layer; `below` = (x_below, Z_below, below_stats) makes this call write the layer below's partial rows."""
+    wrote for this layer; `below` = (x_below, Z_below, in_slope_below, below_stats) makes this call write the layer below's partial rows."""
     B, Ci, T, V = x_in.shape
     Co = Wt.shape[0]
     _chk(x_in, "x_in"); _chk(dU, "dU", (B, Co, T, V)); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
@@ -302,10 +302,11 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
         _chk(sp, "stats_in", optional=True)
         if sp is not None and sp.numel() < srows * (2 * Co * Ci + Co):
             raise ValueError("layer_bwd: stats_in smaller than rows x (2 Co Ci + Co)")
-        xb, zb, bs = below if below is not None else (None, None, None)
+        xb, zb, sb, bs = below if below is not None else (None, None, None, None)
         cb = xb.shape[1] if xb is not None else 0
         _chk(xb, "below x", (B, cb, T, V), optional=True); _chk(zb, "below Z", (B, cb, T, V), optional=True); _chk(bs, "below_stats", optional=True)
-        call("coskad_layer_bwd_chain_f32", *args, ptr(Z), ptr(sp), i32(srows), ptr(xb), ptr(zb), i32(cb), ptr(bs),
+        _chk(sb, "below in_slope", (1,), optional=True)
+        call("coskad_layer_bwd_chain_f32", *args, ptr(Z), ptr(sp), i32(srows), ptr(xb), ptr(zb), ptr(sb), i32(cb), ptr(bs),
              ctypes.c_size_t(_bytes(bs) if bs is not None else 0))
     elif Z is None:
         call("coskad_layer_bwd_f32", *args)

@@ -238,10 +238,11 @@ int coskad_layer_fits(int Ci, int Co, int T, int V);
  * just produced; where that layer's data kernel holds it on chip, it forms the reductions itself:
  *   stats_in [stats_in_rows][2 Co Ci + Co] : this layer's partial rows, written by the call for the layer above (NULL: stage 1
  *                                            runs here, as in coskad_layer_bwd_z_f32)
- *   below_in, below_Z [B,below_Ci,T,V]     : input (raw network input, no activation) and stored Z of the layer below
+ *   below_in, below_Z [B,below_Ci,T,V]     : input of the layer below as stored (pre-activation; below_in_slope = its producer's
+ *                                            PReLU weight, NULL for the raw network input) and its stored Z
  *   below_stats [coskad_layer_bwd_below_rows(B,Ci,Co,below_Ci,T,V)][2 Ci below_Ci + Ci] : receives ITS partial rows (NULL: not formed)
- * coskad_layer_bwd_below_rows returns 0 when the (Ci -> Co) data kernel cannot form them (built: 32 -> 16 above a 2-channel layer,
- * T = 12, V = 17). */
+ * coskad_layer_bwd_below_rows returns 0 when the (Ci -> Co) data kernel cannot form them (built at T = 12, V = 17: 32 -> 16 above
+ * a 2-channel layer, 16 -> 32 above a 32-channel layer, 32 -> 64 above a 16-channel layer: the default stack). */
 int coskad_layer_bwd_below_rows(int B, int Ci, int Co, int below_Ci, int T, int V);
 int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A, const float* Tm,
                                const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
@@ -250,7 +251,7 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
                                float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                                int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z,
                                const float* stats_in, int stats_in_rows, const float* below_in, const float* below_Z,
-                               int below_Ci, float* below_stats, size_t below_stats_bytes);
+                               const float* below_in_slope, int below_Ci, float* below_stats, size_t below_stats_bytes);
 
 /* in   : the layer's input as stored by the producer (pre-activation; in_slope = its PReLU weight,
  *        NULL when `in` is the raw network input)

@@ -194,20 +194,23 @@ def test_fused_backward_ragged_batch_vs_split_kernels(Ci, Co, B):
         np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-4 * max(np.abs(b).max(), 1e-9), err_msg=k)
 
 
-@pytest.mark.parametrize("B", [37, 1026, 4099])
-def test_backward_chain_below_stats_vs_own_pass(B):
-    """coskad_layer_bwd_chain_f32: the 32 -> 16 data kernel also forms the batch reductions of the 2 -> 32 layer below it
-    (csrc/fused_bwd.hip, NS = 1) -- against the same two layers with the layer's own statistics pass (k_first_stats)."""
+@pytest.mark.parametrize("C0,C1,C2,B", [(2, 32, 16, 37), (2, 32, 16, 1026), (2, 32, 16, 4099), (32, 16, 32, 29), (32, 16, 32, 1031),
+                                        (32, 16, 32, 4100), (16, 32, 64, 41), (16, 32, 64, 1027), (16, 32, 64, 4097)])
+def test_backward_chain_below_stats_vs_own_pass(C0, C1, C2, B):
+    """coskad_layer_bwd_chain_f32: the (C1 -> C2) data kernel also forms the batch reductions of the (C0 -> C1) layer below it
+    (csrc/fused_bwd.hip, NS = 1 / 2) -- against the same two layers with the lower layer's own statistics pass (k_first_stats /
+    k_bwd_stats_ring).  The three pairs of the default stack; ragged batches (several clips per wave, partial last round)."""
     from coskad_amd import ops
-    T, V, C0, C1, C2 = 12, 17, 2, 32, 16
+    T, V = 12, 17
     st1, st2 = make_layer_state(C0, C1, V, seed=5), make_layer_state(C1, C2, V, seed=6)
     g = torch.Generator().manual_seed(B)
     x = dev(torch.randn(B, C0, T, V, generator=g))
     probe = dev(torch.randn(B, C2, T, V, generator=g) * 0.1)
     d1, d2 = {k[2:]: dev(v) for k, v in st1.items()}, {k[2:]: dev(v) for k, v in st2.items()}
+    sl0 = dev(torch.tensor([0.3])) if C0 > 2 else None      # x is a pre-activation unless it is the raw input
     sl = dev(torch.tensor([0.2]))
-    ws = torch.empty(max(ops.train_stats_ws_bytes(C1), ops.layer_bwd_ws_bytes(B, C1, C2, T, V), ops.layer_bwd_ws_bytes(B, C0, C1, T, V)),
-                     dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(ops.train_stats_ws_bytes(C1), ops.train_stats_ws_bytes(C0), ops.layer_bwd_ws_bytes(B, C1, C2, T, V),
+                         ops.layer_bwd_ws_bytes(B, C0, C1, T, V)), dtype=torch.uint8, device="cuda")
 
     def stats(xin, dd, Ci, Co, slope):
         Z = torch.empty(B, Ci, T, V, device="cuda")
@@ -217,8 +220,8 @@ def test_backward_chain_below_stats_vs_own_pass(B):
             dd["residual.0.weight"].reshape(Co, Ci), dd["residual.0.bias"], dd["residual.1.weight"], dd["residual.1.bias"],
             dd["residual.1.running_mean"], dd["residual.1.running_var"], dd["residual.1.num_batches_tracked"], ws, Z=Z)
         return Z, wf, bi, stat
-    Z1, wf1, b1, stat1 = stats(x, d1, C0, C1, None)
-    U1 = ops.layer_apply_z(Z1, x, d1["gcn.A"], d1["gcn.T"], wf1, b1, C1)
+    Z1, wf1, b1, stat1 = stats(x, d1, C0, C1, sl0)
+    U1 = ops.layer_apply_z(Z1, x, d1["gcn.A"], d1["gcn.T"], wf1, b1, C1, in_slope=sl0)
     Z2, _, _, stat2 = stats(U1, d2, C1, C2, sl)
 
     def grads(Ci, Co, slope):
@@ -230,34 +233,36 @@ def test_backward_chain_below_stats_vs_own_pass(B):
         return gr
 
     def run(chain):
-        g2, g1 = grads(C1, C2, True), grads(C0, C1, False)
+        g2, g1 = grads(C1, C2, True), grads(C0, C1, sl0 is not None)
         below, buf, rows = None, None, 0
         if chain:
             rows = ops.layer_bwd_below_rows(B, C1, C2, C0, T, V)
             assert rows > 0
             n, guard = rows * (2 * C1 * C0 + C1), 1024
             buf = torch.full((n + 2 * guard,), 12345.0, device="cuda")
-            below = (x, Z1, buf[guard:guard + n])
+            below = (x, Z1, sl0, buf[guard:guard + n])
         dU1 = ops.layer_bwd(U1, probe, d2["gcn.A"], d2["gcn.T"], sl, stat2, d2["tcn.0.weight"].reshape(C2, C1), d2["tcn.1.weight"],
                             d2["residual.0.weight"].reshape(C2, C1), d2["residual.1.weight"], g2, ws, Z=Z2, below=below)
-        ops.layer_bwd(x, dU1, d1["gcn.A"], d1["gcn.T"], None, stat1, d1["tcn.0.weight"].reshape(C1, C0), d1["tcn.1.weight"],
-                      d1["residual.0.weight"].reshape(C1, C0), d1["residual.1.weight"], g1, ws, need_dx=False, Z=Z1,
-                      stats_in=(below[2], rows) if chain else None)
+        dX = ops.layer_bwd(x, dU1, d1["gcn.A"], d1["gcn.T"], sl0, stat1, d1["tcn.0.weight"].reshape(C1, C0), d1["tcn.1.weight"],
+                           d1["residual.0.weight"].reshape(C1, C0), d1["residual.1.weight"], g1, ws, need_dx=sl0 is not None, Z=Z1,
+                           stats_in=(below[3], rows) if chain else None)
         torch.cuda.synchronize()
         if chain:
             assert bool((buf[:1024] == 12345.0).all()) and bool((buf[-1024:] == 12345.0).all()), "wrote outside below_stats"
-        return dU1, g2, g1
+        return dU1, dX, g2, g1
 
-    dU_c, g2c, g1c = run(True)
-    dU_o, g2o, g1o = run(False)
+    dU_c, dX_c, g2c, g1c = run(True)
+    dU_o, dX_o, g2o, g1o = run(False)
     assert torch.equal(dU_c, dU_o)
     for k in g2o:
-        np.testing.assert_array_equal(g2c[k].cpu().numpy(), g2o[k].cpu().numpy(), err_msg="layer 2 " + k)
+        np.testing.assert_array_equal(g2c[k].cpu().numpy(), g2o[k].cpu().numpy(), err_msg="upper layer " + k)
+    if dX_o is not None:
+        close(dX_c, dX_o.cpu(), rtol=1e-3, atol_rel=1e-4, msg="dX of the lower layer")
     gmax = max(float(v.abs().max()) for v in g1o.values())
     for k in g1o:
-        a, b = g1c[k].cpu().numpy(), g1o[k].cpu().numpy()
+        a, b_ = g1c[k].cpu().numpy(), g1o[k].cpu().numpy()
         assert np.isfinite(a).all(), k
-        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * max(np.abs(b).max(), 1e-9) + 2e-5 * gmax, err_msg="layer 1 " + k)
+        np.testing.assert_allclose(a, b_, rtol=1e-3, atol=1e-4 * max(np.abs(b_).max(), 1e-9) + 2e-5 * gmax, err_msg="lower layer " + k)
 
 
 @pytest.mark.parametrize("B,hid,V,L,with_slope", [(37, 64, 17, 16, True), (5, 8, 25, 8, True), (16, 4, 17, 4, False), (300, 16, 17, 16, True)])

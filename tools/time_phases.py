@@ -8,7 +8,9 @@ sys.path.insert(0, ".")
 from coskad_amd import ops
 
 B, T, V = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 12, 17
-names = ["stage", "temporal", "pass1(dZ)", "dA", "pass2(dXres)", "spatial^T", "dT", "temporal^T", "last-epi", "", "", "", "", "", "", "epilogue"]
+names = ["stage", "temporal", "pass1(dZ)", "dA", "pass2(dXres)", "spatial^T", "dT", "temporal^T", "last-epi", "rowpass", "below-stats", "", "", "", "", "loop-head"]
+CHAIN = len(sys.argv) > 2 and sys.argv[2] == "chain"
+BELOW = {(32, 64): 16, (16, 32): 32, (32, 16): 2}
 torch.manual_seed(0)
 for Ci, Co in ((32, 64), (16, 32), (32, 16)):
     dev = "cuda"
@@ -31,8 +33,14 @@ for Ci, Co in ((32, 64), (16, 32), (32, 16)):
          "gr": torch.empty_like(gr), "ber": torch.empty_like(ber), "slope_in": torch.empty(1, device=dev)}
     bws = torch.empty(ops.layer_bwd_ws_bytes(B, Ci, Co, T, V), dtype=torch.uint8, device=dev)
     dIn = torch.empty_like(x)
+    below = None
+    if CHAIN:
+        cb = BELOW[(Ci, Co)]
+        rows = ops.layer_bwd_below_rows(B, Ci, Co, cb, T, V)
+        below = (torch.randn(B, cb, T, V, device=dev), torch.randn(B, cb, T, V, device=dev), slope if cb > 2 else None,
+                 torch.empty(rows * (2 * Ci * cb + Ci), device=dev))
     for _ in range(3):
-        ops.layer_bwd(x, dU, A, Tm, slope, stat, Wt, gt, Wr, gr, g, bws, dIn=dIn, Z=Z)
+        ops.layer_bwd(x, dU, A, Tm, slope, stat, Wt, gt, Wr, gr, g, bws, dIn=dIn, Z=Z, below=below)
     torch.cuda.synchronize()
     t = dIn.flatten()[:256 * 16].view(256, 16).double().mean(0) / 100.0     # 100 MHz ticks -> us
     per = dIn.flatten()[:256 * 16].view(256, 16).double().sum(1) / 100.0
