@@ -372,11 +372,20 @@ def main():
         roof = roof_fwd = None
         ci, co = CHANNELS[-1], HID
         layer_bytes = B * tvb * (co + 2 * ci)      # SURVEY 8d, backward of one layer: read dOut (C_out), read the saved input (C_in), write dIn (C_in)
+        # backward chain (engine.FUSE_BELOW): layer 4's data kernel also forms the batch reductions of layer 3 from the dU3 rows it
+        # holds -- that folded work must read layer 3's stored Z and input (2 x C_in(3) rows); its share of the probed time is included
+        from coskad_amd import engine as _eng, ops as _ops
+        cb = CHANNELS[-2]
+        chained = bool(_eng.FUSE_BELOW and _ops.layer_bwd_below_rows(B, ci, co, cb, T, V))
+        below_bytes = B * tvb * 2 * cb if chained else 0
+        layer_bytes += below_bytes
         if lbw_n.value:
             ach = layer_bytes / (lbw_ms.value * 1e-3) / 1e9
             roof = {"bound": "hbm",
                     "what": "layer 4 backward (64 -> 32 channels), ALL its kernels (batch reductions k_bwd_reduce_z, fp64 folds, "
-                            "k_layer_bwd_fused<2,4> = data path + dA / dT, partial-row sums) against the layer's algorithmic bytes",
+                            "k_layer_bwd_fused<2,4> = data path + dA / dT, partial-row sums) against the layer's algorithmic bytes"
+                            + (f"; the data kernel also forms layer 3's batch reductions (backward chain): + {below_bytes} bytes "
+                               "(layer 3's stored Z and input) in algorithmic_bytes_per_launch, its time in avg_launch_us" if chained else ""),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": (traffic.get("layer4 backward", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
                     "traffic_source": f"{traffic_src} (PMC FETCH_SIZE/WRITE_SIZE summed over the layer's kernels, B=4096)",
@@ -387,6 +396,8 @@ def main():
                 # the same launches against the fp32 MFMA roof: convs Bt.dU, Br.dU (C_in x C_out each),
                 # Kt.Z, Kr.X (C_in x C_in each) + forward temporal mix, both adjoint mixes, dA and dT (3 T + 2 V per element)
                 flops = B * (2 * T * V * (2 * ci * co + 2 * ci * ci) + 2 * ci * T * V * (3 * T + 2 * V))
+                if chained:
+                    flops += B * 2 * T * V * 2 * ci * cb          # P and Q of the layer below: C_in x C_in(below) each
                 tf = flops / (dom_ms * 1e-3) / 1e12
                 roof["kernel_only"] = {"kernel": "k_layer_bwd_fused<2,4>", "note": "the layer's bytes charged to its dominant kernel alone",
                                        "achieved": round(ach1, 1), "frac": round(ach1 / HBM_PEAK_GBS, 4),
