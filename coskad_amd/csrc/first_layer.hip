@@ -88,14 +88,19 @@ __global__ __launch_bounds__(64 * NW, 4) void k_first_stats(const float* __restr
   }
 }
 
+// NWB waves per block: 4 at up to 256 positions per clip; the 25-joint layout (44 KB of mixing tables: two blocks per CU either
+// way) runs 8, i.e. the same four waves per SIMD
+template <int T, int V>
+constexpr int first_bwd_waves() { return T * V > 256 ? 8 : 4; }
 template <int T, int V, int CI, int RW>
-__global__ __launch_bounds__(64 * NW, 4) void k_first_bwd(const float* __restrict__ in, const float* __restrict__ Zg,
+__global__ __launch_bounds__((64 * first_bwd_waves<T, V>()), 4) void k_first_bwd(const float* __restrict__ in, const float* __restrict__ Zg,
                                                       const float* __restrict__ dU, const float* __restrict__ Aw,
                                                       const float* __restrict__ Tw, const float* __restrict__ coef,
                                                       const float* __restrict__ in_slope, float* __restrict__ partials, int B,
                                                       int Co) {
   constexpr int TV = T * V, NA = T * V * V, NT = V * T * T, N4 = TV / 4;
   constexpr int CiP = 16;                       // round_up(C_in, 16): row stride of the coefficient block
+  constexpr int NW = first_bwd_waves<T, V>();   // (shadows the 4 of k_first_stats)
   static_assert(TV % 4 == 0 && CI <= 4, "few-channel layer: T V a multiple of 4");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* AwL = lds;                             // [T][V][V]
@@ -400,13 +405,14 @@ static int launch_first_bwd_tv(const float* in, const float* Zg, const float* dU
   int grid = B < 1024 ? B : 1024;
   if (grid > max_rows) grid = max_rows;
   *rows_out = grid;
-  const int rw = ceil_div(Co, fl::NW);
-  const size_t lds = ((size_t)T * V * V + (size_t)V * T * T + (4 + fl::NW) * (size_t)Ci * T * V) * sizeof(float);
+  constexpr int NWB = fl::first_bwd_waves<T, V>();
+  const int rw = ceil_div(Co, NWB);
+  const size_t lds = ((size_t)T * V * V + (size_t)V * T * T + (4 + NWB) * (size_t)Ci * T * V) * sizeof(float);
 #define LAUNCH_FB1(CI, RW)                                                                                              \
   do {                                                                                                                  \
     auto k = fl::k_first_bwd<T, V, CI, RW>;                                                                             \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * fl::NW), lds, st, in, Zg, dU, Aw, Tw, coef, in_slope, partials, B, Co);          \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NWB), lds, st, in, Zg, dU, Aw, Tw, coef, in_slope, partials, B, Co);             \
   } while (0)
 #define LAUNCH_FB1_C(CI)                        \
   do {                                          \
