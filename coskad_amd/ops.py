@@ -6,6 +6,7 @@ sees a pointer, enqueues on torch's current stream and never synchronises.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -526,6 +527,9 @@ def conv1x1(W: Tensor, x: Tensor, bias: Optional[Tensor] = None, out: Optional[T
     return out, parts
 
 
+WGRAD_BLOCKS = int(os.environ.get("COSKAD_WGRAD_BLOCKS", "256"))   # workgroups a weight-gradient launch aims for (one per CU; sweep 64..2048: wide step 19.7 / 18.0 / 18.2 / 18.7 / 19.5 ms at 64 / 256 / 512 / 1024 / 2048)
+
+
 def conv1x1_wgrad(G: Tensor, x: Tensor, out: Tensor, target_chunks: int = 64, accumulate: bool = False) -> Tensor:
     """out[m, k] (+)= sum_b sum_p G[b, m, p] x[b, k, p]: the weight gradient of a 1x1 convolution (G [B, M, P], x [B, K, P]).
     csrc/conv1x1.hip where the shape allows, the strided GEMM's chunked reduction otherwise; deterministic either way."""
@@ -536,6 +540,10 @@ def conv1x1_wgrad(G: Tensor, x: Tensor, out: Tensor, target_chunks: int = 64, ac
     fn.restype = ctypes.c_int
     if not fn(i32(M), i32(K), i32(P)) or G.data_ptr() % 16 or x.data_ptr() % 16:
         return gemm_reduce(G, x.transpose(1, 2), out, target_chunks=target_chunks, accumulate=accumulate)
+    # the kernel's grid is (K tiles, M tiles, clip chunks): enough chunks for ~WGRAD_BLOCKS workgroups (narrow layers have ONE tile)
+    tm, tk = (128, 128) if (M % 128 == 0 and K % 128 == 0) else ((64, 64) if M % 64 == 0 else (32, 64))
+    tiles = (M // tm) * (K // tk)
+    target_chunks = max(target_chunks, -(-WGRAD_BLOCKS // tiles))
     chunk = max(1, (B + target_chunks - 1) // target_chunks)
     chunks = (B + chunk - 1) // chunk
     part = torch.empty(chunks, M, K, device=G.device, dtype=torch.float32)
