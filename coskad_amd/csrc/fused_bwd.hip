@@ -28,13 +28,32 @@ using namespace ff;
 //           14        dA[t = j][16][16]           (r == 0, q == 0, j < 12)
 //           [15, 32)  dT[v][4q + r][j]            (v = record - 15; 4q + r < 12, j < 12)
 constexpr int PR_A = 0, PR_XA = 12, PR_XB = 13, PR_C = 14, PR_T = 15, PR_N = 32, EROW = PR_N * 256;
-// dA, dT (+)= sum over the P lane-major partial rows (fp64, fixed order); one extra block sums the slope partials
+// dA, dT (+)= sum over the P lane-major partial rows (fp64, fixed order); one extra block sums the slope partials; blocks beyond
+// that one sum the partial rows the data kernel wrote for the layer below (backward chain: brows [bP][bE] -> bout [bE], the
+// k_reduce_partials_d of that layer's call riding in this launch)
 __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__ partials, int P, float* __restrict__ dA,
                                                        float* __restrict__ dT, const float* __restrict__ dap, int ndap,
-                                                       float* __restrict__ dslope, int accumulate) {
+                                                       float* __restrict__ dslope, int accumulate, const float* __restrict__ brows,
+                                                       int bP, int bE, double* __restrict__ bout) {
   __shared__ double sh[1024];
   constexpr int NB = EROW / 64;
+  if ((int)blockIdx.x > NB) {
+    const int e = ((int)blockIdx.x - NB - 1) * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    double s = 0.0;
+    if (e < bE)
+      for (int p = slice; p < bP; p += 16) s += (double)brows[(size_t)p * bE + e];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (slice == 0 && e < bE) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+      bout[e] = t;
+    }
+    return;
+  }
   if ((int)blockIdx.x == NB) {
+    if (!dap) return;
     double s = 0.0;
     for (int i = threadIdx.x; i < ndap; i += 1024) s += (double)dap[i];
     sh[threadIdx.x] = s;
@@ -788,9 +807,10 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
 }
 
 int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, const float* dap, float* dslope, int accumulate,
-                        hipStream_t st) {
-  hipLaunchKernelGGL(fb::k_reduce_fused, dim3(fb::EROW / 64 + (dap ? 1 : 0)), dim3(1024), 0, st, partials, rows, dA, dT, dap, rows,
-                     dslope, accumulate);
+                        hipStream_t st, const float* brows, int bE, double* bout) {
+  const int extra = brows ? 1 + ceil_div(bE, 64) : (dap ? 1 : 0);
+  hipLaunchKernelGGL(fb::k_reduce_fused, dim3(fb::EROW / 64 + extra), dim3(1024), 0, st, partials, rows, dA, dT, dap, rows,
+                     dslope, accumulate, brows, rows, bE, bout);
   return check_launch("bwd_reduce_fused");
 }
 

@@ -1218,7 +1218,9 @@ int launch_first_bwd(const float* in, const float* Zg, const float* dU, const fl
                      const float* in_slope, float* partials, int B, int Ci, int Co, int T, int V, int max_rows, hipStream_t st,
                      int* rows_out);
 int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, const float* dap, float* dslope, int accumulate,
-                        hipStream_t st);
+                        hipStream_t st, const float* brows, int bE, double* bout);
+// chain buffer of a layer's stage-1 sums: [rows][E] partial rows, then (8-byte aligned) their E fp64 sums
+static inline size_t chain_sums_offset(int rows, int E) { return ((size_t)rows * E + 1) / 2 * 2; }
 constexpr size_t kFusedRowFloats = 37 * 256;   // lane-major partial row of fused_bwd.hip
 
 static size_t bwd_emax(int Ci, int Co, int T, int V) {
@@ -1334,8 +1336,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     // the LDS (64 input channels at 25 joints: the default-width decoder on the NTU layout) the two-pass kernel below
     // runs instead; it takes the stored Z as well.
     if (stats_in) {
-      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, stats_in, stats_in_rows, E, w.red);
-      if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+      // summed already: the partial rows rode in the reduction launch of the layer above (k_reduce_fused)
     } else if (Zg && first_layer_ok(T, V, Ci, Co)) {
       // a handful of input channels (the first layer): plain FMAs on full-line loads (first_layer.hip)
       int rows = 0;
@@ -1430,7 +1431,8 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   // the fused data kernel's operand tables are built by extra blocks of the fold launch (parameter-only work)
   const int tab_blocks = fused ? ceil_div(ff::BTAB_F4 * 4, 1024) : 0;
   const int NF = Co >= 32 ? 8 : (Co >= 16 ? 4 : 1);          // fold blocks (slices of the output channels / K pairs)
-  hipLaunchKernelGGL(k_bwd_fold, dim3(NF + tab_blocks), dim3(1024), fold_lds, st, w.red, (double)B * TV, stat,
+  const double* red = stats_in ? reinterpret_cast<const double*>(stats_in + chain_sums_offset(stats_in_rows, 2 * Co * Ci + Co)) : w.red;
+  hipLaunchKernelGGL(k_bwd_fold, dim3(NF + tab_blocks), dim3(1024), fold_lds, st, red, (double)B * TV, stat,
                      Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate, Aw, Tw, w.btab, NF);
   if ((rc = check_launch("bwd_fold"))) return rc;
   // 3 + 4 in one kernel (fused_bwd.hip) for the stored-Z path at the shapes it is built for: dZ never leaves the CU
@@ -1440,7 +1442,9 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows,
                                      below_z, below_in, below_slope, below_Ci, below_stats)))
       return rc;
-    return launch_reduce_fused(w.partials, rows, dA, dT, dap, dslope_in, accumulate, st);
+    const int bE = 2 * Ci * below_Ci + Ci;
+    return launch_reduce_fused(w.partials, rows, dA, dT, dap, dslope_in, accumulate, st, below_stats, bE,
+                               below_stats ? reinterpret_cast<double*>(below_stats + chain_sums_offset(rows, bE)) : nullptr);
   }
   if (Zg && !dIn && !dz_ext && first_layer_ok(T, V, Ci, Co)) {
     int rows = 0;
@@ -1639,12 +1643,17 @@ int coskad_layer_bwd_z_f32(const float* in, const float* dU, const float* A, con
 
 /* coskad_layer_bwd_z_f32 inside a chain of layers.  The batch reductions of a layer's backward (stage 1: P = sum dU.Z^T,
  * Q = sum dU.X^T, sdU) read the dU the layer ABOVE has just produced; where that layer's data kernel can, it forms them itself:
- *   stats_in [stats_in_rows][2 Co Ci + Co] : this layer's partial rows from the call for the layer above (NULL: stage 1 runs here)
+ *   stats_in [stats_in_rows][2 Co Ci + Co] + sums : this layer's chain buffer from the call for the layer above (NULL: stage 1 runs here)
  *   below_in / below_Z [B, below_Ci, T, V], below_in_slope, below_stats [coskad_layer_bwd_below_rows(...)][2 Ci below_Ci + Ci] :
  *     the layer below's input as stored (pre-activation + its producer's PReLU weight, NULL for the raw network input), its
- *     stored Z and the buffer for ITS partial rows (NULL: not formed) */
+ *     stored Z and ITS chain buffer (NULL: not formed): the partial rows, then (8-byte aligned) their fp64 sums, which this
+ *     call's partial-sum launch forms as well: coskad_layer_bwd_below_floats(...) floats in all */
 int coskad_layer_bwd_below_rows(int B, int Ci, int Co, int below_Ci, int T, int V) {
   return layer_bwd_below_rows(T, V, B, Ci, Co, below_Ci);
+}
+size_t coskad_layer_bwd_below_floats(int B, int Ci, int Co, int below_Ci, int T, int V) {
+  const int rows = layer_bwd_below_rows(T, V, B, Ci, Co, below_Ci), bE = 2 * Ci * below_Ci + Ci;
+  return rows ? chain_sums_offset(rows, bE) + 2 * (size_t)bE : 0;
 }
 
 int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A, const float* Tm,
@@ -1661,11 +1670,14 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
   if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: identity residual needs Ci == Co");
   if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: B=%d Ci=%d Co=%d", B, Ci, Co);
   if (stats_in && stats_in_rows <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: stats_in_rows=%d", stats_in_rows);
+  if (stats_in && ((size_t)stats_in & 7)) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: stats_in must be 8-byte aligned");
+  if (below_stats && ((size_t)below_stats & 7)) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: below_stats must be 8-byte aligned");
   if (below_stats) {
     if (!below_in || !below_Z) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: below_in / below_Z missing");
     const int rows = layer_bwd_below_rows(T, V, B, Ci, Co, below_Ci);
     if (rows == 0) return fail(COSKAD_ERR_SHAPE, "layer_bwd_chain: (%d -> %d) cannot form the reductions of a layer with %d input channels", Ci, Co, below_Ci);
-    const size_t need = (size_t)rows * (2 * (size_t)Ci * below_Ci + Ci) * sizeof(float);
+    const int bE = 2 * Ci * below_Ci + Ci;
+    const size_t need = chain_sums_offset(rows, bE) * sizeof(float) + (size_t)bE * sizeof(double);
     if (below_stats_bytes < need) return fail(COSKAD_ERR_WORKSPACE, "layer_bwd_chain: below_stats %zu < %zu bytes", below_stats_bytes, need);
   }
   ProbeScope layer_probe(KID_LAYER_BWD, Ci, Co, stream);

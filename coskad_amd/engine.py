@@ -243,7 +243,7 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
                 rows = ops.layer_bwd_below_rows(B, Ci, L.Co, cb, T, V)
                 if rows:
                     below = (ctx.inputs[i - 1], ctx.zs[i - 1], layers[i - 2].slope if i > 1 else ctx.in_slope,
-                             torch.empty(rows * (2 * Ci * cb + Ci), device=x_in.device, dtype=torch.float32))
+                             torch.empty(ops.layer_bwd_below_floats(B, Ci, L.Co, cb, T, V), device=x_in.device, dtype=torch.float32))
             dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate, Z=ctx.zs[i] if ctx.zs else None,
                                 stats_in=stats_in, below=below)
             stats_in = (below[3], rows) if below is not None else None

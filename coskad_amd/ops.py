@@ -269,6 +269,13 @@ def layer_bwd_below_rows(B: int, Ci: int, Co: int, below_Ci: int, T: int, V: int
     return fn(i32(B), i32(Ci), i32(Co), i32(below_Ci), i32(T), i32(V))
 
 
+def layer_bwd_below_floats(B: int, Ci: int, Co: int, below_Ci: int, T: int, V: int) -> int:
+    """Floats of the chain buffer (partial rows + their fp64 sums) layer_bwd(..., below=...) fills for the layer below."""
+    fn = _lib.lib().coskad_layer_bwd_below_floats
+    fn.restype = ctypes.c_size_t
+    return fn(i32(B), i32(Ci), i32(Co), i32(below_Ci), i32(T), i32(V))
+
+
 def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, need_dx=True,
               dIn=None, accumulate=False, Z=None, stats_in=None, below=None):
     """Backward of one layer.  `grads` maps names -> preallocated gradient tensors:
@@ -301,8 +308,8 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
             raise ValueError("layer_bwd: chain mode needs the stored Z")
         sp, srows = stats_in if stats_in is not None else (None, 0)
         _chk(sp, "stats_in", optional=True)
-        if sp is not None and sp.numel() < srows * (2 * Co * Ci + Co):
-            raise ValueError("layer_bwd: stats_in smaller than rows x (2 Co Ci + Co)")
+        if sp is not None and sp.numel() < (srows * (2 * Co * Ci + Co) + 1) // 2 * 2 + 2 * (2 * Co * Ci + Co):
+            raise ValueError("layer_bwd: stats_in smaller than a chain buffer of that many rows")
         xb, zb, sb, bs = below if below is not None else (None, None, None, None)
         cb = xb.shape[1] if xb is not None else 0
         _chk(xb, "below x", (B, cb, T, V), optional=True); _chk(zb, "below Z", (B, cb, T, V), optional=True); _chk(bs, "below_stats", optional=True)

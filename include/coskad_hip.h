@@ -236,14 +236,17 @@ int coskad_layer_fits(int Ci, int Co, int T, int V);
 /* coskad_layer_bwd_z_f32 inside a chain of layers (reference: autograd walks stsgcn.py:94-116 layer by layer, last to first).
  * Stage 1 of a layer's backward (the batch reductions P = sum dU.Z^T, Q = sum dU.X^T, sdU) reads the dU the layer ABOVE has
  * just produced; where that layer's data kernel holds it on chip, it forms the reductions itself:
- *   stats_in [stats_in_rows][2 Co Ci + Co] : this layer's partial rows, written by the call for the layer above (NULL: stage 1
- *                                            runs here, as in coskad_layer_bwd_z_f32)
+ *   stats_in, stats_in_rows                : this layer's chain buffer, filled by the call for the layer above (NULL: stage 1 runs
+ *                                            here, as in coskad_layer_bwd_z_f32)
  *   below_in, below_Z [B,below_Ci,T,V]     : input of the layer below as stored (pre-activation; below_in_slope = its producer's
  *                                            PReLU weight, NULL for the raw network input) and its stored Z
- *   below_stats [coskad_layer_bwd_below_rows(B,Ci,Co,below_Ci,T,V)][2 Ci below_Ci + Ci] : receives ITS partial rows (NULL: not formed)
+ *   below_stats [coskad_layer_bwd_below_floats(B,Ci,Co,below_Ci,T,V) floats, 8-byte aligned] : ITS chain buffer (NULL: not formed):
+ *       coskad_layer_bwd_below_rows(...) partial rows of 2 Ci below_Ci + Ci floats, then their fp64 sums (formed by this call's
+ *       partial-sum launch: the layer below runs neither its batch reductions nor their summation)
  * coskad_layer_bwd_below_rows returns 0 when the (Ci -> Co) data kernel cannot form them (built at T = 12, V = 17: 32 -> 16 above
  * a 2-channel layer, 16 -> 32 above a 32-channel layer, 32 -> 64 above a 16-channel layer: the default stack). */
 int coskad_layer_bwd_below_rows(int B, int Ci, int Co, int below_Ci, int T, int V);
+size_t coskad_layer_bwd_below_floats(int B, int Ci, int Co, int below_Ci, int T, int V);
 int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A, const float* Tm,
                                const float* in_slope, const float* stat, const float* Wt, const float* gamma_t,
                                const float* Wr, const float* gamma_r, float* dIn, float* dA, float* dT, float* dWt,

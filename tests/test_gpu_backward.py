@@ -238,7 +238,7 @@ def test_backward_chain_below_stats_vs_own_pass(C0, C1, C2, B):
         if chain:
             rows = ops.layer_bwd_below_rows(B, C1, C2, C0, T, V)
             assert rows > 0
-            n, guard = rows * (2 * C1 * C0 + C1), 1024
+            n, guard = ops.layer_bwd_below_floats(B, C1, C2, C0, T, V), 1024
             buf = torch.full((n + 2 * guard,), 12345.0, device="cuda")
             below = (x, Z1, sl0, buf[guard:guard + n])
         dU1 = ops.layer_bwd(U1, probe, d2["gcn.A"], d2["gcn.T"], sl, stat2, d2["tcn.0.weight"].reshape(C2, C1), d2["tcn.1.weight"],

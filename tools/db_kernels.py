@@ -13,7 +13,7 @@ ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
 scols = [r[1] for r in cur.execute(f"pragma table_info({ks})")]
 namecol = "display_name" if "display_name" in scols else "kernel_name"
-rows = list(cur.execute(f"select s.{namecol}, d.start, d.end, d.grid_size_x, d.workgroup_size_x from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
+rows = list(cur.execute(f"select s.{namecol}, d.start, d.end, d.grid_size_x * d.grid_size_y * d.grid_size_z, d.workgroup_size_x * d.workgroup_size_y * d.workgroup_size_z from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
 
 
 def short(name):

@@ -38,7 +38,7 @@ for Ci, Co in ((32, 64), (16, 32), (32, 16)):
         cb = BELOW[(Ci, Co)]
         rows = ops.layer_bwd_below_rows(B, Ci, Co, cb, T, V)
         below = (torch.randn(B, cb, T, V, device=dev), torch.randn(B, cb, T, V, device=dev), slope if cb > 2 else None,
-                 torch.empty(rows * (2 * Ci * cb + Ci), device=dev))
+                 torch.empty(ops.layer_bwd_below_floats(B, Ci, Co, cb, T, V), device=dev))
     for _ in range(3):
         ops.layer_bwd(x, dU, A, Tm, slope, stat, Wt, gt, Wr, gr, g, bws, dIn=dIn, Z=Z, below=below)
     torch.cuda.synchronize()
