@@ -88,10 +88,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_first_stats(const float* __restr
   }
 }
 
-// NWB waves per block: 4 at up to 256 positions per clip; the 25-joint layout (44 KB of mixing tables: two blocks per CU either
-// way) runs 8, i.e. the same four waves per SIMD
+// NWB waves per block.  Measured on the whole train step (B = 4096, 17 joints; tools/ab_engine_flag.py on one box): 4 waves x 1024
+// blocks 1.618 ms, 8 x 512 1.601, 8 x 384 1.606, 16 x 256 1.614: half the partial rows (24 -> 12 MB through k_reduce_gcn), half the
+// dA / dT outputs per thread.  The 25-joint layout (44 KB of mixing tables: two blocks per CU either way) gained 176 -> 90 us
 template <int T, int V>
-constexpr int first_bwd_waves() { return T * V > 256 ? 8 : 4; }
+constexpr int first_bwd_waves() { return 8; }
 template <int T, int V, int CI, int RW>
 __global__ __launch_bounds__((64 * first_bwd_waves<T, V>()), 4) void k_first_bwd(const float* __restrict__ in, const float* __restrict__ Zg,
                                                       const float* __restrict__ dU, const float* __restrict__ Aw,
@@ -402,10 +403,10 @@ template <int T, int V>
 static int launch_first_bwd_tv(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw, const float* coef,
                                const float* in_slope, float* partials, int B, int Ci, int Co, int max_rows, hipStream_t st,
                                int* rows_out) {
-  int grid = B < 1024 ? B : 1024;
+  constexpr int NWB = fl::first_bwd_waves<T, V>();
+  int grid = B < 512 ? B : 512;                 // two 8-wave blocks per CU, one round (sweep below)
   if (grid > max_rows) grid = max_rows;
   *rows_out = grid;
-  constexpr int NWB = fl::first_bwd_waves<T, V>();
   const int rw = ceil_div(Co, NWB);
   const size_t lds = ((size_t)T * V * V + (size_t)V * T * T + (4 + NWB) * (size_t)Ci * T * V) * sizeof(float);
 #define LAUNCH_FB1(CI, RW)                                                                                              \
