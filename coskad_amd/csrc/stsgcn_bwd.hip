@@ -1302,7 +1302,10 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
                             int B, int Ci, int Co, hipStream_t st, float* dz_ext = nullptr,
                             const float* Zg = nullptr, const float* stats_in = nullptr, int stats_in_rows = 0,
                             const float* below_in = nullptr, const float* below_z = nullptr, const float* below_slope = nullptr,
-                            int below_Ci = 0, float* below_stats = nullptr) {
+                            int below_Ci = 0, float* below_stats = nullptr, double stats_count = 0.0, float* stats_out = nullptr,
+                            int* stats_rows_out = nullptr) {
+  // stats_count: positions the stage-1 sums cover (0: this batch, B T V; SyncBN: all ranks' batches);
+  // stats_out: run stage 1 ONLY, into that chain buffer (partial rows, then their fp64 sums); *stats_rows_out = rows written
   // stats_in: this layer's stage-1 partial rows, written by the call for the layer above (stage 1 is then skipped);
   // below_*: the layer below's input / stored Z and the buffer its partial rows go to (fused data kernel only)
   constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
@@ -1314,6 +1317,8 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
     return fail(COSKAD_ERR_WORKSPACE, "layer_bwd: workspace %zu < %zu bytes", ws_bytes, layer_bwd_ws_bytes(B, Ci, Co, T, V));
   BwdWs w = carve(ws, B, Ci, Co, T, V);
   if (dz_ext) w.dz = dz_ext;
+  if (stats_out) w.partials = stats_out;
+  auto red_of = [&](int rows_, int E_) { return stats_out ? reinterpret_cast<double*>(stats_out + chain_sums_offset(rows_, E_)) : w.red; };
   int rc;
   // 1. reductions
   {
@@ -1341,14 +1346,16 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
       // a handful of input channels (the first layer): plain FMAs on full-line loads (first_layer.hip)
       int rows = 0;
       if ((rc = launch_first_stats(in, Zg, dU, in_slope, w.partials, B, Ci, Co, TV, need_q, kMaxGridBwd, st, &rows))) return rc;
-      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, w.red);
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+      if (stats_rows_out) *stats_rows_out = rows;
     } else if (Zg && bwd_stats_ring_ok(T, V, Ci, Co)) {
       // default geometry, 16 / 32 input channels: wave-per-clip reductions (fused_stats.hip)
       int rows = 0;
       if ((rc = launch_bwd_stats_ring(in, Zg, dU, in_slope, w.partials, B, Ci, Co, st, &rows))) return rc;
-      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, w.red);
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+      if (stats_rows_out) *stats_rows_out = rows;
     } else if (Zg && zlds(1) <= (size_t)kMaxLdsBytes) {
       const bool three_z = nto * ntc <= 2 && kBlock <= 512;   // (16-wave blocks: at most two per CU)
       const size_t cap = three_z ? (size_t)52 * 1024 : (size_t)76 * 1024;
@@ -1382,8 +1389,9 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
 #undef LAUNCH_RZ_O
 #undef LAUNCH_RZ
       if ((rc = check_launch("bwd_reduce_z"))) return rc;
-      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, gridz, E, w.red);
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, gridz, E, red_of(gridz, E));
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+      if (stats_rows_out) *stats_rows_out = gridz;
     } else {
     // blocks per CU: three when the accumulators are small enough for 6 waves/SIMD and the images fit a third of
     // the LDS (fewer clips per tile if need be), else two
@@ -1419,10 +1427,12 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
 #undef LAUNCH_R_O
 #undef LAUNCH_R
     if ((rc = check_launch("bwd_reduce"))) return rc;
-    hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, grid, E, w.red);
+    hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, grid, E, red_of(grid, E));
     if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+    if (stats_rows_out) *stats_rows_out = grid;
     }
   }
+  if (stats_out) return 0;
   // 2. fold
   const size_t fold_lds = (size_t)(6 * Co + 2 * Co * Ci + Co) * sizeof(double) + (size_t)(4 * Co * Ci + 2 * Ci + 4 * Co) * sizeof(float);
   if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_bwd_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
@@ -1432,7 +1442,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   const int tab_blocks = fused ? ceil_div(ff::BTAB_F4 * 4, 1024) : 0;
   const int NF = Co >= 32 ? 8 : (Co >= 16 ? 4 : 1);          // fold blocks (slices of the output channels / K pairs)
   const double* red = stats_in ? reinterpret_cast<const double*>(stats_in + chain_sums_offset(stats_in_rows, 2 * Co * Ci + Co)) : w.red;
-  hipLaunchKernelGGL(k_bwd_fold, dim3(NF + tab_blocks), dim3(1024), fold_lds, st, red, (double)B * TV, stat,
+  hipLaunchKernelGGL(k_bwd_fold, dim3(NF + tab_blocks), dim3(1024), fold_lds, st, red, stats_count > 0.0 ? stats_count : (double)B * TV, stat,
                      Wt, gs, Wr, gr, dWt, dbt, dgs, dbs, dWr, dbr, dgr, dbr2, w.coef, Ci, Co, accumulate, Aw, Tw, w.btab, NF);
   if ((rc = check_launch("bwd_fold"))) return rc;
   // 3 + 4 in one kernel (fused_bwd.hip) for the stored-Z path at the shapes it is built for: dZ never leaves the CU
@@ -1663,7 +1673,8 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
                                float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                                int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z,
                                const float* stats_in, int stats_in_rows, const float* below_in, const float* below_Z,
-                               const float* below_in_slope, int below_Ci, float* below_stats, size_t below_stats_bytes) {
+                               const float* below_in_slope, int below_Ci, float* below_stats, size_t below_stats_bytes,
+                               double stats_count) {
   if (!in || !dU || !A || !Tm || !stat || !Wt || !gamma_t || !dA || !dT || !dWt || !dgamma_t || !dbeta_t || !ws || !Z)
     return fail(COSKAD_ERR_ARG, "layer_bwd_chain: null pointer");
   if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: residual grads missing");
@@ -1686,7 +1697,35 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
                                   dbt, dgamma_t, dbeta_t, dWr, dbr, dgamma_r, dbeta_r, dslope_in, ws,      \
                                   ws_bytes, accumulate, B, Ci, Co, stream, nullptr, Z, stats_in, stats_in_rows, \
                                   below_stats ? below_in : nullptr, below_stats ? below_Z : nullptr,                  \
-                                  below_stats ? below_in_slope : nullptr, below_Ci, below_stats)
+                                  below_stats ? below_in_slope : nullptr, below_Ci, below_stats, stats_count)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+/* Stage 1 of coskad_layer_bwd_z_f32 ALONE, into a chain buffer (SyncBN: the caller adds the other ranks' fp64 sums in place, then
+ * passes the buffer as `stats_in` with `stats_count` = global clips x T x V).  stats_out: coskad_layer_bwd_stats_floats(...) floats,
+ * 8-byte aligned; *rows_out = partial rows written (the sums sit behind them: coskad_layer_bwd_sums_offset(rows, Ci, Co)). */
+size_t coskad_layer_bwd_stats_floats(int B, int Ci, int Co, int T, int V) {
+  (void)B; (void)T; (void)V;
+  const size_t E = 2 * (size_t)Co * Ci + Co;
+  return ((size_t)kMaxGridBwd * E + 1) / 2 * 2 + 2 * E;
+}
+size_t coskad_layer_bwd_sums_offset(int rows, int Ci, int Co) { return chain_sums_offset(rows, 2 * Co * Ci + Co); }
+
+int coskad_layer_bwd_stats_f32(const float* in, const float* dU, const float* A, const float* Tm, const float* in_slope,
+                               int has_residual, float* stats_out, size_t stats_out_bytes, int* rows_out, void* ws, size_t ws_bytes,
+                               int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z) {
+  if (!in || !dU || !A || !Tm || !stats_out || !rows_out || !ws) return fail(COSKAD_ERR_ARG, "layer_bwd_stats: null pointer");
+  if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd_stats: B=%d Ci=%d Co=%d", B, Ci, Co);
+  if ((size_t)stats_out & 7) return fail(COSKAD_ERR_ARG, "layer_bwd_stats: stats_out must be 8-byte aligned");
+  if (stats_out_bytes < coskad_layer_bwd_stats_floats(B, Ci, Co, T, V) * sizeof(float))
+    return fail(COSKAD_ERR_WORKSPACE, "layer_bwd_stats: stats_out %zu bytes too small", stats_out_bytes);
+  const float* wr_tag = has_residual ? in : nullptr;   // stage 1 only asks whether the residual branch exists
+#define CALL(T_, V_)                                                                                                      \
+  return launch_layer_bwd<T_, V_>(in, dU, A, Tm, in_slope, nullptr, nullptr, nullptr, wr_tag, nullptr, nullptr, nullptr, nullptr, \
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, \
+                                  0, B, Ci, Co, stream, nullptr, Z, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.0,  \
+                                  stats_out, rows_out)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

@@ -298,9 +298,12 @@ static int launch_reduce_fold(const float* partials, int rows, double* red, doub
                               const float* br, const float* gr, const float* brr, float* rm_r, float* rv_r, long long* nbt_r,
                               float momentum, float* wfold, float* bias, float* stat, int Ci, int Co, hipStream_t st) {
   const int E = 2 * (Ci * Ci + Ci);
-  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, rows, E, red);
-  int rc = check_launch("reduce_partials");
-  if (rc) return rc;
+  int rc = 0;
+  if (partials) {                                        // (NULL: `red` holds the sums already -- SyncBN, summed over the ranks)
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, rows, E, red);
+    if ((rc = check_launch("reduce_partials"))) return rc;
+  }
+  if (!Wt) return 0;                                     // sums only
   const size_t fold_lds = (2 * (size_t)Ci * Ci + 2 * Ci) * sizeof(double) + (4 * (size_t)Co * Ci + 4 * Co) * sizeof(float);
   if (fold_lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_train_fold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
   const int fold_blocks = Co >= 32 ? 8 : (Co >= 16 ? 4 : 1);
@@ -317,7 +320,8 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
                               const float* br, const float* gr, const float* brr, float* rm_r,
                               float* rv_r, long long* nbt_r, float momentum, float* wfold, float* bias,
                               float* stat, void* ws, size_t ws_bytes, int B, int Ci, int Co,
-                              hipStream_t st, float* Zout = nullptr) {
+                              hipStream_t st, float* Zout = nullptr, double* sums_out = nullptr, int need_x_sums = 1) {
+  // sums_out != NULL: stop behind the fp64 moment sums (written there; Wt .. stat unused) -- the caller adds the other ranks'
   constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int kScratchFloats = Geo<T, V>::Scratch;
   constexpr int TV = Geo<T, V>::TV, LD = TV + 2;   // k_fwd_moments' row stride
@@ -337,7 +341,7 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
   float* partials = reinterpret_cast<float*>(ws);
   double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + round_up((int)(kMaxGrid * (size_t)E * sizeof(float)), 256));
-  const int need_x = Wr != nullptr;
+  const int need_x = sums_out ? need_x_sums : (Wr != nullptr);
   const int ntc = ceil_div(Ci, 16);
   int rows = grid;
   if (Zout && Ci <= 4 && TV % 4 == 0) {
@@ -362,6 +366,9 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   }
   int rc = check_launch("fwd_moments");
   if (rc) return rc;
+  if (sums_out)
+    return launch_reduce_fold(partials, rows, sums_out, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, Ci, Co, st);
   return launch_reduce_fold(partials, rows, red, (double)B * TV, Wt, bt, gs, bs, rm_s, rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r,
                             nbt_r, momentum, wfold, bias, stat, Ci, Co, st);
 }
@@ -437,6 +444,48 @@ int coskad_layer_train_fold_f32(const float* partials, int rows, const float* Wt
   return launch_reduce_fold(partials, rows, reinterpret_cast<double*>(ws), (double)B * T * V, Wt, bt, gamma_t, beta_t, rmean_t,
                             rvar_t, nbt_t, Wr, br, gamma_r, beta_r, rmean_r, rvar_r, nbt_r, momentum, wfold, bias, stat, Ci, Co,
                             stream);
+}
+
+/* ---- SyncBN (optional; the reference trains with per-rank statistics, train_COSKAD.py:75-78): the three steps of
+ * coskad_layer_train_stats_z_f32 / coskad_layer_train_fold_f32 as separate calls, so that the caller can add the other ranks'
+ * moment sums (an all-reduce of 2 (Ci^2 + Ci) doubles) between the batch reduction and the fold ------------------------------ */
+
+/* step 1 (a layer with its own statistics pass): Z = gcn(PReLU(in)) [B,Ci,T,V] (NULL: not stored) and this rank's fp64 moment
+ * sums [sum xx^T Ci^2][sum x Ci][sum zz^T Ci^2][sum z Ci] -> sums.  ws: coskad_train_stats_ws_bytes(Ci). */
+int coskad_layer_train_moments_f32(const float* in, const float* A, const float* Tm, const float* in_slope, float* Z, double* sums,
+                                   void* ws, size_t ws_bytes, int B, int Ci, int T, int V, hipStream_t stream) {
+  if (!in || !A || !Tm || !sums || !ws) return fail(COSKAD_ERR_ARG, "layer_train_moments: null pointer");
+  if (B <= 0 || Ci <= 0) return fail(COSKAD_ERR_ARG, "layer_train_moments: B=%d Ci=%d", B, Ci);
+  if ((size_t)sums & 7) return fail(COSKAD_ERR_ARG, "layer_train_moments: sums must be 8-byte aligned");
+#define CALL(T_, V_)                                                                                                       \
+  return launch_train_stats<T_, V_>(in, A, Tm, in_slope, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, \
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, ws,     \
+                                    ws_bytes, B, Ci, Ci, stream, Z, sums, 1)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+/* step 1 (moment partials written by the previous layer's coskad_layer_apply_next_f32): partials [rows][2 (Ci^2 + Ci)] -> sums */
+int coskad_layer_moment_sums_f32(const float* partials, int rows, int Ci, double* sums, hipStream_t stream) {
+  if (!partials || !sums || rows <= 0 || Ci <= 0 || Ci > 64) return fail(COSKAD_ERR_ARG, "layer_moment_sums: bad argument");
+  if ((size_t)sums & 7) return fail(COSKAD_ERR_ARG, "layer_moment_sums: sums must be 8-byte aligned");
+  return launch_reduce_fold(partials, rows, sums, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, Ci, Ci, stream);
+}
+
+/* step 2: the fold (statistics, folded weights, running-statistics update) from moment sums over `count` positions
+ * (= global clips x T x V once the ranks' sums are added). */
+int coskad_layer_train_fold_sums_f32(const double* sums, double count, const float* Wt, const float* bt, const float* gamma_t,
+                                     const float* beta_t, float* rmean_t, float* rvar_t, long long* nbt_t,
+                                     const float* Wr, const float* br, const float* gamma_r,
+                                     const float* beta_r, float* rmean_r, float* rvar_r, long long* nbt_r,
+                                     float momentum, float* wfold, float* bias, float* stat, int Ci, int Co, hipStream_t stream) {
+  if (!sums || !Wt || !gamma_t || !beta_t || !wfold || !bias || !stat) return fail(COSKAD_ERR_ARG, "layer_train_fold_sums: null pointer");
+  if (Wr && (!gamma_r || !beta_r)) return fail(COSKAD_ERR_ARG, "layer_train_fold_sums: residual BN missing");
+  if (!Wr && Ci != Co) return fail(COSKAD_ERR_ARG, "layer_train_fold_sums: identity residual needs Ci == Co");
+  if (count <= 0.0 || Ci <= 0 || Co <= 0 || Ci > 64) return fail(COSKAD_ERR_ARG, "layer_train_fold_sums: count=%g Ci=%d Co=%d", count, Ci, Co);
+  return launch_reduce_fold(nullptr, 0, const_cast<double*>(sums), count, Wt, bt, gamma_t, beta_t, rmean_t, rvar_t, nbt_t, Wr, br,
+                            gamma_r, beta_r, rmean_r, rvar_r, nbt_r, momentum, wfold, bias, stat, Ci, Co, stream);
 }
 
 #ifdef COSKAD_FOLD_TIMING

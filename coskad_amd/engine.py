@@ -109,13 +109,27 @@ class ChainCtx:
     stats: List[Tensor] = field(default_factory=list)    # stat block of layer i
     zs: List[Optional[Tensor]] = field(default_factory=list)   # stored gcn(input) of layer i (None: recompute)
     in_slope: Optional[Tensor] = None                    # activation applied to inputs[0] (None: raw)
+    sync: object = None                                  # SyncBN: the process group of the forward ...
+    sync_count: float = 0.0                              # ... and the positions of the global batch
 
 
 def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Workspace,
-                  in_slope: Optional[Tensor] = None, want_ctx: bool = False):
-    """-> (U_last, ctx).  U_last is the last layer's PRE-activation; apply layers[-1].slope to it."""
+                  in_slope: Optional[Tensor] = None, want_ctx: bool = False, sync=None):
+    """-> (U_last, ctx).  U_last is the last layer's PRE-activation; apply layers[-1].slope to it.
+    sync: a torch.distributed process group -> SyncBN (optional; the reference trains with per-rank statistics,
+    train_COSKAD.py:75-78): every BatchNorm boundary adds the other ranks' fp64 moment sums before the fold."""
     B, C, T, V = x.shape
     ctx = ChainCtx(in_slope=in_slope) if want_ctx else None
+    sync_count = None
+    if sync is not None and training:
+        import torch.distributed as dist
+        if not STORE_Z:
+            raise ValueError("SyncBN runs on the stored-Z training path")
+        cnt = torch.tensor([float(B * T * V)], device=x.device, dtype=torch.float64)
+        dist.all_reduce(cnt, group=sync)
+        sync_count = float(cnt.item())               # positions of the global batch (ranks may hold different batch sizes)
+        if ctx is not None:
+            ctx.sync, ctx.sync_count = sync, sync_count
     h, slope = x, in_slope
     n = len(layers)
     # fuse[i]: layer i's apply kernel also forms layer i+1's Z and moment partials (csrc/fused_apply_next.hip), so
@@ -141,7 +155,18 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
                 L.cache.clear()   # running stats (and, after the optimiser, the weights) change through raw-pointer kernels
                                   # that do not bump torch's version counters: drop the eval-mode fold
             buf = ws.get(ops.train_stats_ws_bytes(L.Ci), x.device)
-            if pending is not None:
+            if sync_count is not None:
+                if pending is not None:
+                    Z, partials, rows = pending
+                    sums = ops.layer_moment_sums(partials, rows, L.Ci)
+                else:
+                    Z = torch.empty_like(h)
+                    sums = ops.layer_train_moments(h, L.A, L.T, slope, buf, Z=Z)
+                dist.all_reduce(sums, group=sync)
+                wfold, bias, stat = ops.layer_train_fold_sums(
+                    sums, sync_count, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
+                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, momentum=L.momentum)
+            elif pending is not None:
                 Z, partials, rows = pending
                 wfold, bias, stat = ops.layer_train_fold(
                     partials, rows, B, T, V, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
@@ -220,6 +245,8 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
     With `side`, dA / dT are computed on its stream (joined into the current stream before returning).
     Returns d(inputs[0]) if need_dx."""
     n = len(layers)
+    if ctx.sync is not None and side is not None:
+        raise ValueError("SyncBN runs on the main stream (side=None)")
     main = torch.cuda.current_stream() if side is not None else None
     if side is not None:
         side.done = [None, None]     # the previous call joined the side stream: nothing of it is still in flight
@@ -237,6 +264,12 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
         buf = ws.get(ops.layer_bwd_ws_bytes(B, Ci, L.Co, T, V), x_in.device)
         args = (x_in, dU, L.A, L.T, in_slope, ctx.stats[i], L.w2(L.Wt), L.gt, L.w2(L.Wr), L.gr, _as2d(g), buf)
         if side is None:
+            sync = ctx.sync
+            if sync is not None:
+                import torch.distributed as dist
+                if stats_in is None:                      # the top layer (or a pair without a chain kernel): stage 1 by itself
+                    stats_in = ops.layer_bwd_stats(x_in, dU, L.A, L.T, in_slope, L.Wr is not None, buf, Z=ctx.zs[i])
+                dist.all_reduce(ops.chain_sums(stats_in[0], stats_in[1], Ci, L.Co), group=sync)
             below = None
             if FUSE_BELOW and ctx.zs and i > 0 and in_slope is not None and layers[i - 1].Wr is not None:
                 cb = ctx.inputs[i - 1].shape[1]
@@ -245,7 +278,7 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
                     below = (ctx.inputs[i - 1], ctx.zs[i - 1], layers[i - 2].slope if i > 1 else ctx.in_slope,
                              torch.empty(ops.layer_bwd_below_floats(B, Ci, L.Co, cb, T, V), device=x_in.device, dtype=torch.float32))
             dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate, Z=ctx.zs[i] if ctx.zs else None,
-                                stats_in=stats_in, below=below)
+                                stats_in=stats_in, below=below, stats_count=ctx.sync_count if sync is not None else 0.0)
             stats_in = (below[3], rows) if below is not None else None
         else:
             k = i & 1

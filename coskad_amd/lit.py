@@ -107,8 +107,10 @@ class LitEncoder(nn.Module):
             mu = self.model.c if self.static_center else self._temp
             self.model.inv_cov_matrix.copy_(inv_cov_from_moments(gram, acc, mu, L))
         self.model.train()
+        # `sync_batchnorm` (not a key of the reference's yamls, whose DDP keeps per-rank BatchNorm statistics): optional SyncBN
+        extra = {"sync_bn": True} if bool(getattr(self.args, "sync_batchnorm", False)) else {}
         self._engine = make_train_step(self.model, lr=self.learning_rate, alpha=float(getattr(self.args, "alpha", 0.0)),
-                                     head="poincare" if self.hyperbolic else ("mahalanobis" if maha else "euclidean"))
+                                     head="poincare" if self.hyperbolic else ("mahalanobis" if maha else "euclidean"), **extra)
         self._epoch = 0
 
     # ---- one optimisation step -----------------------------------------------------------

@@ -139,6 +139,76 @@ def layer_train_stats(x, A, Tm, in_slope, Wt, bt, gt, bet, rm_t, rv_t, nbt_t,
     return wfold, bias, stat
 
 
+# ---- SyncBN building blocks (csrc: "SyncBN" section of include/coskad_hip.h): batch reductions and folds as separate calls ---------
+def layer_train_moments(x, A, Tm, in_slope, ws, Z: Optional[Tensor] = None) -> Tensor:
+    """This rank's fp64 moment sums [sum xx^T Ci^2][sum x Ci][sum zz^T Ci^2][sum z Ci] of one layer's input (and Z = gcn(PReLU(x)))."""
+    B, Ci, T, V = x.shape
+    _chk(x, "x"); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T)); _chk(in_slope, "in_slope", (1,), optional=True)
+    _chk(Z, "Z", tuple(x.shape), optional=True)
+    need = train_stats_ws_bytes(Ci)
+    if ws is None or _bytes(ws) < need:
+        raise ValueError(f"workspace too small: need {need} bytes")
+    sums = torch.empty(2 * (Ci * Ci + Ci), device=x.device, dtype=torch.float64)
+    call("coskad_layer_train_moments_f32", ptr(x), ptr(A), ptr(Tm), ptr(in_slope), ptr(Z), ptr(sums), ptr(ws),
+         ctypes.c_size_t(_bytes(ws)), i32(B), i32(Ci), i32(T), i32(V), _stream())
+    return sums
+
+
+def layer_moment_sums(partials: Tensor, rows: int, Ci: int) -> Tensor:
+    """fp64 sums of the moment partial rows a layer_apply_next wrote for the next layer."""
+    _chk(partials, "partials")
+    if partials.numel() < rows * 2 * (Ci * Ci + Ci):
+        raise ValueError("layer_moment_sums: partials smaller than rows x 2 (Ci^2 + Ci)")
+    sums = torch.empty(2 * (Ci * Ci + Ci), device=partials.device, dtype=torch.float64)
+    call("coskad_layer_moment_sums_f32", ptr(partials), i32(rows), i32(Ci), ptr(sums), _stream())
+    return sums
+
+
+def layer_train_fold_sums(sums, count, Wt, bt, gt, bet, rm_t, rv_t, nbt_t, Wr, br, gr, ber, rm_r, rv_r, nbt_r, momentum: float = 0.1):
+    """(wfold, bias, stat) from moment sums over `count` positions (global clips x T x V once the ranks' sums are added)."""
+    Co, Ci = Wt.shape
+    _chk(sums, "sums", (2 * (Ci * Ci + Ci),), dtype=torch.float64); _chk(Wt, "Wt", (Co, Ci)); _chk(gt, "gamma_t", (Co,)); _chk(bet, "beta_t", (Co,))
+    for n, t in (("bt", bt), ("rm_t", rm_t), ("rv_t", rv_t), ("br", br), ("gamma_r", gr), ("beta_r", ber), ("rm_r", rm_r), ("rv_r", rv_r)):
+        _chk(t, n, (Co,), optional=True)
+    _chk(Wr, "Wr", (Co, Ci), optional=True)
+    _chk(nbt_t, "nbt_t", (), dtype=torch.int64, optional=True); _chk(nbt_r, "nbt_r", (), dtype=torch.int64, optional=True)
+    wfold = torch.empty(2 * Ci, cop(Co), device=Wt.device, dtype=torch.float32)
+    bias = torch.empty(cop(Co), device=Wt.device, dtype=torch.float32)
+    stat = torch.empty(stat_floats(Ci, Co), device=Wt.device, dtype=torch.float32)
+    call("coskad_layer_train_fold_sums_f32", ptr(sums), ctypes.c_double(float(count)), ptr(Wt), ptr(bt), ptr(gt), ptr(bet), ptr(rm_t),
+         ptr(rv_t), ptr(nbt_t), ptr(Wr), ptr(br), ptr(gr), ptr(ber), ptr(rm_r), ptr(rv_r), ptr(nbt_r), ctypes.c_float(momentum),
+         ptr(wfold), ptr(bias), ptr(stat), i32(Ci), i32(Co), _stream())
+    return wfold, bias, stat
+
+
+def layer_bwd_stats(x_in, dU, A, Tm, in_slope, has_residual: bool, ws, Z=None):
+    """Stage 1 of layer_bwd alone -> (chain buffer, rows): the partial rows, then their fp64 sums (chain_sums(buf, rows, Ci, Co))."""
+    B, Ci, T, V = x_in.shape
+    Co = dU.shape[1]
+    _chk(x_in, "x_in"); _chk(dU, "dU", (B, Co, T, V)); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
+    _chk(in_slope, "in_slope", (1,), optional=True); _chk(Z, "Z", (B, Ci, T, V), optional=True)
+    need = layer_bwd_ws_bytes(B, Ci, Co, T, V)
+    if ws is None or _bytes(ws) < need:
+        raise ValueError(f"workspace too small: need {need} bytes")
+    fn = _lib.lib().coskad_layer_bwd_stats_floats
+    fn.restype = ctypes.c_size_t
+    buf = torch.empty(fn(i32(B), i32(Ci), i32(Co), i32(T), i32(V)), device=x_in.device, dtype=torch.float32)
+    rows = ctypes.c_int(0)
+    call("coskad_layer_bwd_stats_f32", ptr(x_in), ptr(dU), ptr(A), ptr(Tm), ptr(in_slope), i32(1 if has_residual else 0), ptr(buf),
+         ctypes.c_size_t(_bytes(buf)), ctypes.byref(rows), ptr(ws), ctypes.c_size_t(_bytes(ws)), i32(B), i32(Ci), i32(Co), i32(T), i32(V),
+         _stream(), ptr(Z))
+    return buf, rows.value
+
+
+def chain_sums(buf: Tensor, rows: int, Ci: int, Co: int) -> Tensor:
+    """The fp64 sums [P Co*Ci][Q Co*Ci][sdU Co] inside a backward chain buffer, as a view (all-reduce it in place for SyncBN)."""
+    fn = _lib.lib().coskad_layer_bwd_sums_offset
+    fn.restype = ctypes.c_size_t
+    off = fn(i32(rows), i32(Ci), i32(Co))
+    E = 2 * Co * Ci + Co
+    return buf[off:off + 2 * E].view(torch.float64)
+
+
 def layer_apply_z(Z, x, A, Tm, wfold, bias, Co, in_slope=None, out_slope=None, out=None):
     """U = Wz.Z + Wx.PReLU(x) + b from the stored Z = gcn(PReLU(x)) (training forward; streaming, no recompute)."""
     B, Ci, T, V = x.shape
@@ -277,11 +347,12 @@ def layer_bwd_below_floats(B: int, Ci: int, Co: int, below_Ci: int, T: int, V: i
 
 
 def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, need_dx=True,
-              dIn=None, accumulate=False, Z=None, stats_in=None, below=None):
+              dIn=None, accumulate=False, Z=None, stats_in=None, below=None, stats_count=0.0):
     """Backward of one layer.  `grads` maps names -> preallocated gradient tensors:
     A, T, Wt, bt (opt), gt, bet, Wr, br (opt), gr, ber, slope_in (opt).  Returns dIn (or None).
     Chain mode (csrc: coskad_layer_bwd_chain_f32, needs Z): `stats_in` = (partial rows tensor, rows) the call for the layer above
-    wrote for this layer; `below` = (x_below, Z_below, in_slope_below, below_stats) makes this call write the layer below's partial rows."""
+    wrote for this layer; `below` = (x_below, Z_below, in_slope_below, below_stats) makes this call write the layer below's partial rows;
+    `stats_count`: positions the sums in `stats_in` cover (0: this batch; SyncBN: global clips x T x V)."""
     B, Ci, T, V = x_in.shape
     Co = Wt.shape[0]
     _chk(x_in, "x_in"); _chk(dU, "dU", (B, Co, T, V)); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
@@ -315,7 +386,7 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
         _chk(xb, "below x", (B, cb, T, V), optional=True); _chk(zb, "below Z", (B, cb, T, V), optional=True); _chk(bs, "below_stats", optional=True)
         _chk(sb, "below in_slope", (1,), optional=True)
         call("coskad_layer_bwd_chain_f32", *args, ptr(Z), ptr(sp), i32(srows), ptr(xb), ptr(zb), ptr(sb), i32(cb), ptr(bs),
-             ctypes.c_size_t(_bytes(bs) if bs is not None else 0))
+             ctypes.c_size_t(_bytes(bs) if bs is not None else 0), ctypes.c_double(float(stats_count)))
     elif Z is None:
         call("coskad_layer_bwd_f32", *args)
     else:       # stored gcn(PReLU(x_in)) from layer_train_stats(..., Z=...): no mixing recompute in the backward kernels

@@ -73,7 +73,7 @@ class STSETrainStep:
 
     def __init__(self, model, lr: float = 1e-4, alpha: float = 1e-6, head: str = 'euclidean',
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, use_graph: bool = False,
-                 side_stream: bool = False) -> None:
+                 side_stream: bool = False, sync_bn: bool = False) -> None:
         from .models.sts.ae import STSE
         from .models.common.components import MLP
         self.mlp = isinstance(model.btlnk, MLP)
@@ -107,6 +107,13 @@ class STSETrainStep:
         # optional: dA / dT on a second stream beside the next layer's reductions.  Measured SLOWER on MI355X (2.43 vs
         # 2.28 ms/step: the two LDS-heavy persistent kernels halve each other's occupancy), so it is off by default.
         self.side = engine.SideStream() if side_stream else None
+        # optional SyncBN of the encoder's BatchNorm2d layers (the reference's DDP keeps per-rank statistics): every
+        # BatchNorm boundary of the forward and the backward adds the other ranks' fp64 sums (engine.chain_forward / _backward)
+        self.sync_group = None
+        if sync_bn and self.world > 1:
+            if self.mlp or side_stream or use_graph:
+                raise ValueError("sync_bn: encoder BatchNorm only (linear projector), on the main stream, outside hipGraph capture")
+            self.sync_group = process_group if process_group is not None else dist.group.WORLD
         # gradient buckets for the data-parallel all-reduce: [encoder | bottleneck]; the bottleneck parameters are the
         # tail of the flat buffer (named_parameters order) and their gradients are final before the encoder backward
         names = self.fp.names
@@ -127,7 +134,7 @@ class STSETrainStep:
     def _body(self, x: Tensor) -> Tensor:
         m = self.model
         B = x.shape[0]
-        U, ctx = engine.chain_forward(x, self.layers, True, self.ws, want_ctx=True)
+        U, ctx = engine.chain_forward(x, self.layers, True, self.ws, want_ctx=True, sync=self.sync_group)
         slope = self.layers[-1].slope
         gv = self.fp.gviews
         if self.mlp:
@@ -543,4 +550,6 @@ def make_train_step(model, **kw):
     if fast:
         return STSETrainStep(model, **kw)
     kw.pop('use_graph', None); kw.pop('side_stream', None)
+    if kw.pop('sync_bn', False):
+        raise ValueError("sync_bn needs the flat-buffer step (STS-GCN encoder within the tile kernels + linear / mlp projector)")
     return AutogradTrainStep(model, **kw)

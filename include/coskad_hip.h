@@ -254,7 +254,30 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
                                float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                                int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z,
                                const float* stats_in, int stats_in_rows, const float* below_in, const float* below_Z,
-                               const float* below_in_slope, int below_Ci, float* below_stats, size_t below_stats_bytes);
+                               const float* below_in_slope, int below_Ci, float* below_stats, size_t below_stats_bytes,
+                               double stats_count);
+
+/* ---- SyncBN (optional: the reference trains with per-rank BatchNorm statistics, train_COSKAD.py:75-78) -------------
+ * The batch reductions and the folds behind them as separate calls, so that a data-parallel caller can add the other ranks'
+ * fp64 sums (one small all-reduce per BatchNorm boundary) in between.  Forward: coskad_layer_train_moments_f32 (a layer with its own
+ * statistics pass) or coskad_layer_moment_sums_f32 (moment partials from coskad_layer_apply_next_f32) -> sums [2 (Ci^2 + Ci)]
+ * doubles: [sum xx^T][sum x][sum zz^T][sum z] -> all-reduce -> coskad_layer_train_fold_sums_f32 with count = global clips x T x V.
+ * Backward: coskad_layer_bwd_stats_f32 (stage 1 alone, into a chain buffer: rows, then sums at coskad_layer_bwd_sums_offset floats)
+ * or the chain buffer the layer above filled -> all-reduce the sums in place -> coskad_layer_bwd_chain_f32 with stats_in and
+ * stats_count = global clips x T x V (0: this batch). */
+int coskad_layer_train_moments_f32(const float* in, const float* A, const float* Tm, const float* in_slope, float* Z, double* sums,
+                                   void* ws, size_t ws_bytes, int B, int Ci, int T, int V, hipStream_t stream);
+int coskad_layer_moment_sums_f32(const float* partials, int rows, int Ci, double* sums, hipStream_t stream);
+int coskad_layer_train_fold_sums_f32(const double* sums, double count, const float* Wt, const float* bt, const float* gamma_t,
+                                     const float* beta_t, float* rmean_t, float* rvar_t, long long* nbt_t,
+                                     const float* Wr, const float* br, const float* gamma_r,
+                                     const float* beta_r, float* rmean_r, float* rvar_r, long long* nbt_r,
+                                     float momentum, float* wfold, float* bias, float* stat, int Ci, int Co, hipStream_t stream);
+size_t coskad_layer_bwd_stats_floats(int B, int Ci, int Co, int T, int V);
+size_t coskad_layer_bwd_sums_offset(int rows, int Ci, int Co);
+int coskad_layer_bwd_stats_f32(const float* in, const float* dU, const float* A, const float* Tm, const float* in_slope,
+                               int has_residual, float* stats_out, size_t stats_out_bytes, int* rows_out, void* ws, size_t ws_bytes,
+                               int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z);
 
 /* in   : the layer's input as stored by the producer (pre-activation; in_slope = its PReLU weight,
  *        NULL when `in` is the raw network input)
