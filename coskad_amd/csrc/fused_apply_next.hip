@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256, 1) void k_layer_apply_next(const float* __rest
   const int nwaves = gridDim.x * 4;
   auto clip_res = [&](const float* base, int c, int rows) {
     const bool in_range = c < B;
+#ifdef COSKAD_HOT   // timing-only: every stream from 64 L2-resident clips
+    return make_res(base + (size_t)(in_range ? (c & 63) : 0) * rows * TV, in_range ? rows * TV * 4u : 0u);
+#else
     return make_res(base + (size_t)(in_range ? c : 0) * rows * TV, in_range ? rows * TV * 4u : 0u);
+#endif
   };
   constexpr int QTAIL = 4 * (TV / 4) - 192;              // lanes of a quarter's 4th piece (12)
   const int l16t = lane < QTAIL ? l16 : 0x7ffffff0;

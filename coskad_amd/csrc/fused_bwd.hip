@@ -164,7 +164,11 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
   // Streams are buffer resources per clip; beyond the batch they are empty (loads return 0 without traffic)
   auto clip_res = [&](const float* base, int c, int rows) {
     const bool in_range = c < B;
+#ifdef COSKAD_HOT   // timing-only: every stream from 64 L2-resident clips
+    return make_res(base + (size_t)(in_range ? (c & 63) : 0) * rows * TV, in_range ? rows * TV * 4u : 0u);
+#else
     return make_res(base + (size_t)(in_range ? c : 0) * rows * TV, in_range ? rows * TV * 4u : 0u);
+#endif
   };
   // X of the NEXT clip is fetched while this clip's epilogue runs and staged at the loop head
   constexpr int XL = (Ci * (TV / 4) + 63) / 64;          // float4 per lane of a clip's input (26 / 13)
