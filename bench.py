@@ -301,6 +301,7 @@ def main():
     KID_LAYER_APPLY, KID_BWD_DATA, KID_LAYER_BWD, KID_FUSED = 1, 2, 6, 7
     probing = not args.graph
     if probing:
+        lib.coskad_probe_stride(8)                   # every 8th step's layer backward: a probed launch costs ~5 us of stream time
         lib.coskad_probe_begin(KID_LAYER_BWD, CHANNELS[-1], HID)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -310,6 +311,7 @@ def main():
     lbw_ms, lbw_n = ctypes.c_float(0), ctypes.c_int(0)
     if probing:
         lib.coskad_probe_end(ctypes.byref(lbw_ms), ctypes.byref(lbw_n))
+        lib.coskad_probe_stride(1)
 
     def probe_steps(kid, ci, co, n=5):
         # every rank runs these steps (they contain the gradient all-reduce); only rank 0 reads its probe
@@ -395,7 +397,7 @@ def main():
                     "traffic": (traffic.get("layer4 backward", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
                     "traffic_source": f"{traffic_src} (PMC FETCH_SIZE/WRITE_SIZE summed over the layer's kernels, B=4096)",
                     "algorithmic_bytes_per_launch": layer_bytes, "avg_launch_us": round(lbw_ms.value * 1e3, 2),
-                    "launches": lbw_n.value}
+                    "launches": lbw_n.value, "probe": "HIP events around every 8th step's layer backward, inside the timed region"}
             if dom_n:
                 ach1 = layer_bytes / (dom_ms * 1e-3) / 1e9
                 # the same launches against the fp32 MFMA roof: convs Bt.dU, Br.dU (C_in x C_out each),

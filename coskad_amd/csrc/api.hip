@@ -34,12 +34,14 @@ namespace coskad {
 namespace {
 struct Probe {
   int kernel = 0, ci = 0, co = 0;
+  int stride = 1, seen = 0;    // every stride-th matching launch is timed (two event records cost ~2.7 us of stream time each pair)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
 } g_probe;
 }  // namespace
 
 ProbeScope::ProbeScope(int kernel, int ci, int co, hipStream_t st) : st_(st) {
-  if (g_probe.kernel == kernel && g_probe.ci == ci && g_probe.co == co && g_probe.evs.size() < 4096) {
+  if (g_probe.kernel == kernel && g_probe.ci == ci && g_probe.co == co && g_probe.evs.size() < 4096 &&
+      (g_probe.seen++ % g_probe.stride) == 0) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
       (void)hipEventRecord(a, st);
@@ -60,6 +62,14 @@ int coskad_probe_begin(int kernel, int Ci, int Co) {
   coskad::g_probe.kernel = kernel;
   coskad::g_probe.ci = Ci;
   coskad::g_probe.co = Co;
+  coskad::g_probe.seen = 0;
+  return COSKAD_OK;
+}
+
+/* Time every n-th matching launch only (n >= 1; stays until changed). */
+int coskad_probe_stride(int n) {
+  if (n < 1) return coskad::fail(COSKAD_ERR_ARG, "probe_stride: n=%d", n);
+  coskad::g_probe.stride = n;
   return COSKAD_OK;
 }
 

@@ -27,6 +27,7 @@ const char* coskad_last_error(void);
  * coskad_layer_bwd*_f32 call together; 7 = the fused eval-mode encoder kernel) with those channel counts is bracketed by
  * HIP events on its launch stream; coskad_probe_end() waits for them and returns the average duration. */
 int coskad_probe_begin(int kernel, int Ci, int Co);
+int coskad_probe_stride(int n);   /* time every n-th matching launch only (default 1) */
 int coskad_probe_end(float* avg_ms, int* launches);
 
 /* ---- forward ------------------------------------------------------------------------ */
