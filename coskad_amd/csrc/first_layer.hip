@@ -224,8 +224,9 @@ __global__ __launch_bounds__((64 * first_bwd_waves<T, V>()), 4) void k_first_bwd
 // k_first_moments: per clip X -> sum x x^T, sum x;  Z = gcn(X) (stsgcn.py:154-155) -> stored;  sum z z^T, sum z.  One clip per
 //   wave round, a lane owns positions lane + 64 k; the mixing is 12 + 17 FMAs per element on LDS operands.  Partial row per
 //   block: [MX C^2][sumX C][MZ C^2][sumZ C] (what k_reduce_partials / k_train_fold consume).
+constexpr int NWM = 8;   // waves per block of k_first_moments: 512 blocks x 8 waves take B = 4096 in ONE round (4 x 768: two, the second a third full)
 template <int T, int V, int CI>
-__global__ __launch_bounds__(256, 4) void k_first_moments(const float* __restrict__ in, const float* __restrict__ Aw,
+__global__ __launch_bounds__(64 * NWM, 4) void k_first_moments(const float* __restrict__ in, const float* __restrict__ Aw,
                                                           const float* __restrict__ Tw, const float* __restrict__ in_slope,
                                                           float* __restrict__ partials, int B, float* __restrict__ Zout) {
   constexpr int TV = T * V, NA = T * V * V, NT = V * T * T, KP = (TV + 63) / 64;
@@ -238,8 +239,8 @@ __global__ __launch_bounds__(256, 4) void k_first_moments(const float* __restric
   float* Yl = Xl + CI * TV;
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
-  for (int e = tid; e < NA; e += 256) AwL[e] = Aw[e];
-  for (int e = tid; e < NT; e += 256) {         // [t][q][v]: consecutive lanes (joints) read consecutive words
+  for (int e = tid; e < NA; e += 64 * NWM) AwL[e] = Aw[e];
+  for (int e = tid; e < NT; e += 64 * NWM) {    // [t][q][v]: consecutive lanes (joints) read consecutive words
     const int v = e / (T * T), tq = e - v * T * T;
     TwL[tq * V + v] = Tw[e];
   }
@@ -251,9 +252,9 @@ __global__ __launch_bounds__(256, 4) void k_first_moments(const float* __restric
     for (int b = 0; b < CI; ++b) { mx[a][b] = 0.f; mz[a][b] = 0.f; }
   }
   __syncthreads();
-  const int rounds = (B + gridDim.x * 4 - 1) / (gridDim.x * 4);
+  const int rounds = (B + gridDim.x * NWM - 1) / (gridDim.x * NWM);
   for (int r = 0; r < rounds; ++r) {              // every wave runs every round (the block barriers below are uniform)
-    const int clip = (r * gridDim.x + blockIdx.x) * 4 + wave;
+    const int clip = (r * gridDim.x + blockIdx.x) * NWM + wave;
     const bool live = clip < B;
     const float* gx = in + (size_t)(live ? clip : 0) * CI * TV;
 #pragma unroll
@@ -328,7 +329,12 @@ __global__ __launch_bounds__(256, 4) void k_first_moments(const float* __restric
     }
   }
   __syncthreads();
-  if (tid < E) partials[(size_t)blockIdx.x * E + tid] = (row[tid] + row[E + tid]) + (row[2 * E + tid] + row[3 * E + tid]);
+  if (tid < E) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWM; ++w) t += row[w * E + tid];   // fixed order
+    partials[(size_t)blockIdx.x * E + tid] = t;
+  }
 }
 
 // k_first_apply: U[o][p] = (sum_c Wz[c][o] Z[c][p] + Wx[c][o] X[c][p]) + b[o]  (wfold rows: Z channels, then X channels; the
@@ -445,16 +451,16 @@ int launch_first_bwd(const float* in, const float* Zg, const float* dU, const fl
 template <int T, int V>
 static int launch_first_moments_tv(const float* in, const float* Aw, const float* Tw, const float* in_slope, float* partials, int B,
                                    int Ci, float* Zout, int max_rows, hipStream_t st, int* rows_out) {
-  int grid = (B + 3) / 4;
-  if (grid > 1024) grid = 1024;
+  int grid = (B + fl::NWM - 1) / fl::NWM;
+  if (grid > 512) grid = 512;
   if (grid > max_rows) grid = max_rows;
   *rows_out = grid;
-  const size_t lds = ((size_t)T * V * V + (size_t)V * T * T + 8 * (size_t)Ci * T * V) * sizeof(float);
+  const size_t lds = ((size_t)T * V * V + (size_t)V * T * T + 2 * fl::NWM * (size_t)Ci * T * V) * sizeof(float);
 #define LAUNCH_FM(CI)                                                                                                   \
   do {                                                                                                                  \
     auto k = fl::k_first_moments<T, V, CI>;                                                                             \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Aw, Tw, in_slope, partials, B, Zout);                      \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * fl::NWM), lds, st, in, Aw, Tw, in_slope, partials, B, Zout);                    \
   } while (0)
   {
     ProbeScope probe(KID_FWD_MOMENTS, Ci, 0, st);
