@@ -170,6 +170,209 @@ __global__ __launch_bounds__(256) void k_bwd_apply(const float* __restrict__ y1,
   }
 }
 
+// ---- hidden, out <= 16 (what the reference's yamls select: `mlp` with one hidden layer of the latent size) ------------------------
+// The kernels above give a feature ONE block and walk the batch with it: 17 blocks, 18 block-wide fp64 tree sums in a row --
+// 104 us for the backward reduction of 256 KB at B = 4096, 166 us for the four launches.  Here a block owns RB = 64 rows: tiles
+// of y1 / dz in LDS, every sum over the rows is one thread's loop in a fixed order, blocks write partial rows and the second
+// kernel of each direction adds them (fp64, fixed order) -- deterministic as before, 64 blocks instead of 17, no tree sums.
+constexpr int HP = 16, RB = 64;
+constexpr int FWD_PART = 2 * HP;                     // per block: sum y [16], sum y^2 [16] (doubles)
+constexpr int BWD_PART = 2 * HP + HP + HP * HP;      // per block: sum dy2 [16], sum dy2 xhat [16], db2 [16], dW2 [16][16] (floats)
+
+// partial[blk][32] (fp64): sums of y and y^2 over the block's rows
+__global__ __launch_bounds__(256) void k_stats16(const float* __restrict__ y1, double* __restrict__ part, int B, int H) {
+  __shared__ double sh[2][16][HP + 1];
+  const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int r0 = blockIdx.x * RB;
+  double s = 0.0, q = 0.0;
+  if (col < H)
+    for (int r = r0 + rl; r < min(B, r0 + RB); r += 16) {
+      const double v = (double)y1[(size_t)r * H + col];
+      s += v;
+      q += v * v;
+    }
+  sh[0][rl][col] = s;
+  sh[1][rl][col] = q;
+  __syncthreads();
+  if (threadIdx.x < 2 * HP) {
+    const int w = threadIdx.x >> 4, c = threadIdx.x & 15;
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[w][k][c];
+    part[(size_t)blockIdx.x * FWD_PART + threadIdx.x] = t;
+  }
+}
+
+// every block adds the partials (fp64, fixed order) -> mean / invstd; block 0 also stores them and updates the running statistics;
+// then z[n] = W2 . relu(bn(y1[n])) + b2 for the block's rows, one thread per (row, quarter of the outputs)
+__global__ __launch_bounds__(256) void k_apply16(const float* __restrict__ y1, const double* __restrict__ part, int nblk,
+                                                 float* __restrict__ stat, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                 long long* __restrict__ nbt, float momentum, float eps, int training,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ z,
+                                                 int B, int H, int L) {
+  __shared__ float sc[HP], sf[HP], w2[HP][HP + 1], bb[HP], ya[RB][HP + 1];
+  __shared__ double tot[FWD_PART];
+  if (training) {
+    if (threadIdx.x < FWD_PART) {
+      double t = 0.0;
+      for (int p = 0; p < nblk; ++p) t += part[(size_t)p * FWD_PART + threadIdx.x];
+      tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < HP) {
+    const int k = threadIdx.x;
+    float mean = 0.f, inv = 0.f;
+    if (k < H) {
+      if (training) {
+        const double m = tot[k] / B;
+        double ss = tot[HP + k] - m * tot[k];               // sum (y - mean)^2
+        if (ss < 0.0) ss = 0.0;
+        const double var = ss / B;
+        mean = (float)m;
+        inv = (float)(1.0 / sqrt(var + (double)eps));
+        if (blockIdx.x == 0) {
+          if (rmean) {
+            const double unb = B > 1 ? ss / (B - 1) : var;
+            rmean[k] = (float)((1.0 - momentum) * rmean[k] + momentum * m);
+            rvar[k] = (float)((1.0 - momentum) * rvar[k] + momentum * unb);
+          }
+          if (k == 0 && nbt) *nbt += 1;
+        }
+      } else {
+        mean = rmean[k];
+        inv = 1.f / sqrtf(rvar[k] + eps);
+      }
+      if (blockIdx.x == 0) { stat[k] = mean; stat[H + k] = inv; }
+    }
+    sc[k] = k < H ? gamma[k] * inv : 0.f;
+    sf[k] = k < H ? beta[k] - gamma[k] * inv * mean : 0.f;
+    bb[k] = (k < L && b2) ? b2[k] : 0.f;
+  }
+  {
+    const int l = threadIdx.x >> 4, k = threadIdx.x & 15;
+    w2[l][k] = (l < L && k < H) ? W2[l * H + k] : 0.f;
+  }
+  __syncthreads();
+  const int r0 = blockIdx.x * RB;
+  {
+    const int col = threadIdx.x & 15;
+    for (int rr = threadIdx.x >> 4; rr < RB; rr += 16) {
+      const int r = r0 + rr;
+      const float y2 = (r < B && col < H) ? fmaf(y1[(size_t)r * H + col], sc[col], sf[col]) : 0.f;
+      ya[rr][col] = y2 > 0.f ? y2 : 0.f;
+    }
+  }
+  __syncthreads();
+  {
+    const int l = threadIdx.x & 15;
+    for (int rr = threadIdx.x >> 4; rr < RB; rr += 16) {
+      const int r = r0 + rr;
+      float acc = bb[l];
+#pragma unroll
+      for (int k = 0; k < HP; ++k) acc = fmaf(ya[rr][k], w2[l][k], acc);
+      if (r < B && l < L) z[(size_t)r * L + l] = acc;
+    }
+  }
+}
+
+// per block of RB rows: partial [sum dy2][sum dy2 xhat][db2][dW2] (floats, each a fixed-order sum over the block's rows)
+__global__ __launch_bounds__(256) void k_bwd_reduce16(const float* __restrict__ y1, const float* __restrict__ stat,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ W2, const float* __restrict__ dz,
+                                                      float* __restrict__ part, int B, int H, int L) {
+  __shared__ float w2[HP][HP + 1], dzl[RB][HP + 1], al[RB][HP + 1], d2[RB][HP + 1], dx[RB][HP + 1];
+  const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int r0 = blockIdx.x * RB;
+  w2[rl][col] = (rl < L && col < H) ? W2[rl * H + col] : 0.f;
+  for (int rr = rl; rr < RB; rr += 16) {
+    const int r = r0 + rr;
+    dzl[rr][col] = (r < B && col < L) ? dz[(size_t)r * L + col] : 0.f;
+  }
+  __syncthreads();
+  const float mean = col < H ? stat[col] : 0.f, inv = col < H ? stat[H + col] : 0.f;
+  const float g = col < H ? gamma[col] : 0.f, bt = col < H ? beta[col] : 0.f;
+  for (int rr = rl; rr < RB; rr += 16) {
+    const int r = r0 + rr;
+    const bool ok = r < B && col < H;
+    const float xh = ok ? (y1[(size_t)r * H + col] - mean) * inv : 0.f;
+    const float y2 = fmaf(g, xh, bt);
+    float da = 0.f;
+#pragma unroll
+    for (int l = 0; l < HP; ++l) da = fmaf(dzl[rr][l], w2[l][col], da);
+    const float dy2 = (ok && y2 > 0.f) ? da : 0.f;
+    al[rr][col] = (ok && y2 > 0.f) ? y2 : 0.f;
+    d2[rr][col] = dy2;
+    dx[rr][col] = dy2 * xh;
+  }
+  __syncthreads();
+  float* dst = part + (size_t)blockIdx.x * BWD_PART;
+  {                                                       // dW2[l][k] = sum_n dz[n][l] a[n][k]: thread (l, k) walks the rows
+    const int l = rl, k = col;
+    float t = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < RB; ++n) t = fmaf(dzl[n][l], al[n][k], t);
+    dst[3 * HP + l * HP + k] = t;
+  }
+  if (threadIdx.x < 3 * HP) {
+    const int w = threadIdx.x >> 4, c = threadIdx.x & 15;
+    float t = 0.f;
+    for (int n = 0; n < RB; ++n) t += w == 0 ? d2[n][c] : (w == 1 ? dx[n][c] : dzl[n][c]);
+    dst[w * HP + c] = t;
+  }
+}
+
+// every block adds the partials of sum dy2 / sum dy2 xhat (fp64, fixed order); block 0 adds all of them and writes the parameter
+// gradients; then dy1 for the block's rows
+__global__ __launch_bounds__(256) void k_bwd_apply16(const float* __restrict__ y1, const float* __restrict__ stat,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ W2, const float* __restrict__ dz,
+                                                     const float* __restrict__ part, int nblk, float* __restrict__ dy1,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dW2, float* __restrict__ db2, int training, int accumulate,
+                                                     int B, int H, int L) {
+  __shared__ float w2[HP][HP + 1], dzl[RB][HP + 1], red[2 * HP];
+  const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int r0 = blockIdx.x * RB;
+  const int nsum = blockIdx.x == 0 ? BWD_PART : 2 * HP;
+  for (int e = threadIdx.x; e < nsum; e += 256) {
+    double t = 0.0;
+    for (int p = 0; p < nblk; ++p) t += (double)part[(size_t)p * BWD_PART + e];
+    if (e < 2 * HP) red[e] = (float)t;
+    if (blockIdx.x == 0) {
+      float* out = nullptr;
+      if (e < HP) { if (e < H) out = dbeta + e; }
+      else if (e < 2 * HP) { if (e - HP < H) out = dgamma + (e - HP); }
+      else if (e < 3 * HP) { if (e - 2 * HP < L && db2) out = db2 + (e - 2 * HP); }
+      else { const int l = (e - 3 * HP) >> 4, k = (e - 3 * HP) & 15; if (l < L && k < H) out = dW2 + l * H + k; }
+      if (out) *out = accumulate ? *out + (float)t : (float)t;
+    }
+  }
+  w2[rl][col] = (rl < L && col < H) ? W2[rl * H + col] : 0.f;
+  for (int rr = rl; rr < RB; rr += 16) {
+    const int r = r0 + rr;
+    dzl[rr][col] = (r < B && col < L) ? dz[(size_t)r * L + col] : 0.f;
+  }
+  __syncthreads();
+  if (col >= H) return;
+  const float mean = stat[col], inv = stat[H + col], g = gamma[col], bt = beta[col];
+  const float invB = 1.f / (float)B;
+  for (int rr = rl; rr < RB; rr += 16) {
+    const int r = r0 + rr;
+    if (r >= B) break;
+    const float xh = (y1[(size_t)r * H + col] - mean) * inv;
+    const float y2 = fmaf(g, xh, bt);
+    float da = 0.f;
+#pragma unroll
+    for (int l = 0; l < HP; ++l) da = fmaf(dzl[rr][l], w2[l][col], da);
+    const float dy2 = y2 > 0.f ? da : 0.f;
+    float rres = dy2;
+    if (training) rres = dy2 - red[col] * invB - xh * red[HP + col] * invB;
+    dy1[(size_t)r * H + col] = inv * g * rres;
+  }
+}
+
 }  // namespace mlp
 }  // namespace coskad
 
@@ -177,7 +380,18 @@ using namespace coskad;
 
 extern "C" {
 
-/* stat: [2H] floats (mean, invstd of this call); red (backward scratch): [2H] floats */
+/* floats of the `stat` buffer of coskad_mlp_head_fwd_f32 and of the `red` scratch of coskad_mlp_head_bwd_f32: [2H] values
+ * (stat: mean, invstd of this call -- what the backward reads) + the per-block partial sums of the fast path (hidden, out <= 16) */
+size_t coskad_mlp_head_ws_floats(int B, int H, int L) {
+  size_t n = 2 * (size_t)H + 2;
+  if (H <= mlp::HP && L <= mlp::HP && B > 0) {
+    const size_t nblk = (size_t)ceil_div(B, mlp::RB);
+    n += nblk * (2 * mlp::FWD_PART > mlp::BWD_PART ? 2 * mlp::FWD_PART : mlp::BWD_PART);
+  }
+  return n;
+}
+
+/* stat, red: coskad_mlp_head_ws_floats(B, H, L) floats, 8-byte aligned */
 int coskad_mlp_head_fwd_f32(const float* y1, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, long long* num_batches_tracked, float momentum, float eps, int training,
                             const float* W2, const float* b2, float* z, float* stat, int B, int H, int L,
@@ -186,9 +400,21 @@ int coskad_mlp_head_fwd_f32(const float* y1, const float* gamma, const float* be
   if (!training && (!running_mean || !running_var)) return fail(COSKAD_ERR_ARG, "mlp_head_fwd: eval mode needs the running statistics");
   if (B <= 0 || H <= 0 || L <= 0) return fail(COSKAD_ERR_ARG, "mlp_head_fwd: B=%d H=%d L=%d", B, H, L);
   if (H > mlp::HMAX || L > mlp::HMAX) return fail(COSKAD_ERR_SHAPE, "mlp_head_fwd: hidden=%d / out=%d > %d not supported", H, L, mlp::HMAX);
+  int rc;
+  if (H <= mlp::HP && L <= mlp::HP) {
+    if ((size_t)stat & 7) return fail(COSKAD_ERR_ARG, "mlp_head_fwd: stat must be 8-byte aligned");
+    const int nblk = ceil_div(B, mlp::RB);
+    double* part = reinterpret_cast<double*>(stat + (2 * H + 2) / 2 * 2);
+    if (training) {
+      hipLaunchKernelGGL(mlp::k_stats16, dim3(nblk), dim3(256), 0, stream, y1, part, B, H);
+      if ((rc = check_launch("mlp_stats16"))) return rc;
+    }
+    hipLaunchKernelGGL(mlp::k_apply16, dim3(nblk), dim3(256), 0, stream, y1, part, nblk, stat, running_mean, running_var,
+                       num_batches_tracked, momentum, eps, training, gamma, beta, W2, b2, z, B, H, L);
+    return check_launch("mlp_apply16");
+  }
   hipLaunchKernelGGL(mlp::k_stats, dim3(H), dim3(256), 0, stream, y1, stat, running_mean, running_var, num_batches_tracked,
                      momentum, eps, training, B, H);
-  int rc;
   if ((rc = check_launch("mlp_stats"))) return rc;
   hipLaunchKernelGGL(mlp::k_apply, dim3(ceil_div(B, 256)), dim3(256), 0, stream, y1, stat, gamma, beta, W2, b2, z, B, H, L);
   return check_launch("mlp_apply");
@@ -201,9 +427,18 @@ int coskad_mlp_head_bwd_f32(const float* y1, const float* stat, const float* gam
     return fail(COSKAD_ERR_ARG, "mlp_head_bwd: null pointer");
   if (B <= 0 || H <= 0 || L <= 0) return fail(COSKAD_ERR_ARG, "mlp_head_bwd: B=%d H=%d L=%d", B, H, L);
   if (H > mlp::HMAX || L > mlp::HMAX) return fail(COSKAD_ERR_SHAPE, "mlp_head_bwd: hidden=%d / out=%d > %d not supported", H, L, mlp::HMAX);
+  int rc;
+  if (H <= mlp::HP && L <= mlp::HP) {
+    const int nblk = ceil_div(B, mlp::RB);
+    float* part = red + (2 * H + 2) / 2 * 2;
+    hipLaunchKernelGGL(mlp::k_bwd_reduce16, dim3(nblk), dim3(256), 0, stream, y1, stat, gamma, beta, W2, dz, part, B, H, L);
+    if ((rc = check_launch("mlp_bwd_reduce16"))) return rc;
+    hipLaunchKernelGGL(mlp::k_bwd_apply16, dim3(nblk), dim3(256), 0, stream, y1, stat, gamma, beta, W2, dz, part, nblk, dy1, dgamma,
+                       dbeta, dW2, db2, training, accumulate, B, H, L);
+    return check_launch("mlp_bwd_apply16");
+  }
   hipLaunchKernelGGL(mlp::k_bwd_reduce, dim3(H + 1), dim3(256), 0, stream, y1, stat, gamma, beta, W2, dz, red, dgamma, dbeta,
                      dW2, db2, accumulate, B, H, L);
-  int rc;
   if ((rc = check_launch("mlp_bwd_reduce"))) return rc;
   hipLaunchKernelGGL(mlp::k_bwd_apply, dim3(ceil_div(B, 256)), dim3(256), 0, stream, y1, stat, gamma, beta, W2, dz, red, dy1,
                      training, B, H, L);

@@ -723,17 +723,23 @@ def bn2_bwd(Ct, Cr, dOut, stat_t, gt, bt, stat_r, gr, br, slope, training: bool,
     return dCt, dCr, dgt, dbt, dgr, dbr, dslope
 
 
+def mlp_head_ws_floats(B: int, H: int, L: int) -> int:
+    fn = _lib.lib().coskad_mlp_head_ws_floats
+    fn.restype = ctypes.c_size_t
+    return fn(i32(B), i32(H), i32(L))
+
+
 def mlp_head_fwd(y1, gamma, beta, running_mean, running_var, nbt, W2, b2, training: bool, momentum: float = 0.1,
                  eps: float = 1e-5):
     """z = W2 . relu(BatchNorm1d(y1)) + b2 (the `mlp` projector behind its first Linear, components.py:209-226).
-    -> (z [B,L], stat [2H] = mean, invstd).  Train mode updates the running statistics in place."""
+    -> (z [B,L], stat: [0:2H] = mean, invstd (the kernels' partial sums behind them)).  Train mode updates the running statistics."""
     B, H = y1.shape
     L = W2.shape[0]
     _chk(y1, "y1"); _chk(gamma, "gamma", (H,)); _chk(beta, "beta", (H,)); _chk(W2, "W2", (L, H)); _chk(b2, "b2", (L,), optional=True)
     _chk(running_mean, "running_mean", (H,), optional=True); _chk(running_var, "running_var", (H,), optional=True)
     _chk(nbt, "num_batches_tracked", (), dtype=torch.int64, optional=True)
     z = torch.empty(B, L, device=y1.device, dtype=torch.float32)
-    stat = torch.empty(2 * H, device=y1.device, dtype=torch.float32)
+    stat = torch.empty(mlp_head_ws_floats(B, H, L), device=y1.device, dtype=torch.float32)
     call("coskad_mlp_head_fwd_f32", ptr(y1), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
          ctypes.c_float(momentum), ctypes.c_float(eps), i32(1 if training else 0), ptr(W2), ptr(b2), ptr(z), ptr(stat),
          i32(B), i32(H), i32(L), _stream())
@@ -744,11 +750,13 @@ def mlp_head_bwd(y1, stat, gamma, beta, W2, dz, grads: dict, training: bool, acc
     """-> dy1 [B,H]; fills grads['gamma'], grads['beta'], grads['W2'] and (optional) grads['b2']."""
     B, H = y1.shape
     L = W2.shape[0]
-    _chk(y1, "y1"); _chk(stat, "stat", (2 * H,)); _chk(gamma, "gamma", (H,)); _chk(beta, "beta", (H,)); _chk(W2, "W2", (L, H))
+    _chk(y1, "y1"); _chk(stat, "stat"); _chk(gamma, "gamma", (H,)); _chk(beta, "beta", (H,)); _chk(W2, "W2", (L, H))
+    if stat.numel() < 2 * H:
+        raise ValueError("mlp_head_bwd: stat holds fewer than 2 H values")
     _chk(dz, "dz", (B, L)); _chk(grads["gamma"], "dgamma", (H,)); _chk(grads["beta"], "dbeta", (H,)); _chk(grads["W2"], "dW2", (L, H))
     _chk(grads.get("b2"), "db2", (L,), optional=True)
     dy1 = torch.empty_like(y1)
-    red = torch.empty(2 * H, device=y1.device, dtype=torch.float32)
+    red = torch.empty(mlp_head_ws_floats(B, H, L), device=y1.device, dtype=torch.float32)
     call("coskad_mlp_head_bwd_f32", ptr(y1), ptr(stat), ptr(gamma), ptr(beta), ptr(W2), ptr(dz), ptr(dy1), ptr(grads["gamma"]),
          ptr(grads["beta"]), ptr(grads["W2"]), ptr(grads.get("b2")), ptr(red), i32(1 if training else 0),
          i32(1 if accumulate else 0), i32(B), i32(H), i32(L), _stream())

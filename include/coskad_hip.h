@@ -214,9 +214,11 @@ int coskad_dropout_mask_f32(float* out, size_t n, float drop_p, unsigned long lo
  * kernels): z = W2 . relu(BatchNorm1d(y1)) + b2 on y1 [B, H]; H, L <= 64.
  * forward : training != 0 -> batch statistics (biased variance normalises, running_mean / running_var (unbiased) and
  *           num_batches_tracked are updated in place; they may be NULL), else the running statistics.
- *           stat [2H] receives (mean, 1/sqrt(var + eps)) for the backward.
- * backward: dy1 [B,H], dgamma, dbeta [H], dW2 [L,H], db2 [L] (may be NULL); red: [2H] floats of scratch;
- *           accumulate != 0 adds into the parameter gradients. */
+ *           stat [0:2H] receives (mean, 1/sqrt(var + eps)) for the backward; the buffer holds coskad_mlp_head_ws_floats(B,H,L)
+ *           floats (behind the 2H values: the per-block partial sums of the hidden, out <= 16 kernels).
+ * backward: dy1 [B,H], dgamma, dbeta [H], dW2 [L,H], db2 [L] (may be NULL); red: coskad_mlp_head_ws_floats(B,H,L) floats of
+ *           scratch; accumulate != 0 adds into the parameter gradients. */
+size_t coskad_mlp_head_ws_floats(int B, int H, int L);   /* floats of `stat` (forward) and of `red` (backward), 8-byte aligned */
 int coskad_mlp_head_fwd_f32(const float* y1, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, long long* num_batches_tracked, float momentum, float eps, int training,
                             const float* W2, const float* b2, float* z, float* stat, int B, int H, int L,

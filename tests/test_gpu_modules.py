@@ -410,6 +410,48 @@ def test_mlp_projector_hip_path_vs_oracle(hidden):
         np.testing.assert_allclose(new[k].cpu().numpy(), p.detach().numpy(), rtol=2e-3, atol=3e-4, err_msg=k)
 
 
+@pytest.mark.parametrize("B,H,L", [(203, 16, 16), (4099, 16, 16), (130, 12, 7), (64, 8, 8), (77, 24, 16)])
+def test_mlp_head_kernels_vs_torch(B, H, L):
+    """csrc/mlp_head.hip through the C ABI -- the 64-rows-per-block kernels of the hidden, out <= 16 shapes (several blocks, a ragged
+    last one, padded columns) and the general kernels (24 features) -- against torch's BatchNorm1d -> ReLU -> Linear: train-mode
+    forward, every gradient, the running statistics; eval-mode forward and input gradient."""
+    from coskad_amd import ops
+    g = torch.Generator().manual_seed(B + H)
+    y = torch.randn(B, H, generator=g) * 1.3 + 0.4
+    bn = torch.nn.BatchNorm1d(H)
+    lin = torch.nn.Linear(H, L)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(H, generator=g)); bn.bias.copy_(0.2 * torch.randn(H, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(H, generator=g)); bn.running_var.copy_(1 + 0.2 * torch.rand(H, generator=g))
+    probe = torch.randn(B, L, generator=g)
+    dev = lambda t: t.detach().clone().cuda().contiguous()
+    for training in (True, False):
+        bn.train(training)
+        rm, rv, nb = dev(bn.running_mean), dev(bn.running_var), bn.num_batches_tracked.detach().clone().cuda()
+        yr = y.clone().requires_grad_(True)
+        for p in list(bn.parameters()) + list(lin.parameters()):
+            p.grad = None
+        zr = lin(torch.relu(bn(yr)))
+        (zr * probe).sum().backward()
+        z, stat = ops.mlp_head_fwd(dev(y), dev(bn.weight), dev(bn.bias), rm, rv, nb, dev(lin.weight), dev(lin.bias), training,
+                                   momentum=bn.momentum, eps=bn.eps)
+        np.testing.assert_allclose(z.cpu().numpy(), zr.detach().numpy(), rtol=1e-4, atol=1e-4)
+        nanf = lambda *s_: torch.full(s_, float("nan"), device="cuda")
+        gr = {"gamma": nanf(H), "beta": nanf(H), "W2": nanf(L, H), "b2": nanf(L)}
+        dy = ops.mlp_head_bwd(dev(y), stat, dev(bn.weight), dev(bn.bias), dev(lin.weight), dev(probe), gr, training)
+        torch.cuda.synchronize()
+        scale = float(yr.grad.abs().max())
+        np.testing.assert_allclose(dy.cpu().numpy(), yr.grad.numpy(), rtol=1e-3, atol=1e-4 * scale + 1e-6)
+        for name, ref in (("gamma", bn.weight.grad), ("beta", bn.bias.grad), ("W2", lin.weight.grad), ("b2", lin.bias.grad)):
+            a, b = gr[name].cpu().numpy(), ref.numpy()
+            assert np.isfinite(a).all(), name
+            np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * np.abs(b).max() + 1e-6, err_msg=name)
+        if training:
+            np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=1e-4, atol=1e-6)
+            assert int(nb) == int(bn.num_batches_tracked)
+
+
 def _randomise_bn(m):
     with torch.no_grad():
         for mod in m.modules():
