@@ -151,12 +151,31 @@ __global__ __launch_bounds__(256) void k_gemm(Args a) {
 }
 
 // out[e] (+)= sum_c partials[c][e] (fp64, fixed order)
-__global__ void k_sum(const float* __restrict__ part, int chunks, size_t E, float* __restrict__ out, int accumulate) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)part[(size_t)c * E + e];
-  out[e] = accumulate ? out[e] + (float)s : (float)s;
+// block = 64 elements x 16 chunk slices, four loads in flight per thread, slices combined in a fixed order (one thread walking all
+// chunks of an element took 62 us for 256 chunks of a 32 x 64 weight gradient: 8 blocks of dependent loads)
+__global__ __launch_bounds__(1024) void k_sum(const float* __restrict__ part, int chunks, size_t E, float* __restrict__ out, int accumulate) {
+  __shared__ double sh[1024];
+  const size_t e = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < E) {
+    int c = slice;
+    for (; c + 48 < chunks; c += 64) {
+      s0 += (double)part[(size_t)c * E + e];
+      s1 += (double)part[(size_t)(c + 16) * E + e];
+      s2 += (double)part[(size_t)(c + 32) * E + e];
+      s3 += (double)part[(size_t)(c + 48) * E + e];
+    }
+    for (; c < chunks; c += 16) s0 += (double)part[(size_t)c * E + e];
+  }
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (slice == 0 && e < E) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+    out[e] = accumulate ? out[e] + (float)t : (float)t;
+  }
 }
 
 // g = dout * (out > 0);  dbias[c] (+)= sum over (n, p) of g[n][c][p]: block = one (channel, slice) pair -> partials
@@ -245,7 +264,7 @@ int coskad_gemm_f32(const float* A, const float* B, float* C, const float* bias,
 /* out[e] (+)= sum_c partials[c][e], e < E (fp64 accumulation, fixed order) */
 int coskad_gemm_sum_f32(const float* partials, int chunks, size_t E, float* out, int accumulate, hipStream_t stream) {
   if (!partials || !out || chunks <= 0 || E == 0) return fail(COSKAD_ERR_ARG, "gemm_sum: bad argument");
-  hipLaunchKernelGGL(gemm::k_sum, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, partials, chunks, E, out, accumulate);
+  hipLaunchKernelGGL(gemm::k_sum, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, stream, partials, chunks, E, out, accumulate);
   return check_launch("gemm_sum");
 }
 
