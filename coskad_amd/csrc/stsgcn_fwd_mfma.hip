@@ -264,11 +264,10 @@ extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* 
   if (!out_slope && Ci <= 4 && (T * V) % 4 == 0) return launch_first_apply(Z, in, out, wfold, bias, in_slope, B, Ci, Co, T * V, stream);
   // default geometry, 16 / 32 input channels, pre-activation output: the wave-per-clip K-ring GEMM (fused_apply.hip)
   if (!out_slope && layer_apply_ring_ok(T, V, Ci, Co)) return launch_layer_apply_ring(Z, in, out, wfold, bias, in_slope, B, Ci, Co, stream);
-  // <= 32 output channels: streaming GEMM over Z and `in`; wider: the LDS-tiled kernel with Z staged instead of mixed
-  // (needs the mixing tables only as a layout; A/Tm are not read when Z is given)
-#define CALL(T_, V_)                                                                                              \
-  return Co <= 32 ? launch_layer_apply_z<T_, V_>(Z, in, out, wfold, bias, in_slope, out_slope, B, Ci, Co, stream) \
-                  : launch_layer_apply_m<T_, V_>(in, out, A, Tm, wfold, bias, in_slope, out_slope, B, Ci, Co, stream, Z)
+  // the streaming GEMM over Z and `in` (nothing staged) for every width up to 64: at 64 output channels on the 25-joint layout it
+  // beats the LDS-tiled kernel with Z staged (258 -> ~235 us; encoder step 3.15 -> 3.13 ms)
+  (void)A; (void)Tm;
+#define CALL(T_, V_) return launch_layer_apply_z<T_, V_>(Z, in, out, wfold, bias, in_slope, out_slope, B, Ci, Co, stream)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }
