@@ -6,7 +6,6 @@ sees a pointer, enqueues on torch's current stream and never synchronises.
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import Optional
 
 import torch
@@ -605,7 +604,7 @@ def conv1x1(W: Tensor, x: Tensor, bias: Optional[Tensor] = None, out: Optional[T
     return out, parts
 
 
-WGRAD_BLOCKS = int(os.environ.get("COSKAD_WGRAD_BLOCKS", "256"))   # workgroups a weight-gradient launch aims for (one per CU; sweep 64..2048: wide step 19.7 / 18.0 / 18.2 / 18.7 / 19.5 ms at 64 / 256 / 512 / 1024 / 2048)
+WGRAD_BLOCKS = 256   # workgroups a weight-gradient launch aims for (one per CU; sweep 64..2048: wide step 19.7 / 18.0 / 18.2 / 18.7 / 19.5 ms at 64 / 256 / 512 / 1024 / 2048)
 
 
 def conv1x1_wgrad(G: Tensor, x: Tensor, out: Tensor, target_chunks: int = 64, accumulate: bool = False) -> Tensor:
