@@ -51,6 +51,31 @@ def test_stse_eval_and_train_step(golden, name):
             np.testing.assert_allclose(m.state_dict()[k[4:]].cpu().numpy(), v, rtol=1e-4, atol=1e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("below,nxt", [(False, True), (True, False), (False, False)])
+def test_stse_train_step_without_the_fusions(golden, below, nxt):
+    """The same reference gradients with the cross-layer fusions switched off one at a time (engine.FUSE_BELOW: backward chain,
+    engine.FUSE_NEXT: apply + next-layer statistics): the per-layer statistics kernels stay covered."""
+    from coskad_amd import engine
+    g = golden("stse_default.npz")
+    m, st = build_stse(g)
+    x = torch.from_numpy(g["x"]).cuda()
+    c = torch.from_numpy(g["c"]).cuda()
+    old = engine.FUSE_BELOW, engine.FUSE_NEXT
+    engine.FUSE_BELOW, engine.FUSE_NEXT = below, nxt
+    try:
+        m.train()
+        z = m(x)
+        ((z - c) ** 2).mean().backward()
+        torch.cuda.synchronize()
+    finally:
+        engine.FUSE_BELOW, engine.FUSE_NEXT = old
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["train.z"], rtol=1e-4, atol=1e-4)
+    gmax = max(np.abs(g["grad." + n]).max() for n, _ in m.named_parameters())
+    for n, p in m.named_parameters():
+        ref = g["grad." + n]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max() + 2e-5 * gmax, err_msg=n)
+
+
 def test_legacy_keywords(golden):
     from coskad_amd.models.sts.ae import STSE
     m = STSE(c_in=2, h_dim=64, latent_dim=16, n_frames=12, dropout=0.0, n_joints=17, channels=[32, 16, 32],
