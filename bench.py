@@ -415,7 +415,7 @@ def main():
         if fwd_n:
             byts = B * tvb * (ci + co)        # layer 4 forward: read 32 channels, write 64
             ach = byts / (fwd_ms * 1e-3) / 1e9
-            roof_fwd = {"bound": "hbm", "kernel": "k_layer_apply_ring<2,4,1> (layer 4 training forward from the stored Z, 32 -> 64 channels)",
+            roof_fwd = {"bound": "hbm", "kernel": "k_layer_apply_bpc<2> (layer 4 training forward from the stored Z, 32 -> 64 channels: one clip per workgroup)",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": byts,
                         "traffic": (traffic.get("layer_apply layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),

@@ -248,6 +248,9 @@ namespace coskad {
 bool layer_apply_ring_ok(int T_, int V_, int Ci, int Co);
 int launch_layer_apply_ring(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
                             const float* in_slope, int B, int Ci, int Co, hipStream_t st);
+// fused_apply_bpc.hip
+int launch_layer_apply_bpc(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
+                           const float* in_slope, int B, int Ci, int Co, hipStream_t st);
 // first_layer.hip
 int launch_first_apply(const float* Z, const float* in, float* out, const float* wfold, const float* bias, const float* in_slope,
                        int B, int Ci, int Co, int TVr, hipStream_t st);
@@ -263,6 +266,10 @@ extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* 
   // a handful of input channels (the first layer): plain FMAs on full-line stores (first_layer.hip)
   if (!out_slope && Ci <= 4 && (T * V) % 4 == 0) return launch_first_apply(Z, in, out, wfold, bias, in_slope, B, Ci, Co, T * V, stream);
   // default geometry, 16 / 32 input channels, pre-activation output: the wave-per-clip K-ring GEMM (fused_apply.hip)
+  // default geometry, 32 -> 64 channels, pre-activation output: one clip per WORKGROUP, four waves sharing its K window
+  // (fused_apply_bpc.hip: three waves per SIMD instead of one)
+  if (!out_slope && T == 12 && V == 17 && Ci == 32 && Co == 64)
+    return launch_layer_apply_bpc(Z, in, out, wfold, bias, in_slope, B, Ci, Co, stream);
   if (!out_slope && layer_apply_ring_ok(T, V, Ci, Co)) return launch_layer_apply_ring(Z, in, out, wfold, bias, in_slope, B, Ci, Co, stream);
   // the streaming GEMM over Z and `in` (nothing staged) for every width up to 64: at 64 output channels on the 25-joint layout it
   // beats the LDS-tiled kernel with Z staged (258 -> ~235 us; encoder step 3.15 -> 3.13 ms)
