@@ -189,7 +189,7 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
             stat = None
         pending = None
         if fuse[i]:
-            rows_max = min((B + 3) // 4, 256)
+            rows_max = ops.layer_apply_next_rows(B, h.shape[1], L.Co)
             partials = torch.empty(rows_max * 2 * (L.Co * L.Co + L.Co), device=x.device, dtype=torch.float32)
             u, Zn, rows = ops.layer_apply_next(Z, h, wfold, bias, L.Co, slope, L.slope, ftab[i + 1], partials, T, V)
             pending = (Zn, partials, rows)

@@ -228,6 +228,13 @@ def layer_apply_next_ok(Ci: int, Co: int, T: int, V: int) -> bool:
     return bool(fn(i32(Ci), i32(Co), i32(T), i32(V)))
 
 
+def layer_apply_next_rows(B: int, Ci: int, Co: int) -> int:
+    """Partial rows layer_apply_next writes for a batch of B clips (each 2 (Co^2 + Co) floats)."""
+    fn = _lib.lib().coskad_layer_apply_next_rows
+    fn.restype = ctypes.c_int
+    return fn(i32(B), i32(Ci), i32(Co))
+
+
 def ftab_floats() -> int:
     fn = _lib.lib().coskad_ftab_floats
     fn.restype = ctypes.c_int
@@ -260,9 +267,7 @@ def layer_apply_next(Z, x, wfold, bias, Co, in_slope, out_slope, ftab_next, part
     if Z_next is None:
         Z_next = torch.empty(B, Co, T, V, device=x.device, dtype=torch.float32)
     _chk(out, "out", (B, Co, T, V)); _chk(Z_next, "Z_next", (B, Co, T, V))
-    fn = _lib.lib().coskad_layer_apply_next_rows
-    fn.restype = ctypes.c_int
-    rows = fn(i32(B))
+    rows = layer_apply_next_rows(B, Ci, Co)
     call("coskad_layer_apply_next_f32", ptr(Z), ptr(x), ptr(out), ptr(wfold), ptr(bias), ptr(in_slope), ptr(out_slope),
          ptr(ftab_next), ptr(Z_next), ptr(partials), ctypes.c_size_t(_bytes(partials)), i32(B), i32(Ci), i32(Co), i32(T), i32(V),
          _stream(), tag=(Ci, Co))

@@ -119,12 +119,12 @@ int coskad_layer_apply_z_f32(const float* Z, const float* in, float* out, const 
  * layer i+1 (coskad_layer_train_stats_z_f32's first kernel) and its re-read of U_i disappear.
  *   coskad_build_ftab_f32       : forward mixing tables (coskad_ftab_floats() floats each) of n <= 4 layers from their A / T
  *                                 (host arrays of n device pointers), one launch
- *   coskad_layer_apply_next_f32 : out = U_i [B,Co,T,V]; Z_next [B,Co,T,V]; partials [coskad_layer_apply_next_rows(B)][2 (Co^2 + Co)]
+ *   coskad_layer_apply_next_f32 : out = U_i [B,Co,T,V]; Z_next [B,Co,T,V]; partials [coskad_layer_apply_next_rows(B, Ci, Co)][2 (Co^2 + Co)]
  *   coskad_layer_train_fold_f32 : the rest of coskad_layer_train_stats_f32 for layer i+1 (fp64 sums of the partial rows, statistics,
  *                                 folded weights, stat block, running-stat update); ws >= coskad_train_stats_ws_bytes(Ci). */
 int coskad_layer_apply_next_ok(int Ci, int Co, int T, int V);
 int coskad_ftab_floats(void);
-int coskad_layer_apply_next_rows(int B);
+int coskad_layer_apply_next_rows(int B, int Ci, int Co);
 int coskad_build_ftab_f32(const float* const* A, const float* const* Tm, float* const* tab, int n, int T, int V,
                           hipStream_t stream);
 int coskad_layer_apply_next_f32(const float* Z, const float* in, float* out, const float* wfold, const float* bias,

@@ -213,7 +213,7 @@ def test_apply_next_vs_separate_kernels(Ci, Co, Cn, B):
     n, guard = B * Co * T * V, 4096
     bufU = torch.full((n + 2 * guard,), 12345.0, device="cuda")
     bufZ = torch.full((n + 2 * guard,), 12345.0, device="cuda")
-    rows_max = min((B + 3) // 4, 256)
+    rows_max = ops.layer_apply_next_rows(B, Ci, Co)
     E = 2 * (Co * Co + Co)
     bufP = torch.full((rows_max * E + 2 * guard,), 12345.0, device="cuda")
     U, Z2, partials = bufU[guard:guard + n].view(B, Co, T, V), bufZ[guard:guard + n].view(B, Co, T, V), bufP[guard:guard + rows_max * E]

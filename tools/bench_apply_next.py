@@ -17,7 +17,7 @@ for Ci, Co in ((2, 32), (32, 16), (16, 32)):
     ftab = torch.empty(ops.ftab_floats(), device="cuda")
     ops.build_ftabs([A], [Tm], [ftab])
     out = torch.empty(B, Co, T, V, device="cuda"); zn = torch.empty(B, Co, T, V, device="cuda")
-    part = torch.empty(256 * 2 * (Co * Co + Co), device="cuda")
+    part = torch.empty(ops.layer_apply_next_rows(B, Ci, Co) * 2 * (Co * Co + Co), device="cuda")
     f = lambda: ops.layer_apply_next(Z, x, wfold, bias, Co, sl if Ci > 2 else None, sl, ftab, part, T, V, out=out, Z_next=zn)
     for _ in range(3): f()
     torch.cuda.synchronize()
