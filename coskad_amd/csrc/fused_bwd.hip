@@ -519,8 +519,9 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_fused(const float* __restr
         }
         buf_store4(ores, l16, 64 * i * 16, float4{g[0], g[1], g[2], g[3]});    // beyond the clip: dropped (bounds check)
         if constexpr (NS != 0) {                         // the image keeps dU_prev for the reductions below
+          // (masked lanes: BOTH halves to the padding columns -- p + 2 there is row 1's first two positions)
           *reinterpret_cast<float2*>(p) = float2{g[0], g[1]};
-          *reinterpret_cast<float2*>(p + 2) = float2{g[2], g[3]};
+          *reinterpret_cast<float2*>(e4 < N4 ? p + 2 : p) = float2{g[2], g[3]};
         }
         xs[i] = buf_load4(xn, l16, 64 * i * 16);
       }
@@ -818,11 +819,18 @@ int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, c
   return check_launch("bwd_reduce_fused");
 }
 
+int bwd_bpc_rows(int B);   // fused_bwd_bpc.hip
+bool bwd_bpc_on(int Ci, int Co) {
+  static const bool on = [] { const char* e = getenv("COSKAD_BWD_BPC"); return e && e[0] == '1'; }();   // EXPERIMENT
+  return on && ((Ci == 32 && Co == 16) || (Ci == 16 && Co == 32) || (Ci == 32 && Co == 64));
+}
+
 // rows of [2 Ci below_Ci + Ci] floats the data kernel of a (Ci -> Co) layer writes for the layer below it (0: it cannot)
 int layer_bwd_below_rows(int T_, int V_, int B, int Ci, int Co, int below_Ci) {
   const bool built = (Ci == 32 && Co == 16 && below_Ci == 2) || (Ci == 16 && Co == 32 && below_Ci == 32) ||
                      (Ci == 32 && Co == 64 && below_Ci == 16);
   if (!(T_ == ff::T && V_ == ff::V && built) || B <= 0) return 0;
+  if (bwd_bpc_on(Ci, Co)) return bwd_bpc_rows(B);
   const int nblk = (B + 3) / 4;
   return nblk < FB_GRID ? nblk : FB_GRID;
 }

@@ -1204,6 +1204,11 @@ int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, co
                            float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out, const float* below_z,
                            const float* below_x, const float* below_slope, int below_Ci, float* below_stats);
 int layer_bwd_below_rows(int T_, int V_, int B, int Ci, int Co, int below_Ci);
+// fused_bwd_bpc.hip: the same work, one clip per workgroup
+int launch_layer_bwd_bpc(const float* in, const float* Zg, const float* dU, const float* coef, const float* in_slope, float* dIn,
+                         float* btab, float* partials, float* dap, int B, int Ci, int Co, hipStream_t st, int* rows_out,
+                         const float* below_z, const float* below_x, const float* below_slope, int below_Ci, float* below_stats);
+bool bwd_bpc_on(int Ci, int Co);
 constexpr size_t kXscrFloats = (size_t)kMaxGridBwd * 13 * 2 * 256;   // fused_bwd.hip: one tile-major dXres slab per wave
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
 // fused_stats.hip
@@ -1450,8 +1455,12 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   if (fused) {
     int rows = 0;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
-    if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows,
-                                     below_z, below_in, below_slope, below_Ci, below_stats)))
+    if (bwd_bpc_on(Ci, Co)) {
+      if ((rc = launch_layer_bwd_bpc(in, Zg, dU, w.coef, in_slope, dIn, w.btab, w.partials, dap, B, Ci, Co, st, &rows, below_z, below_in,
+                                     below_slope, below_Ci, below_stats)))
+        return rc;
+    } else if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows,
+                                            below_z, below_in, below_slope, below_Ci, below_stats)))
       return rc;
     const int bE = 2 * Ci * below_Ci + Ci;
     return launch_reduce_fused(w.partials, rows, dA, dT, dap, dslope_in, accumulate, st, below_stats, bE,
