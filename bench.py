@@ -390,7 +390,7 @@ def main():
             ach = layer_bytes / (lbw_ms.value * 1e-3) / 1e9
             roof = {"bound": "hbm",
                     "what": "layer 4 backward (64 -> 32 channels), ALL its kernels (batch reductions k_bwd_reduce_z, fp64 folds, "
-                            "k_layer_bwd_fused<2,4> = data path + dA / dT, partial-row sums) against the layer's algorithmic bytes"
+                            "k_layer_bwd_bpc<2,4,..> = data path + dA / dT, partial-row sums) against the layer's algorithmic bytes"
                             + (f"; the data kernel also forms layer 3's batch reductions (backward chain): + {below_bytes} bytes "
                                "(layer 3's stored Z and input) in algorithmic_bytes_per_launch, its time in avg_launch_us" if chained else ""),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -406,7 +406,7 @@ def main():
                 if chained:
                     flops += B * 2 * T * V * 2 * ci * cb          # P and Q of the layer below: C_in x C_in(below) each
                 tf = flops / (dom_ms * 1e-3) / 1e12
-                roof["kernel_only"] = {"kernel": "k_layer_bwd_fused<2,4>", "note": "the layer's bytes charged to its dominant kernel alone",
+                roof["kernel_only"] = {"kernel": "k_layer_bwd_bpc<2,4,2,1>", "note": "the layer's bytes charged to its dominant kernel alone",
                                        "achieved": round(ach1, 1), "frac": round(ach1 / HBM_PEAK_GBS, 4),
                                        "avg_launch_us": round(dom_ms * 1e3, 2), "launches": dom_n,
                                        "traffic": (traffic.get("bwd_fused layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),

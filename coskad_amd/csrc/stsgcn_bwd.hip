@@ -27,7 +27,7 @@
 
 namespace coskad {
 
-constexpr int kMaxGridBwd = 1024;  // partial rows: up to three 512-thread blocks per CU, or 4 waves x 256 blocks of the fused kernel
+constexpr int kMaxGridBwd = 1024;  // partial rows: up to three 512-thread blocks per CU, or the 768 workgroups of the fused kernel
 constexpr int kBtabFloats = (2 * 17 * 64 + 12 * 3 * 64) * 4;   // operand streams of fused_bwd.hip (T = 12, V = 17)
 
 // ---------------------------------------------------------------------------------------
@@ -1194,22 +1194,14 @@ struct BwdWs {
   float* coef;
   float* dap;
   float* btab;
-  float* xscr;
   float* dz;
 };
 
 // fused_bwd.hip
-int launch_layer_bwd_fused(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw,
-                           const float* coef, const float* in_slope, float* dIn, float* btab, float* partials, float* dap,
-                           float* xscr, int B, int Ci, int Co, hipStream_t st, int* rows_out, const float* below_z,
-                           const float* below_x, const float* below_slope, int below_Ci, float* below_stats);
 int layer_bwd_below_rows(int T_, int V_, int B, int Ci, int Co, int below_Ci);
-// fused_bwd_bpc.hip: the same work, one clip per workgroup
 int launch_layer_bwd_bpc(const float* in, const float* Zg, const float* dU, const float* coef, const float* in_slope, float* dIn,
                          float* btab, float* partials, float* dap, int B, int Ci, int Co, hipStream_t st, int* rows_out,
                          const float* below_z, const float* below_x, const float* below_slope, int below_Ci, float* below_stats);
-bool bwd_bpc_on(int Ci, int Co);
-constexpr size_t kXscrFloats = (size_t)kMaxGridBwd * 13 * 2 * 256;   // fused_bwd.hip: one tile-major dXres slab per wave
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
 // fused_stats.hip
 bool bwd_stats_ring_ok(int T_, int V_, int Ci, int Co);
@@ -1226,7 +1218,7 @@ int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, c
                         hipStream_t st, const float* brows, int bE, double* bout);
 // chain buffer of a layer's stage-1 sums: [rows][E] partial rows, then (8-byte aligned) their E fp64 sums
 static inline size_t chain_sums_offset(int rows, int E) { return ((size_t)rows * E + 1) / 2 * 2; }
-constexpr size_t kFusedRowFloats = 37 * 256;   // lane-major partial row of fused_bwd.hip
+constexpr size_t kFusedRowFloats = 32 * 256;   // lane-major partial row of fused_bwd.hip (fb::EROW)
 
 static size_t bwd_emax(int Ci, int Co, int T, int V) {
   const size_t e1 = 2 * (size_t)Co * Ci + Co;
@@ -1240,7 +1232,7 @@ size_t layer_bwd_ws_bytes(int B, int Ci, int Co, int T, int V) {
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   return al(kMaxGridBwd * E * sizeof(float)) + al(E * sizeof(double)) +
          al(coef_floats(Ci, Co) * sizeof(float)) + al((size_t)((B > kMaxGridBwd ? B : kMaxGridBwd) + 1) * sizeof(float)) +
-         al((size_t)kBtabFloats * sizeof(float)) + al(kXscrFloats * sizeof(float)) + al((size_t)B * Ci * T * V * sizeof(float));
+         al((size_t)kBtabFloats * sizeof(float)) + al((size_t)B * Ci * T * V * sizeof(float));
 }
 
 static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
@@ -1253,7 +1245,6 @@ static BwdWs carve(void* ws, int B, int Ci, int Co, int T, int V) {
   w.coef = reinterpret_cast<float*>(p);     p += al(coef_floats(Ci, Co) * sizeof(float));
   w.dap = reinterpret_cast<float*>(p);      p += al((size_t)((B > kMaxGridBwd ? B : kMaxGridBwd) + 1) * sizeof(float));
   w.btab = reinterpret_cast<float*>(p);     p += al((size_t)kBtabFloats * sizeof(float));
-  w.xscr = reinterpret_cast<float*>(p);     p += al(kXscrFloats * sizeof(float));
   w.dz = reinterpret_cast<float*>(p);
   return w;
 }
@@ -1455,12 +1446,8 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   if (fused) {
     int rows = 0;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
-    if (bwd_bpc_on(Ci, Co)) {
-      if ((rc = launch_layer_bwd_bpc(in, Zg, dU, w.coef, in_slope, dIn, w.btab, w.partials, dap, B, Ci, Co, st, &rows, below_z, below_in,
-                                     below_slope, below_Ci, below_stats)))
-        return rc;
-    } else if ((rc = launch_layer_bwd_fused(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.btab, w.partials, dap, w.xscr, B, Ci, Co, st, &rows,
-                                            below_z, below_in, below_slope, below_Ci, below_stats)))
+    if ((rc = launch_layer_bwd_bpc(in, Zg, dU, w.coef, in_slope, dIn, w.btab, w.partials, dap, B, Ci, Co, st, &rows, below_z, below_in,
+                                   below_slope, below_Ci, below_stats)))
       return rc;
     const int bE = 2 * Ci * below_Ci + Ci;
     return launch_reduce_fused(w.partials, rows, dA, dT, dap, dslope_in, accumulate, st, below_stats, bE,

@@ -149,9 +149,9 @@ def test_first_layer_backward_stored_z_vs_oracle(Ci, Co, V, B):
         np.testing.assert_allclose(a, b, rtol=5e-4, atol=5e-5 * max(np.abs(b).max(), 1e-9) + 2e-5 * gmax, err_msg=k)
 
 
-@pytest.mark.parametrize("Ci,Co,B", [(32, 64, 1031), (16, 32, 2053), (32, 16, 1026)])
+@pytest.mark.parametrize("Ci,Co,B", [(32, 64, 1031), (16, 32, 2053), (32, 16, 1026), (16, 16, 771), (16, 64, 1537), (32, 32, 800)])
 def test_fused_backward_ragged_batch_vs_split_kernels(Ci, Co, B):
-    """Stored-Z path (csrc/fused_bwd.hip: one clip per wavefront, several clips per wave, ragged last round) against the
+    """Stored-Z path (csrc/fused_bwd_bpc.hip: one clip per workgroup, several clips per workgroup, ragged last round) against the
     recompute path of the same library (k_bwd_reduce / k_bwd_data / k_bwd_gcn_params: block-per-tile kernels, no stored Z):
     two independent implementations of stsgcn.py:94-116's autograd.  dIn sits inside a guarded buffer: the fused kernel
     addresses clips through bounds-checked buffer descriptors and must not write a byte outside the tensor."""

@@ -129,8 +129,8 @@ def main(tag: str) -> None:
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, B=4096); "
                    "counters are KB; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE reads "
                    "1/2 of a wide coalesced stream; narrower accesses uncalibrated: upper bound)"}
-    for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2,1>"), ("bwd_fused layer4", "k_layer_bwd_fused<2,4"),
-                          ("bwd_fused layer3", "k_layer_bwd_fused<1,2"), ("bwd_fused layer2", "k_layer_bwd_fused<2,1"),
+    for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2,1>"), ("bwd_fused layer4", "k_layer_bwd_bpc<2,4"),
+                          ("bwd_fused layer3", "k_layer_bwd_bpc<1,2"), ("bwd_fused layer2", "k_layer_bwd_bpc<2,1"),
                           ("layer_apply layer4", "k_layer_apply_bpc<2>"), ("fused_encoder", "k_fused_encoder"),
                           ("bwd_stats layer4", "k_bwd_reduce_z<12,17,4,2>"), ("apply_next layer1", "k_layer_apply_next_bpc<0,2>"),
                           ("apply_next layer2", "k_layer_apply_next_bpc<2,1>"), ("apply_next layer3", "k_layer_apply_next_bpc<1,2>")):
