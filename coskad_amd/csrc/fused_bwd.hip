@@ -41,25 +41,45 @@ constexpr int PR_A = 0, PR_XA = 12, PR_XB = 13, PR_C = 14, PR_T = 15, PR_N = 32,
 // dA, dT (+)= sum over the P lane-major partial rows (fp64, fixed order); one extra block sums the slope partials; blocks beyond
 // that one sum the partial rows the data kernel wrote for the layer below (backward chain: brows [bP][bE] -> bout [bE], the
 // k_reduce_partials_d of that layer's call riding in this launch)
+constexpr int RE = 32;   // columns per block of k_reduce_fused: 1024 / RE row slices (256 + 66 blocks at the default stack's widths)
+// column `e` of P rows `stride` floats apart: this thread's slice in fp64, eight loads in flight, then the slices in a fixed order
+__device__ __forceinline__ double column_sum(const float* __restrict__ rows, int P, size_t stride, int e, bool ok, double* sh) {
+  constexpr int NSL = 1024 / RE;
+  const int slice = threadIdx.x / RE;
+  double s = 0.0;
+  if (ok) {
+    const float* base = rows + e;
+    int p = slice;
+    for (; p + 7 * NSL < P; p += 8 * NSL) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(p + u * NSL) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; p < P; p += NSL) s += (double)base[(size_t)p * stride];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  double t = 0.0;
+  if (slice == 0) {
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) t += sh[threadIdx.x + RE * k];
+  }
+  return t;
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__ partials, int P, float* __restrict__ dA,
                                                        float* __restrict__ dT, const float* __restrict__ dap, int ndap,
                                                        float* __restrict__ dslope, int accumulate, const float* __restrict__ brows,
                                                        int bP, int bE, double* __restrict__ bout) {
   __shared__ double sh[1024];
-  constexpr int NB = EROW / 64;
+  constexpr int NB = EROW / RE;
+  const int col = threadIdx.x % RE;
   if ((int)blockIdx.x > NB) {
-    const int e = ((int)blockIdx.x - NB - 1) * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    double s = 0.0;
-    if (e < bE)
-      for (int p = slice; p < bP; p += 16) s += (double)brows[(size_t)p * bE + e];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (slice == 0 && e < bE) {
-      double t = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
-      bout[e] = t;
-    }
+    const int e = ((int)blockIdx.x - NB - 1) * RE + col;
+    const double t = column_sum(brows, bP, (size_t)bE, e, e < bE, sh);
+    if ((int)threadIdx.x < RE && e < bE) bout[e] = t;
     return;
   }
   if ((int)blockIdx.x == NB) {
@@ -75,15 +95,9 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
     if (threadIdx.x == 0) dslope[0] = accumulate ? dslope[0] + (float)sh[0] : (float)sh[0];
     return;
   }
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-  double s = 0.0;
-  for (int p = slice; p < P; p += 16) s += (double)partials[(size_t)p * EROW + e];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  if (slice == 0) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+  const int e = blockIdx.x * RE + col;
+  const double t = column_sum(partials, P, (size_t)EROW, e, true, sh);
+  if ((int)threadIdx.x < RE) {
     const int rec = e >> 8, l = (e >> 2) & 63, r = e & 3, j = l & 15, q = l >> 4;
     float* out = nullptr;
     if (rec < PR_XA) out = dA + rec * V * V + (4 * q + r) * V + j;
@@ -623,8 +637,8 @@ int launch_layer_bwd_bpc(const float* in, const float* Zg, const float* dU, cons
 
 int launch_reduce_fused(const float* partials, int rows, float* dA, float* dT, const float* dap, float* dslope, int accumulate,
                         hipStream_t st, const float* brows, int bE, double* bout) {
-  const int extra = brows ? 1 + ceil_div(bE, 64) : (dap ? 1 : 0);
-  hipLaunchKernelGGL(fb::k_reduce_fused, dim3(fb::EROW / 64 + extra), dim3(1024), 0, st, partials, rows, dA, dT, dap, rows,
+  const int extra = brows ? 1 + ceil_div(bE, fb::RE) : (dap ? 1 : 0);
+  hipLaunchKernelGGL(fb::k_reduce_fused, dim3(fb::EROW / fb::RE + extra), dim3(1024), 0, st, partials, rows, dA, dT, dap, rows,
                      dslope, accumulate, brows, rows, bE, bout);
   return check_launch("bwd_reduce_fused");
 }

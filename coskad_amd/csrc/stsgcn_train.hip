@@ -68,28 +68,32 @@ __global__ __launch_bounds__((Geo<T, V>::Block), (Geo<T, V>::Block <= 512 && NTC
 
 // out[e] = sum_p partials[p][e] in fp64 (fixed order).  block = 64 elements x 16 partial-slices, 4 loads in
 // flight per thread: the table is tiny (<= 512 x E floats) and the kernel is latency-bound.
+constexpr int kRedCols = 16;   // columns per block: 64 row slices, a thread's <= 16 rows all in flight (132 blocks at E = 2112)
 __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int P, int E,
                                                            double* __restrict__ out) {
   __shared__ double sh[1024];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int slice = threadIdx.x >> 6;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  constexpr int NSL = 1024 / kRedCols;
+  const int e = blockIdx.x * kRedCols + (threadIdx.x % kRedCols);
+  const int slice = threadIdx.x / kRedCols;
+  double s = 0.0;
   if (e < E) {
+    const float* base = partials + e;
     int p = slice;
-    for (; p + 48 < P; p += 64) {
-      s0 += (double)partials[(size_t)p * E + e];
-      s1 += (double)partials[(size_t)(p + 16) * E + e];
-      s2 += (double)partials[(size_t)(p + 32) * E + e];
-      s3 += (double)partials[(size_t)(p + 48) * E + e];
+    for (; p + 7 * NSL < P; p += 8 * NSL) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(p + u * NSL) * E];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
     }
-    for (; p < P; p += 16) s0 += (double)partials[(size_t)p * E + e];
+    for (; p < P; p += NSL) s += (double)base[(size_t)p * E];
   }
-  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  sh[threadIdx.x] = s;
   __syncthreads();
   if (slice == 0 && e < E) {
     double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+#pragma unroll 8
+    for (int k = 0; k < NSL; ++k) t += sh[threadIdx.x + kRedCols * k];
     out[e] = t;
   }
 }
@@ -300,7 +304,7 @@ static int launch_reduce_fold(const float* partials, int rows, double* red, doub
   const int E = 2 * (Ci * Ci + Ci);
   int rc = 0;
   if (partials) {                                        // (NULL: `red` holds the sums already -- SyncBN, summed over the ranks)
-    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, 64)), dim3(1024), 0, st, partials, rows, E, red);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, partials, rows, E, red);
     if ((rc = check_launch("reduce_partials"))) return rc;
   }
   if (!Wt) return 0;                                     // sums only
