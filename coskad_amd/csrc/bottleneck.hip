@@ -264,7 +264,15 @@ __global__ __launch_bounds__(256) void k_btlnk_reduce(const float* __restrict__ 
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
     double s = 0.0;
-    for (int p = 0; p < P; ++p) s += (double)partials[(size_t)p * E + e];
+    int p = 0;
+    for (; p + 8 <= P; p += 8) {                     // eight rows in flight, summed in row order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(p + u) * E + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; p < P; ++p) s += (double)partials[(size_t)p * E + e];
     out[e] = accumulate ? out[e] + (float)s : (float)s;
     return;
   }

@@ -81,6 +81,38 @@ __device__ __forceinline__ void lds_barrier() {
 // wave-uniform value -> SGPR (lets hipcc use s_load for everything indexed by it)
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// Column `e` of P partial rows `stride` floats apart, summed in fp64 in a fixed order by a 1024-thread block of COLS columns:
+// 1024 / COLS row slices, eight loads of a slice in flight, then the slices one after another.  The sum is returned to the
+// threads of slice 0 (threadIdx.x < COLS); `sh`: 1024 doubles.  Partial-row sums are latency kernels: their time is the number
+// of dependent load rounds, so many small blocks beat few wide ones (64 columns x 16 slices: 16 us for 768 rows of 32 KB, this
+// at 32 columns: 8 us).
+template <int COLS>
+__device__ __forceinline__ double column_sum_f64(const float* __restrict__ rows, int P, size_t stride, int e, bool ok, double* sh) {
+  constexpr int NSL = 1024 / COLS;
+  const int slice = threadIdx.x / COLS;
+  double s = 0.0;
+  if (ok) {
+    const float* base = rows + e;
+    int p = slice;
+    for (; p + 7 * NSL < P; p += 8 * NSL) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(p + u * NSL) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; p < P; p += NSL) s += (double)base[(size_t)p * stride];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  double t = 0.0;
+  if (slice == 0) {
+#pragma unroll 8
+    for (int k = 0; k < NSL; ++k) t += sh[threadIdx.x + COLS * k];
+  }
+  return t;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -42,33 +42,6 @@ constexpr int PR_A = 0, PR_XA = 12, PR_XB = 13, PR_C = 14, PR_T = 15, PR_N = 32,
 // that one sum the partial rows the data kernel wrote for the layer below (backward chain: brows [bP][bE] -> bout [bE], the
 // k_reduce_partials_d of that layer's call riding in this launch)
 constexpr int RE = 32;   // columns per block of k_reduce_fused: 1024 / RE row slices (256 + 66 blocks at the default stack's widths)
-// column `e` of P rows `stride` floats apart: this thread's slice in fp64, eight loads in flight, then the slices in a fixed order
-__device__ __forceinline__ double column_sum(const float* __restrict__ rows, int P, size_t stride, int e, bool ok, double* sh) {
-  constexpr int NSL = 1024 / RE;
-  const int slice = threadIdx.x / RE;
-  double s = 0.0;
-  if (ok) {
-    const float* base = rows + e;
-    int p = slice;
-    for (; p + 7 * NSL < P; p += 8 * NSL) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(p + u * NSL) * stride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (double)v[u];
-    }
-    for (; p < P; p += NSL) s += (double)base[(size_t)p * stride];
-  }
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  double t = 0.0;
-  if (slice == 0) {
-#pragma unroll
-    for (int k = 0; k < NSL; ++k) t += sh[threadIdx.x + RE * k];
-  }
-  return t;
-}
-
 __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__ partials, int P, float* __restrict__ dA,
                                                        float* __restrict__ dT, const float* __restrict__ dap, int ndap,
                                                        float* __restrict__ dslope, int accumulate, const float* __restrict__ brows,
@@ -78,7 +51,7 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
   const int col = threadIdx.x % RE;
   if ((int)blockIdx.x > NB) {
     const int e = ((int)blockIdx.x - NB - 1) * RE + col;
-    const double t = column_sum(brows, bP, (size_t)bE, e, e < bE, sh);
+    const double t = column_sum_f64<RE>(brows, bP, (size_t)bE, e, e < bE, sh);
     if ((int)threadIdx.x < RE && e < bE) bout[e] = t;
     return;
   }
@@ -96,7 +69,7 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
     return;
   }
   const int e = blockIdx.x * RE + col;
-  const double t = column_sum(partials, P, (size_t)EROW, e, true, sh);
+  const double t = column_sum_f64<RE>(partials, P, (size_t)EROW, e, true, sh);
   if ((int)threadIdx.x < RE) {
     const int rec = e >> 8, l = (e >> 2) & 63, r = e & 3, j = l & 15, q = l >> 4;
     float* out = nullptr;

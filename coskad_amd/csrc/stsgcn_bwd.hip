@@ -250,30 +250,13 @@ __global__ __launch_bounds__((Geo<T, V>::Block), (Geo<T, V>::Block <= 512 && NTO
   store_rowsums<NTO>(srow, scratch, dst + 2 * Co * Ci, Co);
 }
 
+constexpr int kRedCols = 16;   // columns per block of the partial-row sums (common.h: column_sum_f64)
 __global__ __launch_bounds__(1024) void k_reduce_partials_d(const float* __restrict__ partials, int P, int E,
                                                              double* __restrict__ out) {
   __shared__ double sh[1024];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int slice = threadIdx.x >> 6;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (e < E) {
-    int p = slice;
-    for (; p + 48 < P; p += 64) {
-      s0 += (double)partials[(size_t)p * E + e];
-      s1 += (double)partials[(size_t)(p + 16) * E + e];
-      s2 += (double)partials[(size_t)(p + 32) * E + e];
-      s3 += (double)partials[(size_t)(p + 48) * E + e];
-    }
-    for (; p < P; p += 16) s0 += (double)partials[(size_t)p * E + e];
-  }
-  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (slice == 0 && e < E) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
-    out[e] = t;
-  }
+  const int e = blockIdx.x * kRedCols + (threadIdx.x % kRedCols);
+  const double t = column_sum_f64<kRedCols>(partials, P, (size_t)E, e, e < E, sh);
+  if ((int)threadIdx.x < kRedCols && e < E) out[e] = t;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1134,14 +1117,15 @@ __global__ __launch_bounds__(256) void k_sum_to(const float* __restrict__ v, int
 }
 
 // dA, dT (and optionally the producer's slope gradient) from the block partials in ONE launch:
-// blocks [0, ceil(E/64)) reduce 64 elements x 16 partial-slices of [dA | dT]; one extra block sums `dap` (<= 1024).
+// blocks [0, ceil(E / kGcnCols)) sum kGcnCols columns x 32 row slices of [dA | dT] (common.h: column_sum_f64); one extra block sums `dap`.
+constexpr int kGcnCols = 32;
 __global__ __launch_bounds__(1024) void k_reduce_gcn(const float* __restrict__ partials, int P, int nA, int nT,
                                                       float* __restrict__ dA, float* __restrict__ dT,
                                                       const float* __restrict__ dap, int ndap,
                                                       float* __restrict__ dslope, int accumulate) {
   __shared__ double sh[1024];
   const int E = nA + nT;
-  const int nblk = (E + 63) / 64;
+  const int nblk = (E + kGcnCols - 1) / kGcnCols;
   if ((int)blockIdx.x == nblk) {     // slope-gradient block (launched only when dap != NULL)
     double s = 0.0;
     for (int i = threadIdx.x; i < ndap; i += 1024) s += (double)dap[i];
@@ -1154,26 +1138,9 @@ __global__ __launch_bounds__(1024) void k_reduce_gcn(const float* __restrict__ p
     if (threadIdx.x == 0) dslope[0] = accumulate ? dslope[0] + (float)sh[0] : (float)sh[0];
     return;
   }
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int slice = threadIdx.x >> 6;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (e < E) {
-    const float* base = partials + e;
-    int p = slice;
-    for (; p + 48 < P; p += 64) {
-      s0 += (double)base[(size_t)p * E];
-      s1 += (double)base[(size_t)(p + 16) * E];
-      s2 += (double)base[(size_t)(p + 32) * E];
-      s3 += (double)base[(size_t)(p + 48) * E];
-    }
-    for (; p < P; p += 16) s0 += (double)base[(size_t)p * E];
-  }
-  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (slice == 0 && e < E) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[threadIdx.x + 64 * k];
+  const int e = blockIdx.x * kGcnCols + (threadIdx.x % kGcnCols);
+  const double t = column_sum_f64<kGcnCols>(partials, P, (size_t)E, e, e < E, sh);
+  if ((int)threadIdx.x < kGcnCols && e < E) {
     float* out = e < nA ? dA + e : dT + (e - nA);
     out[0] = accumulate ? out[0] + (float)t : (float)t;
   }
@@ -1285,7 +1252,7 @@ static int launch_layer_gcn_params(const float* in, const float* in_slope, const
   }
   int rc;
   if ((rc = check_launch("bwd_gcn_params"))) return rc;
-  hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(E, 64) + (dap ? 1 : 0)), dim3(1024), 0, st, partials, grid, T * V * V,
+  hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(E, kGcnCols) + (dap ? 1 : 0)), dim3(1024), 0, st, partials, grid, T * V * V,
                      V * T * T, dA, dT, dap, ndap, dslope, accumulate);
   return check_launch("bwd_gcn_reduce");
 }
@@ -1343,14 +1310,14 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
       // a handful of input channels (the first layer): plain FMAs on full-line loads (first_layer.hip)
       int rows = 0;
       if ((rc = launch_first_stats(in, Zg, dU, in_slope, w.partials, B, Ci, Co, TV, need_q, kMaxGridBwd, st, &rows))) return rc;
-      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
       if (stats_rows_out) *stats_rows_out = rows;
     } else if (Zg && bwd_stats_ring_ok(T, V, Ci, Co)) {
       // default geometry, 16 / 32 input channels: wave-per-clip reductions (fused_stats.hip)
       int rows = 0;
       if ((rc = launch_bwd_stats_ring(in, Zg, dU, in_slope, w.partials, B, Ci, Co, st, &rows))) return rc;
-      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
       if (stats_rows_out) *stats_rows_out = rows;
     } else if (Zg && zlds(1) <= (size_t)kMaxLdsBytes) {
@@ -1386,7 +1353,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
 #undef LAUNCH_RZ_O
 #undef LAUNCH_RZ
       if ((rc = check_launch("bwd_reduce_z"))) return rc;
-      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, gridz, E, red_of(gridz, E));
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, w.partials, gridz, E, red_of(gridz, E));
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
       if (stats_rows_out) *stats_rows_out = gridz;
     } else {
@@ -1424,7 +1391,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
 #undef LAUNCH_R_O
 #undef LAUNCH_R
     if ((rc = check_launch("bwd_reduce"))) return rc;
-    hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, 64)), dim3(1024), 0, st, w.partials, grid, E, red_of(grid, E));
+    hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, w.partials, grid, E, red_of(grid, E));
     if ((rc = check_launch("bwd_reduce_partials"))) return rc;
     if (stats_rows_out) *stats_rows_out = grid;
     }
@@ -1456,7 +1423,7 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   if (Zg && !dIn && !dz_ext && first_layer_ok(T, V, Ci, Co)) {
     int rows = 0;
     if ((rc = launch_first_bwd(in, Zg, dU, Aw, Tw, w.coef, in_slope, w.partials, B, Ci, Co, T, V, kMaxGridBwd, st, &rows))) return rc;
-    hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(T * V * V + V * T * T, 64)), dim3(1024), 0, st, w.partials, rows, T * V * V,
+    hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(T * V * V + V * T * T, kGcnCols)), dim3(1024), 0, st, w.partials, rows, T * V * V,
                        V * T * T, dA, dT, (const float*)nullptr, 0, (float*)nullptr, accumulate);
     return check_launch("bwd_gcn_reduce");
   }

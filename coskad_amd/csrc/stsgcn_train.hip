@@ -68,34 +68,13 @@ __global__ __launch_bounds__((Geo<T, V>::Block), (Geo<T, V>::Block <= 512 && NTC
 
 // out[e] = sum_p partials[p][e] in fp64 (fixed order).  block = 64 elements x 16 partial-slices, 4 loads in
 // flight per thread: the table is tiny (<= 512 x E floats) and the kernel is latency-bound.
-constexpr int kRedCols = 16;   // columns per block: 64 row slices, a thread's <= 16 rows all in flight (132 blocks at E = 2112)
+constexpr int kRedCols = 16;   // columns per block (132 blocks at E = 2112; a thread's <= 16 rows all in flight)
 __global__ __launch_bounds__(1024) void k_reduce_partials(const float* __restrict__ partials, int P, int E,
                                                            double* __restrict__ out) {
   __shared__ double sh[1024];
-  constexpr int NSL = 1024 / kRedCols;
   const int e = blockIdx.x * kRedCols + (threadIdx.x % kRedCols);
-  const int slice = threadIdx.x / kRedCols;
-  double s = 0.0;
-  if (e < E) {
-    const float* base = partials + e;
-    int p = slice;
-    for (; p + 7 * NSL < P; p += 8 * NSL) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(p + u * NSL) * E];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (double)v[u];
-    }
-    for (; p < P; p += NSL) s += (double)base[(size_t)p * E];
-  }
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  if (slice == 0 && e < E) {
-    double t = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < NSL; ++k) t += sh[threadIdx.x + kRedCols * k];
-    out[e] = t;
-  }
+  const double t = column_sum_f64<kRedCols>(partials, P, (size_t)E, e, e < E, sh);
+  if ((int)threadIdx.x < kRedCols && e < E) out[e] = t;
 }
 
 // stat block (floats), saved for the backward pass:
