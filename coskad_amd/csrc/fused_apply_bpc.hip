@@ -17,6 +17,9 @@ using namespace ff;
 // Measured (B = 4096, 32 -> 64; the wave-per-clip ring kernel: 114-116 us on the same box): two waves per SIMD 101-104 us, three
 // (148 registers with ONE set of B operands, read behind the MFMAs that used the previous ones) 98-101 us, four waves per SIMD only
 // with scratch spills in the K loop (212 B: 214 us).  Two groups of K rows in flight (DEPTH 2) beat one by 2 us.
+#ifndef BPC_GRID
+#define BPC_GRID (256 * BPC_OCC)   // every workgroup resident: 92-94 us against 96 with 1024 (a second, thinner round of workgroups)
+#endif
 #ifndef BPC_OCC
 #define BPC_OCC 3
 #endif
@@ -172,7 +175,7 @@ int launch_layer_apply_bpc(const float* Z, const float* in, float* out, const fl
                            const float* in_slope, int B, int Ci, int Co, hipStream_t st) {
   if (!(Ci == 32 && Co == 64)) return fail(COSKAD_ERR_SHAPE, "apply_bpc: built for 32 -> 64 channels (%d, %d)", Ci, Co);
   const size_t lds = (size_t)ff::WAVE_LDS_W * sizeof(float);
-  const int grid = B < 1024 ? B : 1024;                    // four workgroups per CU
+  const int grid = B < BPC_GRID ? B : BPC_GRID;
   auto k = fpc::k_layer_apply_bpc<2>;
   {
     ProbeScope probe(KID_LAYER_APPLY, Ci, Co, st);

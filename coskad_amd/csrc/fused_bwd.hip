@@ -34,7 +34,7 @@ using namespace ff;
 // A workgroup's partial sums of dA / dT in the workspace, lane-major (one float4 per lane and record: 1 KB per load / store):
 //   records [0, 12)   dA[t][4q + r][j]            (t = record)
 //           12        dA[t = 4q + r][16][j]       (t < 12)
-//           13        dA[t = j][v = 4q + r][16]   (j < 12)
+//           13        dA[t = 4q + r][v = j][16]   (t < 12)
 //           14        dA[t = j][16][16]           (r == 0, q == 0, j < 12)
 //           [15, 32)  dT[v][4q + r][j]            (v = record - 15; 4q + r < 12, j < 12)
 constexpr int PR_A = 0, PR_XA = 12, PR_XB = 13, PR_C = 14, PR_T = 15, PR_N = 32, EROW = PR_N * 256;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
     float* out = nullptr;
     if (rec < PR_XA) out = dA + rec * V * V + (4 * q + r) * V + j;
     else if (rec == PR_XA) { if (4 * q + r < T) out = dA + (4 * q + r) * V * V + 16 * V + j; }
-    else if (rec == PR_XB) { if (j < T) out = dA + j * V * V + (4 * q + r) * V + 16; }
+    else if (rec == PR_XB) { if (4 * q + r < T) out = dA + (4 * q + r) * V * V + j * V + 16; }
     else if (rec == PR_C) { if (r == 0 && q == 0 && j < T) out = dA + j * V * V + 16 * V + 16; }
     else if (4 * q + r < T && j < T) out = dT + (rec - PR_T) * T * T + (4 * q + r) * T + j;
     if (out) *out = accumulate ? *out + (float)t : (float)t;
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __r
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* r1 = lds;                 // 32-row image (stride LD)
   float* r2 = lds + 32 * LD;       // 16-row K window (stride LDW; LD in the statistics phase)
+  float* zs = lds + WAVE_LDS_W + 256 * (threadIdx.x >> 6);   // 1 KB per wave: the joint-16 dZ tile, lane-major
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   auto geo = [&]() {
@@ -325,17 +326,25 @@ __global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __r
 #pragma unroll
       for (int r = 0; r < 4; ++r) corner = fmaf(y16[r], az[MAXF][r], corner);
     }
+    *reinterpret_cast<f32x4*>(zs + lane * 4) = az[MAXF];  // the joint-16 tile through this wave's 1 KB of LDS: its columns by frame
 #pragma unroll
     for (int k = 0; k < ((FBB_SKIP & 4) ? 0 : MAXF); ++k) {
       const int t = f0 + k;
       const f32x4 y = tile_load(r1, 16 * ct, t * V + L.j, L);            // A operand: Y[16 ct + 4q + r][t, v = j]
       const f32x4 y16 = tile_load(r1, 16 * ct, t * V + 16, L);          // Y[..][t, 16] (same address in every column)
+      const f32x4 dz16 = *reinterpret_cast<const f32x4*>(zs + (16 * L.q + t) * 4);   // dZ[..][t, 16]: column t of the joint-16 tile
+      // the 17th row / column: this lane group's four channels on the VALU, the four groups' shares meet in ONE product with a
+      // one-hot row selector (A[i][k] = [i == t]): D[t][j] += sum_q p(j, q)
+      float pa = 0.f, pb = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         dAacc[k] = mfma(y[r], az[k][r], dAacc[k]);
-        exA = mfma(L.j == t ? y16[r] : 0.f, az[k][r], exA);
-        exB = mfma(y[r], L.j == t ? az[MAXF][r] : 0.f, exB);
+        pa = fmaf(y16[r], az[k][r], pa);                 // dA[t][16][w = j]
+        pb = fmaf(y[r], dz16[r], pb);                    // dA[t][v = j][16]
       }
+      const float sel = L.j == t ? 1.f : 0.f;
+      exA = mfma(sel, pa, exA);
+      exB = mfma(sel, pb, exB);
     }
     __syncthreads();                                     // every wave has read Y (frames AND the joint-16 column)
 #pragma unroll
@@ -580,7 +589,7 @@ int bwd_bpc_rows(int B) { return B < FBB_GRID ? B : FBB_GRID; }
 int launch_layer_bwd_bpc(const float* in, const float* Zg, const float* dU, const float* coef, const float* in_slope, float* dIn,
                          float* btab, float* partials, float* dap, int B, int Ci, int Co, hipStream_t st, int* rows_out,
                          const float* below_z, const float* below_x, const float* below_slope, int below_Ci, float* below_stats) {
-  const size_t lds = (size_t)ff::WAVE_LDS_W * sizeof(float);
+  const size_t lds = (size_t)(ff::WAVE_LDS_W + 4 * 256) * sizeof(float);
   const int grid = bwd_bpc_rows(B);
   *rows_out = grid;
 #define LAUNCH_FBB(CT, OT, NS, CB)                                                                                   \
