@@ -192,11 +192,156 @@ __global__ __launch_bounds__(256, 1) void k_bwd_stats_ring(const float* __restri
   for (int e = threadIdx.x; e < E; e += 256) dst[e] = row[e];
 }
 
+
+// The same sums, ONE CLIP PER WORKGROUP, for 32 input channels and 32 / 64 output channels (the top layer of the default stack,
+// whose dU comes from the bottleneck's split-K kernel -- no producer holds a clip's rows together for the backward chain):
+// the image holds the clip's dU rows (Co x 206 floats), the B side -- Z's two 16-row groups, then PReLU(U_prev)'s -- alternates
+// between two 16-row windows, every row staged by all 256 threads (one float4 each per quarter), ONE workgroup barrier per
+// group; the 26 double k-steps of a group are dealt to the four waves round-robin (each keeps its own partial sums: they meet
+// at the end of the launch).  The next group travels in 16 registers, the next clip's dU rows in 52, while the current group
+// multiplies.  65.9 + 13.2 KB of LDS per workgroup: two workgroups per CU.
+template <int CT, int OT>
+__global__ __launch_bounds__(256, 2) void k_bwd_stats_bpc(const float* __restrict__ in, const float* __restrict__ Zg,
+                                                         const float* __restrict__ dU, const float* __restrict__ in_slope,
+                                                         float* __restrict__ partials, int B) {
+  constexpr int Ci = 16 * CT, Co = 16 * OT, NG = 2 * CT, E = 2 * Co * Ci + Co;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* r1 = lds;                       // dU image: Co rows (stride LD)
+  float* w0 = lds + Co * LD;             // two 16-row windows (stride LD: (row, position) operand reads on both sides)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto geo = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return Lane{l & 15, l >> 4};
+  };
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  auto clip_res = [&](const float* base, int c, int rows) {
+    const bool in_range = c < B;
+    return make_res(base + (size_t)(in_range ? c : 0) * rows * TV, in_range ? rows * TV * 4u : 0u);
+  };
+  constexpr int Q4 = 4 * (TV / 4);
+  const bool stg = tid < Q4;
+  const int srow = tid / (TV / 4), scol = 4 * (tid - srow * (TV / 4));
+  const int svoff = stg ? tid * 16 : 0x7ffffff0;
+  auto qload = [&](const BufRes& res, int row0, int q) { return buf_load4(res, svoff, (row0 + 4 * q) * (TV / 4) * 16); };
+  auto qstore = [&](float* win, int q, float4 v, bool act) {
+    if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+    // (threads beyond the quarter: both halves to the padding columns of the window's last row)
+    *reinterpret_cast<float2*>(win + (stg ? (4 * q + srow) * LD + scol : 15 * LD + PADCOL)) = float2{v.x, v.y};
+    *reinterpret_cast<float2*>(win + (stg ? (4 * q + srow) * LD + scol + 2 : 15 * LD + PADCOL)) = float2{v.z, v.w};
+  };
+  constexpr int N4 = Co * (TV / 4), XL = (N4 + 255) / 256;
+  float4 xs[XL];
+  auto xload = [&](const BufRes& r) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) xs[i] = buf_load4(r, (tid + 256 * i) < N4 ? (tid + 256 * i) * 16 : 0x7ffffff0, 0);
+  };
+  f32x4 acc[NG][OT];
+  float rs[OT];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int c = 0; c < OT; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < OT; ++c) rs[c] = 0.f;
+
+  int clip = blockIdx.x;
+  float4 gq[4];
+  xload(clip_res(dU, clip, Co));
+  {
+    const BufRes z0 = clip_res(Zg, clip, Ci);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gq[q] = qload(z0, 0, q);
+  }
+  for (; clip < B; clip += gridDim.x) {
+    const BufRes zres = clip_res(Zg, clip, Ci), xres = clip_res(in, clip, Ci);
+    const BufRes znext = clip_res(Zg, clip + gridDim.x, Ci);
+    // group g: Z rows 16g .. (g < CT), then the layer input's; beyond this clip: the next clip's first group
+    auto gload = [&](int g, int q) {
+      return g < CT ? qload(zres, 16 * g, q) : (g < NG ? qload(xres, 16 * (g - CT), q) : qload(znext, 0, q));
+    };
+    __syncthreads();                                     // the previous clip's readers of the image and window 0 are done
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int e4 = tid + 256 * i;
+      const int row = e4 / (TV / 4), col = 4 * (e4 - row * (TV / 4));
+      *reinterpret_cast<float2*>(r1 + (e4 < N4 ? row * LD + col : PADCOL)) = float2{xs[i].x, xs[i].y};
+      *reinterpret_cast<float2*>(r1 + (e4 < N4 ? row * LD + col + 2 : PADCOL)) = float2{xs[i].z, xs[i].w};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      qstore(w0, q, gq[q], false);
+      gq[q] = gload(1, q);
+    }
+    xload(clip_res(dU, clip + gridDim.x, Co));           // the next clip's rows: a whole clip of MFMAs to arrive
+    __syncthreads();                                     // the image holds dU, window 0 group 0
+    constexpr int NM = (TV + 7) / 8;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      // (window (g + 1) & 1 was last read in group g - 1: the barrier at its end has passed)
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          qstore(w0 + ((g + 1) & 1) * 16 * LD, q, gq[q], g + 1 >= CT && pre);
+          gq[q] = gload(g + 2, q);
+        }
+      }
+      const Lane L = geo();
+      const float* pb = w0 + (g & 1) * 16 * LD + L.j * LD + 2 * L.q;
+      const float* pa = r1 + L.j * LD + 2 * L.q;
+      // (operands read just in time, the loop rolled: reading step i + 1's in front of step i's products measured 20 us
+      // slower per launch, rolled or unrolled)
+      for (int m = wave; m < NM; m += 4) {
+        const bool ok = 8 * m + 2 * L.q < TV;            // (beyond the row: the window's / image's next row -- masked)
+        float2 b = *reinterpret_cast<const float2*>(pb + 8 * m);
+        b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
+#pragma unroll
+        for (int c = 0; c < OT; ++c) {
+          float2 a = *reinterpret_cast<const float2*>(pa + 16 * c * LD + 8 * m);
+          a.x = ok ? a.x : 0.f; a.y = ok ? a.y : 0.f;
+          acc[g][c] = mfma(a.x, b.x, acc[g][c]);
+          acc[g][c] = mfma(a.y, b.y, acc[g][c]);
+          if (g == 0) rs[c] += a.x + a.y;
+        }
+      }
+      if (g + 1 < NG) __syncthreads();                   // group g + 1 is staged; every wave has left window g & 1
+    }
+  }
+  // ---- the workgroup's sums: the waves add theirs into ONE [P][Q][s] row in LDS one after another (fixed order) ----------------
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) lds[e] = 0.f;
+  __syncthreads();
+  const Lane L = geo();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int c = 0; c < OT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 16 * c + 4 * L.q + r;
+            lds[(g < CT ? 0 : Co * Ci) + o * Ci + 16 * (g < CT ? g : g - CT) + L.j] += acc[g][c][r];
+          }
+#pragma unroll
+      for (int c = 0; c < OT; ++c) {
+        const float t = quad_sum(rs[c]);
+        if (L.q == 0) lds[2 * Co * Ci + 16 * c + L.j] += t;
+      }
+    }
+    __syncthreads();
+  }
+  float* dst = partials + (size_t)blockIdx.x * E;
+  for (int e = tid; e < E; e += 256) dst[e] = lds[e];
+}
+
 }  // namespace fs
 
 // Used where it wins (B = 4096, in-step timings): 32 -> 16 channels 54 vs 73 us, 16 -> 32 channels 44-55 vs 55 us; at
 // 32 -> 64 the rows of dU pass the window twice (two phases x four groups) and the block-per-tile kernel is faster (125 vs
-// 148 us), so wide outputs on 32 input channels stay there.
+// 148 us): wide outputs on 32 input channels take k_bwd_stats_bpc below (118 us).
 bool bwd_stats_ring_ok(int T_, int V_, int Ci, int Co) {
   return T_ == ff::T && V_ == ff::V && ((Ci == 16 && (Co == 16 || Co == 32 || Co == 64)) || (Ci == 32 && Co == 16));
 }
@@ -226,6 +371,32 @@ int launch_bwd_stats_ring(const float* in, const float* Zg, const float* dU, con
   }
 #undef LAUNCH_FS
   return check_launch("bwd_stats_ring");
+}
+
+
+// One clip per workgroup: 32 input channels, 32 / 64 output channels.  Partial rows written: *rows_out (<= 512).
+bool bwd_stats_bpc_ok(int T_, int V_, int Ci, int Co) { return T_ == ff::T && V_ == ff::V && Ci == 32 && (Co == 32 || Co == 64); }
+
+int launch_bwd_stats_bpc(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
+                         int Ci, int Co, hipStream_t st, int* rows_out) {
+  const size_t lds = (size_t)(Co + 32) * ff::LD * sizeof(float);
+  const int per_cu = lds <= (size_t)52 * 1024 ? 3 : 2;
+  const int grid = B < 256 * per_cu ? B : 256 * per_cu;
+  *rows_out = grid;
+#define LAUNCH_FSB(CT, OT)                                                                                       \
+  do {                                                                                                           \
+    auto k = fs::k_bwd_stats_bpc<CT, OT>;                                                                        \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, in_slope, partials, B);                    \
+  } while (0)
+  {
+    ProbeScope probe(KID_BWD_REDUCE, Ci, Co, st);
+    if (Ci == 32 && Co == 32) LAUNCH_FSB(2, 2);
+    else if (Ci == 32 && Co == 64) LAUNCH_FSB(2, 4);
+    else return fail(COSKAD_ERR_SHAPE, "bwd_stats_bpc: unsupported channels (%d, %d)", Ci, Co);
+  }
+#undef LAUNCH_FSB
+  return check_launch("bwd_stats_bpc");
 }
 
 }  // namespace coskad

@@ -1174,6 +1174,9 @@ bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co);
 bool bwd_stats_ring_ok(int T_, int V_, int Ci, int Co);
 int launch_bwd_stats_ring(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
                           int Ci, int Co, hipStream_t st, int* rows_out);
+bool bwd_stats_bpc_ok(int T_, int V_, int Ci, int Co);
+int launch_bwd_stats_bpc(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
+                         int Ci, int Co, hipStream_t st, int* rows_out);
 // first_layer.hip
 bool first_layer_ok(int T_, int V_, int Ci, int Co);
 int launch_first_stats(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B, int Ci,
@@ -1310,6 +1313,13 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
       // a handful of input channels (the first layer): plain FMAs on full-line loads (first_layer.hip)
       int rows = 0;
       if ((rc = launch_first_stats(in, Zg, dU, in_slope, w.partials, B, Ci, Co, TV, need_q, kMaxGridBwd, st, &rows))) return rc;
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
+      if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+      if (stats_rows_out) *stats_rows_out = rows;
+    } else if (Zg && bwd_stats_bpc_ok(T, V, Ci, Co)) {
+      // default geometry, 32 input channels and a wide output (the top layer): one clip per workgroup (fused_stats.hip)
+      int rows = 0;
+      if ((rc = launch_bwd_stats_bpc(in, Zg, dU, in_slope, w.partials, B, Ci, Co, st, &rows))) return rc;
       hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
       if (stats_rows_out) *stats_rows_out = rows;
