@@ -7,20 +7,23 @@
 //   dA[t]   = Y_t^T dZ_t   (Y = temporal mix of X)     dT[v] = X_v^T dY_v   (dY = spatial adjoint of dZ)
 //   (+ the batch reductions of the layer BELOW from the dU_prev rows, NS != 0: the backward chain)
 //
-// dZ never leaves the CU, X is staged once for the mixes, the PReLU mask and the dT / second-pass rows are re-reads from L2.  One
-// 32-row LDS image carries X -> Y -> dZ -> dY -> gcn^T(dZ) -> dX -> dU_prev in place; the rows of dU, Z and X stream through a
+// dZ never leaves the CU and the rows of dU are read ONCE: the K pass feeds both dZ = Bt.dU + .. and Br.dU (two accumulator
+// sets on the same window rows), Kr.X rides on the X halves that dT stages anyway -- round 2's second pass over dU (from the
+// Infinity Cache) and its 24 barriers are gone, for 28 more accumulator registers: two waves per SIMD instead of three.  One
+// 32-row LDS image carries X -> Y -> dZ -> dY -> gcn^T(dZ) -> dX -> dU_prev in place; the rows of dU and Z stream through a
 // 16-row K window quarter by quarter (full-line buffer loads by all 256 threads, a quarter per k-step, one group in flight in
-// registers).  The four waves of a workgroup share the image and the window (39.7 KB per workgroup: three workgroups per CU at
-// 168 registers) and split the work:
-//   K passes      a wave owns one channel tile x 6 frames (3 at 16 channels) + the joint-16 tile, which every wave computes for
-//                 itself in the first pass (dA's 17th column needs it beside every frame): 7 (4) accumulator tiles
+// registers).  The four waves of a workgroup share the image and the window (40.7 KB per workgroup) and split the work:
+//   K pass        a wave owns one channel tile x 6 frames (3 at 16 channels) + the joint-16 tile, which every wave computes for
+//                 itself for dZ (dA's 17th column needs it beside every frame): 7 + 6.25 (4 + 3.25) accumulator tiles
 //   dA            from the wave's own dZ tiles (accumulator tile -> B operand): its frames' dA[t] only; the waves' sums meet at
 //                 the very end
-//   mixing        joints (temporal) / frames (spatial) round-robin;  dT: joints round-robin, X staged in the window by all threads
+//   mixing        joints (temporal) / frames (spatial) round-robin;  dT + Kr.X: joints round-robin / the wave's tiles, X staged
+//                 in the window 16 rows at a time by all threads
 //   row pass      all 256 threads
-// with a workgroup barrier between the phases and one per k-step of the K passes.  Round 2's kernel kept all of this in ONE
+// with a workgroup barrier between the phases and one per k-step of the K pass.  Round 2's kernel kept all of this in ONE
 // wave per clip (one wave per SIMD: 104 pass accumulators + 124 sums, 37 % of its cycles issuing MFMAs; 290 / 160 / 240 us at
-// B = 4096 for 32->64 / 16->32 / 32->16 with the chain, against 262 / 143 / 217 us here).  Phase costs at 32->64 (timing-only
+// B = 4096 for 32->64 / 16->32 / 32->16 with the chain); four waves per clip with two passes: 262 / 143 / 217 us at three waves
+// per SIMD; one pass: 32->64 -18 us, the train step 1.401 -> 1.376 ms.  Phase costs at 32->64 before the merge (timing-only
 // builds, FBB_SKIP): K passes 150 us, temporal mixes 45, dA 45, dT 45, spatial 20, row pass + statistics 35; with every stream
 // L2-resident (COSKAD_HOT) the kernel loses 45 us: the fp32 MFMA issue of its ~550 products per wave and clip is half its time.
 // Per-workgroup partial sums of dA / dT live in the workspace (summed in a fixed order by k_reduce_fused: deterministic).
@@ -88,9 +91,9 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
 // [grid][2 Ci Cb + Ci] partial rows as k_bwd_fold reads them.
 //   NS = 1: Cb = 2 (a first layer): Z0 Z1 X0 X1 are ONE 4-row operand group
 //   NS = 2: Cb = 16 CB: 2 CB groups of 16 rows through the K window, (row, position) operands on both sides
-#ifndef FBB_OCC
-#define FBB_OCC 3
-#endif
+// waves per SIMD: the one-pass kernel needs up to 256 registers (two); 16 input channels without the chain fit three in 168
+// (B = 4096, 16 -> 32: 163 vs 172 us; WITH the chain's sums three waves spill 30 registers and the step loses 7 us)
+constexpr int bpc_occ(int CT, int NS) { return CT == 1 && NS == 0 ? 3 : 2; }
 #ifndef FBB_BDBL   // K passes: operands of k-step s+1 read in front of step s's MFMAs (two register sets) / behind them (one): same speed
 #define FBB_BDBL 0
 #endif
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const float* __restrict__
 #endif
 
 template <int CT, int OT, int NS, int CB>
-__global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __restrict__ in, const float* __restrict__ Zg,
+__global__ __launch_bounds__(256, bpc_occ(CT, NS)) void k_layer_bwd_bpc(const float* __restrict__ in, const float* __restrict__ Zg,
                                                                const float* __restrict__ dU, const float* __restrict__ coef,
                                                                const float* __restrict__ btab, const float* __restrict__ in_slope,
                                                                float* __restrict__ dIn, float* __restrict__ partials,
@@ -269,13 +272,20 @@ __global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __r
     const int lq = (L.q * CiP + 16 * ct + L.j) * 4;
     const int jc = L.j < T ? L.j : T - 1;
     auto pos_of = [&](int k) { return k < MAXF ? (f0 + k) * V + L.j : jc * V + 16; };   // tile k of this wave (MAXF: joint 16)
-    auto kpass = [&](f32x4 (&acc)[MAXF + 1], const BufRes& res2, bool act2, int c0, int c1, bool with16) {
-      // on entry group 0 is staged in the window and group 1 is in the registers
-      float wc[2][4];
+    auto kpass = [&](f32x4 (&acc)[MAXF + 1], f32x4 (&acc2)[MAXF + 1], const BufRes& res2, bool act2, int c0, int c1, int c2,
+                     bool with16, bool with16b) {
+      // on entry group 0 is staged in the window and group 1 is in the registers.  The dU groups feed BOTH sets of sums: `acc`
+      // with coefficient rows [c0 ..) (then the second source's groups with rows [c1 ..)), `acc2` with rows [c2 ..) -- one read
+      // of the dU rows for what were two passes in the round-2 kernel
+      constexpr bool DUAL = true;
+      float wc[2][4], wc2[2][4];
       auto cload = [&](int buf, int g) {
         const int krow = g < OT ? c0 + 16 * g : c1 + 16 * (g - OT);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wc[buf][s] = buf_load1(cres, lq, ((krow + 4 * s) * CiP) * 4);
+        for (int s = 0; s < 4; ++s) {
+          wc[buf][s] = buf_load1(cres, lq, ((krow + 4 * s) * CiP) * 4);
+          if (DUAL && g < OT) wc2[buf][s] = buf_load1(cres, lq, ((c2 + 16 * g + 4 * s) * CiP) * 4);
+        }
       };
       cload(0, 0);
       float b[1 + FBB_BDBL][MAXF + 1];
@@ -302,6 +312,11 @@ __global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __r
 #pragma unroll
           for (int k = 0; k <= MAXF; ++k)
             if (k < MAXF || with16) acc[k] = mfma(wc[g & 1][s], b[FBB_BDBL ? (s & 1) : 0][k], acc[k]);
+          if (DUAL && g < OT) {
+#pragma unroll
+            for (int k = 0; k <= MAXF; ++k)
+              if (k < MAXF || with16b) acc2[k] = mfma(wc2[g & 1][s], b[FBB_BDBL ? (s & 1) : 0][k], acc2[k]);
+          }
           if (!FBB_BDBL && (s + 1 < 4 || g + 1 < NG)) {  // single set: the next k-step's operands behind this step's MFMAs
 #pragma unroll
             for (int k = 0; k <= MAXF; ++k) b[0][k] = r2[(4 * sn + L.q) * LDW + pos_of(k)];
@@ -315,8 +330,15 @@ __global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __r
 #pragma unroll
       for (int k = 0; k <= MAXF; ++k) az[k] = f32x4{a.x, a.y, a.z, a.w};
     }
+    f32x4 xr[MAXF + 1];                                  // Br.dU + Kr.X + kr
+    {
+      const float4 kq = buf_load4(cres, L.q * 16, (KR0 + 16 * ct) * 4);
+#pragma unroll
+      for (int k = 0; k <= MAXF; ++k) xr[k] = f32x4{kq.x, kq.y, kq.z, kq.w};
+    }
     __syncthreads();                                     // the image holds Y (the K pass itself does not touch the image)
-    if (!(FBB_SKIP & 2)) kpass(az, zres, false, 0, Co, true);                 // Bt rows [0, Co), Kt rows [Co, Co + Ci)
+    // Bt rows [0, Co), Kt rows [Co, Co + Ci); Br rows [DX0 / CiP ..)
+    if (!(FBB_SKIP & 2)) kpass(az, xr, zres, false, 0, Co, DX0 / CiP, true, owns16);
     // dT's first X half takes off behind the dA products (the group registers are free)
 #pragma unroll
     for (int q = 0; q < 4; ++q) gq[q] = qload(xres, 0, q);
@@ -363,11 +385,22 @@ __global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                    // X rows 16h .. 16h+15 -> window; the next half / dU group 0 -> registers
           qstore(q, gq[q], true, a_in, LDW);
-          gq[q] = h + 1 < CT ? qload(xres, 16 * (h + 1), q) : qload(dures, 0, q);
+          if (h + 1 < CT) gq[q] = qload(xres, 16 * (h + 1), q);
         }
+        float wk[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wk[s] = buf_load1(cres, lq, ((DX0 / CiP + Co + 16 * h + 4 * s) * CiP) * 4);   // Kr rows
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+          if (!(FBB_SKIP & 2)) {                         // + Kr.X: the staged half IS the second pass's last group
+            float bx[MAXF + 1];
+#pragma unroll
+            for (int k = 0; k <= MAXF; ++k) bx[k] = r2[(4 * s + L.q) * LDW + pos_of(k)];
+#pragma unroll
+            for (int k = 0; k <= MAXF; ++k)
+              if (k < MAXF || owns16) xr[k] = mfma(wk[s], bx[k], xr[k]);
+          }
 #pragma unroll
           for (int k = 0; k < MAXJ; ++k) {
             const int v = wave + 4 * k;
@@ -381,29 +414,22 @@ __global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __r
         __syncthreads();                                 // the window is rewritten next
       }
     }
-    // second K pass: dU group 0 -> window, group 1 on its way across the temporal adjoint
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      qstore(q, gq[q], false, 0.f, LDW);
-      gq[q] = kload(1, q, xres);
-    }
-    // ---- gcn^T: temporal adjoint in place -------------------------------------------------------------------------------------------
-    if (!(FBB_SKIP & 1)) temporal_rr(TEMP_F4 + SPAT_F4);
-    __syncthreads();                                     // the image holds gcn^T(dZ), the window group 0
-    // ---- + dXres: the second K pass starts from the image's own tiles and returns them in place ------------------------------
-    L = geo();
     float4 u[XL];
     {
-      const float4 kq = buf_load4(cres, L.q * 16, (KR0 + 16 * ct) * 4);
-      const f32x4 krq = {kq.x, kq.y, kq.z, kq.w};
-      f32x4 xr[MAXF + 1];
-#pragma unroll
-      for (int k = 0; k <= MAXF; ++k) xr[k] = tile_load(r1, 16 * ct, pos_of(k), L) + krq;
-      if (!(FBB_SKIP & 2)) kpass(xr, xres, true, DX0 / CiP, DX0 / CiP + Co, owns16);   // Br / Kr rows
+      // ---- gcn^T: temporal adjoint in place, + Br.dU + Kr.X + kr (in the registers since the K pass): dX -------------------------
+      if (!(FBB_SKIP & 1)) temporal_rr(TEMP_F4 + SPAT_F4);
+      __syncthreads();                                   // the image holds gcn^T(dZ)
       xload(u, xres);                                    // the pre-activations come back (from L2) for the row pass
+      L = geo();
 #pragma unroll
-      for (int k = 0; k < MAXF; ++k) tile_store(r1, 16 * ct, (f0 + k) * V + L.j, true, xr[k], L);
-      if (owns16) tile_store(r1, 16 * ct, jc * V + 16, L.j < T, xr[MAXF], L);
+      for (int k = 0; k < MAXF; ++k) {
+        const int pos = (f0 + k) * V + L.j;
+        tile_store(r1, 16 * ct, pos, true, xr[k] + tile_load(r1, 16 * ct, pos, L), L);
+      }
+      if (owns16) {
+        const int pos = (L.j < T ? L.j : T - 1) * V + 16;
+        tile_store(r1, 16 * ct, pos, L.j < T, xr[MAXF] + tile_load(r1, 16 * ct, pos, L), L);
+      }
     }
     __syncthreads();                                     // the image holds dX
     // ---- dU_prev = image * PReLU'(U_prev), slope gradient: row-wise, full lines both ways; the next clip's rows take off ---------
@@ -581,16 +607,17 @@ __global__ __launch_bounds__(256, FBB_OCC) void k_layer_bwd_bpc(const float* __r
 
 }  // namespace fb
 
-#ifndef FBB_GRID
-#define FBB_GRID (256 * FBB_OCC)
-#endif
-int bwd_bpc_rows(int B) { return B < FBB_GRID ? B : FBB_GRID; }
+// every workgroup resident: 256 CUs x the waves per SIMD the registers allow
+int bwd_bpc_rows(int B, int Ci, bool chain) {
+  const int grid = 256 * fb::bpc_occ(Ci / 16, chain ? 1 : 0);
+  return B < grid ? B : grid;
+}
 
 int launch_layer_bwd_bpc(const float* in, const float* Zg, const float* dU, const float* coef, const float* in_slope, float* dIn,
                          float* btab, float* partials, float* dap, int B, int Ci, int Co, hipStream_t st, int* rows_out,
                          const float* below_z, const float* below_x, const float* below_slope, int below_Ci, float* below_stats) {
   const size_t lds = (size_t)(ff::WAVE_LDS_W + 4 * 256) * sizeof(float);
-  const int grid = bwd_bpc_rows(B);
+  const int grid = bwd_bpc_rows(B, Ci, below_stats != nullptr);
   *rows_out = grid;
 #define LAUNCH_FBB(CT, OT, NS, CB)                                                                                   \
   do {                                                                                                               \
@@ -630,7 +657,7 @@ int layer_bwd_below_rows(int T_, int V_, int B, int Ci, int Co, int below_Ci) {
   const bool built = (Ci == 32 && Co == 16 && below_Ci == 2) || (Ci == 16 && Co == 32 && below_Ci == 32) ||
                      (Ci == 32 && Co == 64 && below_Ci == 16);
   if (!(T_ == ff::T && V_ == ff::V && built) || B <= 0) return 0;
-  return bwd_bpc_rows(B);
+  return bwd_bpc_rows(B, Ci, true);
 }
 
 bool layer_bwd_fused_ok(int T_, int V_, int Ci, int Co) {

@@ -254,8 +254,11 @@ def test_backward_chain_below_stats_vs_own_pass(C0, C1, C2, B):
     dU_c, dX_c, g2c, g1c = run(True)
     dU_o, dX_o, g2o, g1o = run(False)
     assert torch.equal(dU_c, dU_o)
+    # the upper layer's own results do not depend on the chain: dU bit for bit; its dA / dT / slope sums are summed over a
+    # different number of workgroups (the chain variant runs two waves per SIMD, the plain 16-channel one three): fp32 rounding only
     for k in g2o:
-        np.testing.assert_array_equal(g2c[k].cpu().numpy(), g2o[k].cpu().numpy(), err_msg="upper layer " + k)
+        a, b_ = g2c[k].cpu().numpy(), g2o[k].cpu().numpy()
+        np.testing.assert_allclose(a, b_, rtol=2e-5, atol=2e-6 * max(np.abs(b_).max(), 1e-9), err_msg="upper layer " + k)
     if dX_o is not None:
         close(dX_c, dX_o.cpu(), rtol=1e-3, atol_rel=1e-4, msg="dX of the lower layer")
     gmax = max(float(v.abs().max()) for v in g1o.values())
