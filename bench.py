@@ -389,7 +389,7 @@ def main():
         if lbw_n.value:
             ach = layer_bytes / (lbw_ms.value * 1e-3) / 1e9
             roof = {"bound": "hbm",
-                    "what": "layer 4 backward (64 -> 32 channels), ALL its kernels (batch reductions k_bwd_reduce_z, fp64 folds, "
+                    "what": "layer 4 backward (64 -> 32 channels), ALL its kernels (batch reductions k_bwd_stats_bpc, fp64 folds, "
                             "k_layer_bwd_bpc<2,4,..> = data path + dA / dT, partial-row sums) against the layer's algorithmic bytes"
                             + (f"; the data kernel also forms layer 3's batch reductions (backward chain): + {below_bytes} bytes "
                                "(layer 3's stored Z and input) in algorithmic_bytes_per_launch, its time in avg_launch_us" if chained else ""),

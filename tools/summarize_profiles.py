@@ -132,7 +132,7 @@ def main(tag: str) -> None:
     for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2,1>"), ("bwd_fused layer4", "k_layer_bwd_bpc<2,4"),
                           ("bwd_fused layer3", "k_layer_bwd_bpc<1,2"), ("bwd_fused layer2", "k_layer_bwd_bpc<2,1"),
                           ("layer_apply layer4", "k_layer_apply_bpc<2>"), ("fused_encoder", "k_fused_encoder"),
-                          ("bwd_stats layer4", "k_bwd_reduce_z<12,17,4,2>"), ("apply_next layer1", "k_layer_apply_next_bpc<0,2>"),
+                          ("bwd_stats layer4", "k_bwd_stats_bpc<2,4>"), ("apply_next layer1", "k_layer_apply_next_bpc<0,2>"),
                           ("apply_next layer2", "k_layer_apply_next_bpc<2,1>"), ("apply_next layer3", "k_layer_apply_next_bpc<1,2>")):
         b = biggest(prefix)
         if b:
