@@ -1,0 +1,215 @@
+// Training-mode layer apply on the stored-Z path for layouts other than 12 x 17 (reference: models/graph_layers/stsgcn.py:94-116
+// with both BatchNorms folded from this batch's statistics):
+//     U[o][pos] = sum_c Wz[c][o] Z[c][pos] + sum_c Wx[c][o] PReLU(U_prev)[c][pos] + b[o]
+// The product does not see frames or joints: fused_apply_bpc.hip's layout -- ONE CLIP PER WORKGROUP, the four waves sharing a
+// 16-row K window and a 32-row flush image, the K rows staged by all 256 threads a quarter per k-step, a workgroup barrier per
+// k-step -- over FLAT 16-position tiles of a clip's T V positions (the last tile masked), templated on T V.  Built for the
+// 25-joint layout (T V = 300: 19 tiles, 58 KB of LDS per workgroup, two workgroups per CU), 16 / 32 input and 16 / 32 / 64
+// output channels; replaces the streaming strip GEMM (k_layer_apply_z: nothing staged, every operand fetched per strip) there.
+#include "fused_ops.h"
+
+namespace coskad {
+namespace fpf {
+
+using ff::BufRes;
+using ff::buf_load1;
+using ff::buf_load4;
+using ff::buf_store4;
+using ff::f32x4;
+using ff::Lane;
+using ff::make_res;
+using ff::mfma;
+using ff::prelu;
+
+// window row stride: >= TVg, 16-byte rows, rows 4s + q (q = 0..3) on disjoint bank quarters (stride = 16 or 48 mod 64 floats)
+constexpr int window_stride(int tv) {
+  int l = (tv + 3) / 4 * 4;
+  while (l % 64 != 16 && l % 64 != 48) l += 4;
+  return l;
+}
+
+// CT: 16-row groups of the input; OT: 16-channel output tiles
+template <int TVg, int CT, int OT>
+__global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __restrict__ in, const float* __restrict__ Zg,
+                                                            const float* __restrict__ wfold, const float* __restrict__ bias,
+                                                            const float* __restrict__ in_slope, float* __restrict__ out, int B) {
+  static_assert(TVg % 4 == 0, "rows are staged as float4");
+  constexpr int Ci = 16 * CT, Co = 16 * OT, CoP = Co, NG = 2 * CT;
+  constexpr int R4 = TVg / 4;                            // float4 per row
+  constexpr int LDg = TVg + 2;                           // flush image stride (two padding columns: masked lanes store there)
+  constexpr int LDWg = window_stride(TVg);
+  constexpr int NT = (TVg + 15) / 16;                    // position tiles
+  // a wave's share: 64 output channels: its own output tile x all position tiles; 32: output tile wave & 1 x half of them;
+  // 16: a quarter of them
+  constexpr int MAXT = OT == 4 ? NT : (OT == 2 ? (NT + 1) / 2 : (NT + 3) / 4);
+  constexpr int Q4 = 4 * R4, NQ = (Q4 + 255) / 256;      // float4 of a quarter (4 rows), pieces per thread
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* r2 = lds;                   // 16-row K window (stride LDWg)
+  float* r1 = lds + 16 * LDWg;       // 32-row flush image (stride LDg)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto geo = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return Lane{l & 15, l >> 4};
+  };
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  const BufRes wres = make_res(wfold, 2 * Ci * CoP * 4u);
+  const BufRes bres = make_res(bias, CoP * 4u);
+  auto clip_res = [&](const float* base, int c, int rows) {
+    const bool in_range = c < B;
+    return make_res(base + (size_t)(in_range ? c : 0) * rows * TVg, in_range ? rows * TVg * 4u : 0u);
+  };
+  const int ot = OT == 4 ? wave : (OT == 2 ? (wave & 1) : 0);
+  const int t0 = OT == 4 ? 0 : (OT == 2 ? (wave >> 1) * MAXT : wave * MAXT);
+  const int nt = NT - t0 < MAXT ? NT - t0 : MAXT;        // (> 0 for every wave at the shapes built)
+  // K ring: one group in flight, a quarter = NQ float4 per thread
+  float4 gq[4][NQ];
+  auto qload = [&](const BufRes& res, int row0, int q, float4 (&dst)[NQ]) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + 256 * i;
+      dst[i] = buf_load4(res, e < Q4 ? e * 16 : 0x7ffffff0, (row0 + 4 * q) * R4 * 16);
+    }
+  };
+  auto qstore = [&](int q, const float4 (&src)[NQ], bool act) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + 256 * i;
+      float4 v = src[i];
+      if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+      const int row = e / R4, col = 4 * (e - row * R4);
+      if (e < Q4) *reinterpret_cast<float4*>(r2 + (4 * q + row) * LDWg + col) = v;
+    }
+  };
+
+  int clip = blockIdx.x;
+  {
+    const BufRes z0 = clip_res(Zg, clip, Ci);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qload(z0, 0, q, gq[q]);
+  }
+  for (; clip < B; clip += gridDim.x) {
+    const BufRes xres = clip_res(in, clip, Ci), zres = clip_res(Zg, clip, Ci), ores = clip_res(out, clip, Co);
+    const BufRes znext = clip_res(Zg, clip + gridDim.x, Ci);
+    // group g of this clip: Z rows first (CT groups), then the layer input; beyond: the next clip's first group
+    auto gload = [&](int g, int q, float4 (&dst)[NQ]) {
+      if (g < CT) qload(zres, 16 * g, q, dst);
+      else if (g < NG) qload(xres, 16 * (g - CT), q, dst);
+      else qload(znext, 0, q, dst);
+    };
+    Lane L = geo();
+    f32x4 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // position of tile t of this wave in the lane's column (beyond the clip: clamped -- those columns are never stored)
+    auto pos_of = [&](int t) {
+      const int p = 16 * (t0 + (t < nt ? t : 0)) + L.j;
+      return p < TVg ? p : TVg - 1;
+    };
+    // entry: the registers hold group 0 (fetched during the previous clip; its flush ended with a barrier)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      qstore(q, gq[q], false);
+      gload(1, q, gq[q]);
+    }
+    const int lq = (L.q * CoP + 16 * ot + L.j) * 4;        // this wave's output tile of the folded weights
+    float wc[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wc[0][s] = buf_load1(wres, lq, (4 * s) * CoP * 4);
+    __syncthreads();                                       // the window holds group 0
+    float b[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) b[t] = r2[L.q * LDWg + pos_of(t)];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wc[(g + 1) & 1][s] = buf_load1(wres, lq, ((16 * (g + 1) + 4 * s) * CoP) * 4);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        // every wave has read rows 4s .. 4s+3 (a k-step ago); in the last group: its fourth quarter (stored a k-step ago) is visible
+        if (g + 1 < NG || s == 0) __syncthreads();
+        if (g + 1 < NG) {
+          qstore(s, gq[s], g + 1 >= CT && pre);
+          gload(g + 2, s, gq[s]);                          // (beyond this clip: the next clip's first group)
+        }
+        // (a wave with one tile fewer multiplies its first tile twice instead of branching: that sum is never stored)
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = mfma(wc[g & 1][s], b[t], acc[t]);
+        if (s + 1 < 4 || g + 1 < NG) {                     // the next k-step's operands behind this step's MFMAs
+          const int sn = (s + 1) & 3;
+#pragma unroll
+          for (int t = 0; t < MAXT; ++t) b[t] = r2[(4 * sn + L.q) * LDWg + pos_of(t)];
+        }
+      }
+    }
+    L = geo();
+    const float4 b4 = buf_load4(bres, L.q * 16, (16 * ot) * 4);
+    const f32x4 bq = {b4.x, b4.y, b4.z, b4.w};
+    // ---- flush: 32 channels at a time through the image, full lines to HBM ---------------------------------------------------
+    constexpr int NR = (Co + 31) / 32;
+#pragma unroll
+    for (int rnd = 0; rnd < NR; ++rnd) {
+      if (OT < 4 || (wave >> 1) == rnd) {
+        const int row0 = OT == 4 ? 16 * (wave & 1) : 16 * ot;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const int p = 16 * (t0 + t) + L.j;
+          if (t < nt) {
+            const f32x4 v = acc[t] + bq;
+            float* dst = r1 + (row0 + 4 * L.q) * LDg + (p < TVg ? p : TVg);
+            dst[0] = v[0]; dst[LDg] = v[1]; dst[2 * LDg] = v[2]; dst[3 * LDg] = v[3];
+          }
+        }
+      }
+      __syncthreads();
+      constexpr int rows = Co < 32 ? Co : 32;
+      constexpr int n4 = rows * R4;
+#pragma unroll
+      for (int i = 0; i < (n4 + 255) / 256; ++i) {
+        const int e4 = tid + 256 * i;
+        const bool ok = e4 < n4;
+        const int row = e4 / R4, col = 4 * (e4 - row * R4);
+        const float* p = r1 + (ok ? row * LDg + col : TVg);
+        const float2 g0 = *reinterpret_cast<const float2*>(p), g1 = *reinterpret_cast<const float2*>(ok ? p + 2 : p);
+        buf_store4(ores, ok ? e4 * 16 : 0x7ffffff0, (32 * rnd) * R4 * 16, float4{g0.x, g0.y, g1.x, g1.y});
+      }
+      __syncthreads();                                     // (the image / the window are rewritten next)
+    }
+  }
+}
+
+}  // namespace fpf
+
+bool layer_apply_flat_ok(int TV_, int Ci, int Co) {
+  return TV_ == 300 && (Ci == 16 || Ci == 32) && (Co == 16 || Co == 32 || Co == 64);
+}
+
+int launch_layer_apply_flat(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
+                            const float* in_slope, int B, int Ci, int Co, int TV_, hipStream_t st) {
+  if (!layer_apply_flat_ok(TV_, Ci, Co)) return fail(COSKAD_ERR_SHAPE, "apply_flat: unsupported shape (%d positions, %d -> %d)", TV_, Ci, Co);
+  constexpr int TVg = 300;
+  const size_t lds = (size_t)(16 * fpf::window_stride(TVg) + 32 * (TVg + 2)) * sizeof(float);
+  const int grid = B < 512 ? B : 512;                      // two workgroups per CU (four at 16 output channels: same speed)
+#define LAUNCH_FPF(CT, OT)                                                                                       \
+  do {                                                                                                           \
+    auto k = fpf::k_layer_apply_flat<TVg, CT, OT>;                                                               \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Z, wfold, bias, in_slope, out, B);                 \
+  } while (0)
+  {
+    ProbeScope probe(KID_LAYER_APPLY, Ci, Co, st);
+    if (Ci == 16 && Co == 16) LAUNCH_FPF(1, 1);
+    else if (Ci == 16 && Co == 32) LAUNCH_FPF(1, 2);
+    else if (Ci == 16 && Co == 64) LAUNCH_FPF(1, 4);
+    else if (Ci == 32 && Co == 16) LAUNCH_FPF(2, 1);
+    else if (Ci == 32 && Co == 32) LAUNCH_FPF(2, 2);
+    else LAUNCH_FPF(2, 4);
+  }
+#undef LAUNCH_FPF
+  return check_launch("layer_apply_flat");
+}
+
+}  // namespace coskad

@@ -254,6 +254,10 @@ int launch_layer_apply_bpc(const float* Z, const float* in, float* out, const fl
 // first_layer.hip
 int launch_first_apply(const float* Z, const float* in, float* out, const float* wfold, const float* bias, const float* in_slope,
                        int B, int Ci, int Co, int TVr, hipStream_t st);
+// fused_apply_flat.hip
+bool layer_apply_flat_ok(int TV_, int Ci, int Co);
+int launch_layer_apply_flat(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
+                            const float* in_slope, int B, int Ci, int Co, int TV_, hipStream_t st);
 }  // namespace coskad
 
 using namespace coskad;
@@ -271,6 +275,10 @@ extern "C" int coskad_layer_apply_z_f32(const float* Z, const float* in, float* 
   if (!out_slope && T == 12 && V == 17 && Ci == 32 && Co == 64)
     return launch_layer_apply_bpc(Z, in, out, wfold, bias, in_slope, B, Ci, Co, stream);
   if (!out_slope && layer_apply_ring_ok(T, V, Ci, Co)) return launch_layer_apply_ring(Z, in, out, wfold, bias, in_slope, B, Ci, Co, stream);
+  // the 25-joint layout, 16 / 32 input channels: the same K-ring GEMM, one clip per workgroup, over flat position tiles
+  // (fused_apply_flat.hip)
+  if (!out_slope && layer_apply_flat_ok(T * V, Ci, Co))
+    return launch_layer_apply_flat(Z, in, out, wfold, bias, in_slope, B, Ci, Co, T * V, stream);
   // the streaming GEMM over Z and `in` (nothing staged) for every width up to 64: at 64 output channels on the 25-joint layout it
   // beats the LDS-tiled kernel with Z staged (258 -> ~235 us; encoder step 3.15 -> 3.13 ms)
   (void)A; (void)Tm;

@@ -135,13 +135,16 @@ def test_train_forward_large_ragged_batch():
         np.testing.assert_allclose(v.numpy(), st_ref[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("Ci,Co,B", [(32, 64, 1031), (16, 32, 2053), (32, 16, 1026), (16, 16, 7), (32, 32, 5), (16, 64, 6)])
-def test_apply_ring_ragged_batch_vs_recompute_kernel(Ci, Co, B):
-    """Training-mode apply on the stored-Z path (csrc/fused_apply.hip: wave-per-clip K-ring GEMM, several clips per wave,
-    ragged last round) against the recompute kernel of the same library (k_layer_apply / _m: mixes X itself) with the same
-    folded weights: two independent implementations of stsgcn.py:94-116's forward.  The output sits inside a guarded buffer."""
+@pytest.mark.parametrize("Ci,Co,B,V", [(32, 64, 1031, 17), (16, 32, 2053, 17), (32, 16, 1026, 17), (16, 16, 7, 17), (32, 32, 5, 17),
+                                       (16, 64, 6, 17), (32, 64, 1027, 25), (16, 32, 1030, 25), (32, 16, 1025, 25), (16, 16, 9, 25),
+                                       (32, 32, 3, 25), (16, 64, 515, 25)])
+def test_apply_ring_ragged_batch_vs_recompute_kernel(Ci, Co, B, V):
+    """Training-mode apply on the stored-Z path (csrc/fused_apply.hip / fused_apply_bpc.hip at 17 joints, fused_apply_flat.hip at
+    25: K-ring GEMMs, several clips per wave / workgroup, ragged last round) against the recompute kernel of the same library
+    (k_layer_apply / _m: mixes X itself) with the same folded weights: two independent implementations of stsgcn.py:94-116's
+    forward.  The output sits inside a guarded buffer."""
     from coskad_amd import ops
-    T, V = 12, 17
+    T = 12
     g = torch.Generator().manual_seed(Ci * 7 + Co + B)
     x = (torch.randn(B, Ci, T, V, generator=g)).cuda()
     A = ((torch.rand(T, V, V, generator=g) * 2 - 1) / V ** 0.5).cuda()
