@@ -337,6 +337,171 @@ __global__ __launch_bounds__(256, 2) void k_bwd_stats_bpc(const float* __restric
   for (int e = tid; e < E; e += 256) dst[e] = lds[e];
 }
 
+
+// The same sums on layouts other than 12 x 17: nothing in them sees frames or joints, so k_bwd_stats_bpc's scheme runs over a
+// clip's FLAT T V positions, templated on T V (built for the 25-joint layout, T V = 300).  The image holds up to 32 rows of dU
+// at a time (64 output channels: two passes, the B side -- Z's 16-row groups, then PReLU(U_prev)'s -- streamed through the two
+// windows once per pass, the second time from L2): (32 + 2 x 16) x 302 floats = 77 KB per workgroup, two workgroups per CU.
+template <int TVg, int CT, int OT>
+__global__ __launch_bounds__(256, 2) void k_bwd_stats_flat(const float* __restrict__ in, const float* __restrict__ Zg,
+                                                          const float* __restrict__ dU, const float* __restrict__ in_slope,
+                                                          float* __restrict__ partials, int B) {
+  static_assert(TVg % 4 == 0, "rows are staged as float4");
+  constexpr int Ci = 16 * CT, Co = 16 * OT, NG = 2 * CT, E = 2 * Co * Ci + Co;
+  constexpr int OTP = OT < 2 ? OT : 2, NP = OT / OTP;    // dU tiles per pass, passes
+  constexpr int R4 = TVg / 4, LDg = TVg + 2;             // float4 per row; row stride of the image and the windows
+  constexpr int Q4 = 4 * R4, NQ = (Q4 + 255) / 256;      // float4 of a quarter (4 rows), pieces per thread
+  constexpr int N4 = 16 * OTP * R4, XL = (N4 + 255) / 256;   // float4 of a pass's dU rows, pieces per thread
+  constexpr int NM = (TVg + 7) / 8;                      // double k-steps
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* r1 = lds;                       // dU image: 32 rows
+  float* w0 = lds + 32 * LDg;            // two 16-row windows
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto geo = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return Lane{l & 15, l >> 4};
+  };
+  const bool pre = in_slope != nullptr;
+  const float a_in = pre ? in_slope[0] : 0.f;
+  auto clip_res = [&](const float* base, int c, int rows) {
+    const bool in_range = c < B;
+    return make_res(base + (size_t)(in_range ? c : 0) * rows * TVg, in_range ? rows * TVg * 4u : 0u);
+  };
+  float4 gq[4][NQ];
+  auto qload = [&](const BufRes& res, int row0, int q) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + 256 * i;
+      gq[q][i] = buf_load4(res, e < Q4 ? e * 16 : 0x7ffffff0, (row0 + 4 * q) * R4 * 16);
+    }
+  };
+  auto qstore = [&](float* win, int q, bool act) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = tid + 256 * i;
+      float4 v = gq[q][i];
+      if (act) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+      const int row = e / R4, col = 4 * (e - row * R4);
+      // (pieces beyond the quarter: both halves to the padding columns of the window's last row)
+      *reinterpret_cast<float2*>(win + (e < Q4 ? (4 * q + row) * LDg + col : 15 * LDg + TVg)) = float2{v.x, v.y};
+      *reinterpret_cast<float2*>(win + (e < Q4 ? (4 * q + row) * LDg + col + 2 : 15 * LDg + TVg)) = float2{v.z, v.w};
+    }
+  };
+  float4 xs[XL];
+  auto xload = [&](const BufRes& r, int row0) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) xs[i] = buf_load4(r, (tid + 256 * i) < N4 ? (tid + 256 * i) * 16 : 0x7ffffff0, row0 * R4 * 16);
+  };
+  f32x4 acc[NP][NG][OTP];
+  float rs[NP][OTP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int c = 0; c < OTP; ++c) acc[p][g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < OTP; ++c) rs[p][c] = 0.f;
+  }
+
+  int clip = blockIdx.x;
+  xload(clip_res(dU, clip, Co), 0);
+  {
+    const BufRes z0 = clip_res(Zg, clip, Ci);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qload(z0, 0, q);
+  }
+  for (; clip < B; clip += gridDim.x) {
+    const BufRes zres = clip_res(Zg, clip, Ci), xres = clip_res(in, clip, Ci), dures = clip_res(dU, clip, Co);
+    const BufRes znext = clip_res(Zg, clip + gridDim.x, Ci), dunext = clip_res(dU, clip + gridDim.x, Co);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      // group g of this pass: Z rows 16g .. (g < CT), then the layer input's; beyond: the first group of the next pass / clip
+      auto gload = [&](int g, int q) {
+        if (g < CT) qload(zres, 16 * g, q);
+        else if (g < NG) qload(xres, 16 * (g - CT), q);
+        else qload(p + 1 < NP ? zres : znext, 0, q);
+      };
+      __syncthreads();                                   // the previous pass's readers of the image and window 0 are done
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        const int e4 = tid + 256 * i;
+        const int row = e4 / R4, col = 4 * (e4 - row * R4);
+        *reinterpret_cast<float2*>(r1 + (e4 < N4 ? row * LDg + col : TVg)) = float2{xs[i].x, xs[i].y};
+        *reinterpret_cast<float2*>(r1 + (e4 < N4 ? row * LDg + col + 2 : TVg)) = float2{xs[i].z, xs[i].w};
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        qstore(w0, q, false);
+        gload(1, q);
+      }
+      if (p + 1 < NP) xload(dures, 16 * OTP * (p + 1));  // the next pass's rows / the next clip's: a whole pass of MFMAs to arrive
+      else xload(dunext, 0);
+      __syncthreads();                                   // the image holds the pass's dU rows, window 0 group 0
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        // (window (g + 1) & 1 was last read in group g - 1: the barrier at its end has passed)
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            qstore(w0 + ((g + 1) & 1) * 16 * LDg, q, g + 1 >= CT && pre);
+            gload(g + 2, q);
+          }
+        }
+        const Lane L = geo();
+        const float* pb = w0 + (g & 1) * 16 * LDg + L.j * LDg + 2 * L.q;
+        const float* pa = r1 + L.j * LDg + 2 * L.q;
+        for (int m = wave; m < NM; m += 4) {
+          const bool ok = 8 * m + 2 * L.q < TVg;         // (beyond the row: the next row / the padding -- masked)
+          float2 b = *reinterpret_cast<const float2*>(pb + 8 * m);
+          b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
+#pragma unroll
+          for (int c = 0; c < OTP; ++c) {
+            float2 a = *reinterpret_cast<const float2*>(pa + 16 * c * LDg + 8 * m);
+            a.x = ok ? a.x : 0.f; a.y = ok ? a.y : 0.f;
+            acc[p][g][c] = mfma(a.x, b.x, acc[p][g][c]);
+            acc[p][g][c] = mfma(a.y, b.y, acc[p][g][c]);
+            if (g == 0) rs[p][c] += a.x + a.y;
+          }
+        }
+        if (g + 1 < NG) __syncthreads();                 // group g + 1 is staged; every wave has left window g & 1
+      }
+    }
+  }
+  // ---- the workgroup's sums: the waves add theirs into ONE [P][Q][s] row in LDS one after another (fixed order) ----------------
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) lds[e] = 0.f;
+  __syncthreads();
+  const Lane L = geo();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int c = 0; c < OTP; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int o = 16 * (OTP * p + c) + 4 * L.q + r;
+              lds[(g < CT ? 0 : Co * Ci) + o * Ci + 16 * (g < CT ? g : g - CT) + L.j] += acc[p][g][c][r];
+            }
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int c = 0; c < OTP; ++c) {
+          const float t = quad_sum(rs[p][c]);
+          if (L.q == 0) lds[2 * Co * Ci + 16 * (OTP * p + c) + L.j] += t;
+        }
+    }
+    __syncthreads();
+  }
+  float* dst = partials + (size_t)blockIdx.x * E;
+  for (int e = tid; e < E; e += 256) dst[e] = lds[e];
+}
+
 }  // namespace fs
 
 // Used where it wins (B = 4096, in-step timings): 32 -> 16 channels 54 vs 73 us, 16 -> 32 channels 44-55 vs 55 us; at
@@ -397,6 +562,36 @@ int launch_bwd_stats_bpc(const float* in, const float* Zg, const float* dU, cons
   }
 #undef LAUNCH_FSB
   return check_launch("bwd_stats_bpc");
+}
+
+
+// Flat-position form for other layouts (the 25-joint one): 16 / 32 input, 16 / 32 / 64 output channels.  *rows_out <= 512.
+bool bwd_stats_flat_ok(int TV_, int Ci, int Co) { return TV_ == 300 && (Ci == 16 || Ci == 32) && (Co == 16 || Co == 32 || Co == 64); }
+
+int launch_bwd_stats_flat(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
+                          int Ci, int Co, int TV_, hipStream_t st, int* rows_out) {
+  if (!bwd_stats_flat_ok(TV_, Ci, Co)) return fail(COSKAD_ERR_SHAPE, "bwd_stats_flat: unsupported shape (%d positions, %d -> %d)", TV_, Ci, Co);
+  constexpr int TVg = 300;
+  const size_t lds = (size_t)64 * (TVg + 2) * sizeof(float);
+  const int grid = B < 512 ? B : 512;
+  *rows_out = grid;
+#define LAUNCH_FSF(CT, OT)                                                                                       \
+  do {                                                                                                           \
+    auto k = fs::k_bwd_stats_flat<TVg, CT, OT>;                                                                  \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Zg, dU, in_slope, partials, B);                    \
+  } while (0)
+  {
+    ProbeScope probe(KID_BWD_REDUCE, Ci, Co, st);
+    if (Ci == 16 && Co == 16) LAUNCH_FSF(1, 1);
+    else if (Ci == 16 && Co == 32) LAUNCH_FSF(1, 2);
+    else if (Ci == 16 && Co == 64) LAUNCH_FSF(1, 4);
+    else if (Ci == 32 && Co == 16) LAUNCH_FSF(2, 1);
+    else if (Ci == 32 && Co == 32) LAUNCH_FSF(2, 2);
+    else LAUNCH_FSF(2, 4);
+  }
+#undef LAUNCH_FSF
+  return check_launch("bwd_stats_flat");
 }
 
 }  // namespace coskad

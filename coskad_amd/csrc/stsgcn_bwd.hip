@@ -1175,6 +1175,9 @@ bool bwd_stats_ring_ok(int T_, int V_, int Ci, int Co);
 int launch_bwd_stats_ring(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
                           int Ci, int Co, hipStream_t st, int* rows_out);
 bool bwd_stats_bpc_ok(int T_, int V_, int Ci, int Co);
+bool bwd_stats_flat_ok(int TV_, int Ci, int Co);
+int launch_bwd_stats_flat(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
+                          int Ci, int Co, int TV_, hipStream_t st, int* rows_out);
 int launch_bwd_stats_bpc(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
                          int Ci, int Co, hipStream_t st, int* rows_out);
 // first_layer.hip
@@ -1320,6 +1323,13 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
       // default geometry, 32 input channels and a wide output (the top layer): one clip per workgroup (fused_stats.hip)
       int rows = 0;
       if ((rc = launch_bwd_stats_bpc(in, Zg, dU, in_slope, w.partials, B, Ci, Co, st, &rows))) return rc;
+      hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
+      if ((rc = check_launch("bwd_reduce_partials"))) return rc;
+      if (stats_rows_out) *stats_rows_out = rows;
+    } else if (Zg && bwd_stats_flat_ok(T * V, Ci, Co)) {
+      // the 25-joint layout: the same scheme over flat positions (fused_stats.hip)
+      int rows = 0;
+      if ((rc = launch_bwd_stats_flat(in, Zg, dU, in_slope, w.partials, B, Ci, Co, T * V, st, &rows))) return rc;
       hipLaunchKernelGGL(k_reduce_partials_d, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, w.partials, rows, E, red_of(rows, E));
       if ((rc = check_launch("bwd_reduce_partials"))) return rc;
       if (stats_rows_out) *stats_rows_out = rows;

@@ -368,3 +368,32 @@ def test_adam_and_reg():
         opt.step()
         ops.adam(ph, dev(gr), m, v, dev(mask), 1e-2, 0.9, 0.999, 1e-8, step, reg_coef=alpha * 2 * reg_scale)
     np.testing.assert_allclose(ph.cpu().numpy(), pt.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("Ci,Co,V,B", [(32, 64, 25, 1027), (16, 32, 25, 515), (32, 16, 25, 1025), (16, 16, 25, 9), (32, 32, 25, 3),
+                                       (16, 64, 25, 30), (32, 64, 17, 1031), (32, 32, 17, 40), (16, 32, 17, 700), (32, 16, 17, 600)])
+def test_bwd_stats_kernels_vs_torch(Ci, Co, V, B):
+    """Stage 1 of the layer backward alone (coskad_layer_bwd_stats_f32: the batch reductions behind both BatchNorm backward folds,
+    stsgcn.py:94-116 under autograd) on the stored-Z path -- csrc/fused_stats.hip: one clip per workgroup at 12 x 17 with 32 input
+    channels and a wide output, flat positions on the 25-joint layout, wave-per-clip otherwise -- against fp64 einsums:
+    P = sum dU Z^T, Q = sum dU PReLU(x)^T, s = sum dU.  Ragged batches (several clips per workgroup, partial last round)."""
+    from coskad_amd import ops
+    T = 12
+    g = torch.Generator().manual_seed(Ci + 3 * Co + V + B)
+    x = dev(torch.randn(B, Ci, T, V, generator=g))
+    Z = dev(torch.randn(B, Ci, T, V, generator=g))
+    dU = dev(torch.randn(B, Co, T, V, generator=g) * 0.3)
+    A = dev((torch.rand(T, V, V, generator=g) * 2 - 1) / V ** 0.5)
+    Tm = dev((torch.rand(V, T, T, generator=g) * 2 - 1) / T ** 0.5)
+    sl = dev(torch.tensor([0.2]))
+    ws = torch.empty(ops.layer_bwd_ws_bytes(B, Ci, Co, T, V), dtype=torch.uint8, device="cuda")
+    buf, rows = ops.layer_bwd_stats(x, dU, A, Tm, sl, True, ws, Z=Z)
+    assert rows > 0
+    got = ops.chain_sums(buf, rows, Ci, Co).cpu().numpy()
+    X = torch.where(x > 0, x, 0.2 * x).double()
+    d = dU.double()
+    P = torch.einsum("botv,bctv->oc", d, Z.double()).reshape(-1)
+    Q = torch.einsum("botv,bctv->oc", d, X).reshape(-1)
+    s = d.sum(dim=(0, 2, 3))
+    want = torch.cat([P, Q, s]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
