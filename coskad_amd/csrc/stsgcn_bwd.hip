@@ -870,7 +870,8 @@ __global__ __launch_bounds__((Geo<T, V>::Block), (V <= 17 ? 6 : 4)) void k_bwd_g
                                                           const float* __restrict__ Tw,
                                                           const float* __restrict__ in_slope,
                                                           float* __restrict__ partials, int B, int Ci,
-                                                          int NB
+                                                          int NB, float* __restrict__ dX_out,
+                                                          const float* __restrict__ dX_add
 #ifdef COSKAD_ABLATE
                                                           , int abl
 #endif
@@ -1011,6 +1012,33 @@ __global__ __launch_bounds__((Geo<T, V>::Block), (V <= 17 ? 6 : 4)) void k_bwd_g
 #pragma unroll
               for (int tb = 0; tb < NTT; ++tb)
                 accT[vv][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ta], b[u][tb], accT[vv][ta][tb], 0, 0, 0);
+        }
+      }
+    }
+    if (dX_out) {
+      // the adjoint mix's other half rides here: the second image holds dY = spatial^T(dZ) -- temporal^T of it is the input
+      // gradient of ConvTemporalGraphical (+ an addend: the identity residual's gradient), written in place of a k_gcn launch
+      // that would read dZ a second time
+      lds_barrier();                                 // every wave has read dY
+      temporal_mfma<T, V, true>(img2, rows, TwL);
+      lds_barrier();
+      if constexpr (TV % 4 == 0) {
+        float4* g4 = reinterpret_cast<float4*>(dX_out + (size_t)clip0 * Ci * TV);
+        const float4* a4 = dX_add ? reinterpret_cast<const float4*>(dX_add + (size_t)clip0 * Ci * TV) : nullptr;
+        const int n4 = (rows * TV) >> 2;
+        for (int i = threadIdx.x; i < n4; i += kBlock) {
+          const int e = i << 2;
+          const int row = e / TV, col = e - row * TV;
+          const float* sp = img2 + row * LD + col;
+          float4 v = {sp[0], sp[1], sp[2], sp[3]};
+          if (a4) { const float4 w = a4[i]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+          g4[i] = v;
+        }
+      } else {
+        float* gp = dX_out + (size_t)clip0 * Ci * TV;
+        for (int e = threadIdx.x; e < rows * TV; e += kBlock) {
+          const int row = e / TV, col = e - row * TV;
+          gp[e] = img2[row * LD + col] + (dX_add ? dX_add[(size_t)clip0 * Ci * TV + e] : 0.f);
         }
       }
     }
@@ -1251,9 +1279,11 @@ static int launch_layer_gcn_params(const float* in, const float* in_slope, const
 #ifdef COSKAD_ABLATE
     static int ablg = -1;
     if (ablg < 0) { const char* e = getenv("COSKAD_ABLG"); ablg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, rows_total, 1, NB, ablg);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, rows_total, 1, NB, (float*)nullptr,
+                       (const float*)nullptr, ablg);
 #else
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, rows_total, 1, NB);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, in, dz, Aw, Tw, in_slope, partials, rows_total, 1, NB, (float*)nullptr,
+                       (const float*)nullptr);
 #endif
   }
   int rc;
@@ -1529,7 +1559,8 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
 namespace coskad {
 template <int T, int V>
 static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* Aw, const float* Tw, float* dA,
-                                 float* dT, void* ws, int accumulate, int rows, hipStream_t st) {
+                                 float* dT, void* ws, int accumulate, int rows, hipStream_t st, float* dX = nullptr,
+                                 const float* dX_add = nullptr) {
   constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = Geo<T, V>::LD;
   const int E = T * V * V + V * T * T;
@@ -1541,9 +1572,9 @@ static int launch_gcn_bwd_params(const float* x, const float* dZ, const float* A
   auto k = k_bwd_gcn_params<T, V>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #ifdef COSKAD_ABLATE
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB, 0);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB, dX, dX_add, 0);
 #else
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, x, dZ, Aw, Tw, (const float*)nullptr, partials, rows, 1, NB, dX, dX_add);
 #endif
   hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(T * V * V, 64)), dim3(1024), 0, st, partials, grid, E, 0, T * V * V, dA, accumulate);
   hipLaunchKernelGGL(k_reduce_to_f32, dim3(ceil_div(V * T * T, 64)), dim3(1024), 0, st, partials, grid, E, T * V * V, V * T * T, dT, accumulate);
@@ -1590,6 +1621,20 @@ int coskad_gcn_bwd_params_f32(const float* x, const float* dZ, const float* A, c
   if (rows <= 0) return fail(COSKAD_ERR_ARG, "gcn_bwd_params: rows=%d", rows);
   if (ws_bytes < coskad_gcn_bwd_params_ws_bytes(T, V)) return fail(COSKAD_ERR_WORKSPACE, "gcn_bwd_params: workspace too small");
 #define CALL(T_, V_) return launch_gcn_bwd_params<T_, V_>(x, dZ, A, Tm, dA, dT, ws, accumulate, rows, stream)
+  COSKAD_DISPATCH_TV(T, V, CALL);
+#undef CALL
+}
+
+/* coskad_gcn_bwd_params_f32 AND the input gradient of ConvTemporalGraphical in one pass over dZ:
+ * dX = gcn^T(dZ) (+ dX_add, optional: same shape -- the gradient an identity residual carries beside the mix), what
+ * coskad_gcn_f32(adjoint) would compute from a second read of dZ.  The wide layers' backward (stsgcn.py:94-116 under autograd). */
+int coskad_gcn_bwd_params_dx_f32(const float* x, const float* dZ, const float* A, const float* Tm, float* dA, float* dT,
+                                 float* dX, const float* dX_add, void* ws, size_t ws_bytes, int accumulate, int rows, int T,
+                                 int V, hipStream_t stream) {
+  if (!x || !dZ || !A || !Tm || !dA || !dT || !dX || !ws) return fail(COSKAD_ERR_ARG, "gcn_bwd_params_dx: null pointer");
+  if (rows <= 0) return fail(COSKAD_ERR_ARG, "gcn_bwd_params_dx: rows=%d", rows);
+  if (ws_bytes < coskad_gcn_bwd_params_ws_bytes(T, V)) return fail(COSKAD_ERR_WORKSPACE, "gcn_bwd_params_dx: workspace too small");
+#define CALL(T_, V_) return launch_gcn_bwd_params<T_, V_>(x, dZ, A, Tm, dA, dT, ws, accumulate, rows, stream, dX, dX_add)
   COSKAD_DISPATCH_TV(T, V, CALL);
 #undef CALL
 }

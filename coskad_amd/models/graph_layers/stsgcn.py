@@ -210,16 +210,15 @@ class _WideLayerFn(torch.autograd.Function):
         Wt2 = Wt.view(Co, Ci)
         dWt = ops.conv1x1_wgrad(dCt, Z.view(B, Ci, P), torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
         dZ = ops.conv1x1(Wt2.t(), dCt)[0].view(B, Ci, Tn, V)
-        dX = ops.gcn(dZ, A, T, adjoint=True)
-        dA, dT = ops.gcn_bwd_params(X, dZ, A, T)
+        # dA, dT and dX = gcn^T(dZ) from ONE pass over dZ (csrc/stsgcn_bwd.hip: k_bwd_gcn_params writes the adjoint mix too); an
+        # identity residual's gradient joins it there instead of in an add of its own
+        dA, dT, dX = ops.gcn_bwd_params_dx(X, dZ, A, T, add=None if Wr is not None else dCr.view(B, Ci, Tn, V))
         dWr = dbr = None
         if Wr is not None:
             dWr = ops.conv1x1_wgrad(dCr, Xv, torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
             ops.conv1x1(Wr.view(Co, Ci).t(), dCr, out=dX.view(B, Ci, P), accumulate=True)
             if ctx.has_br:      # a bias in front of a BatchNorm: its gradient is the sum of a mean-free tensor (exactly 0 in training)
                 dbr = dCr.sum((0, 2)) if not ctx.training else torch.zeros(Co, device=X.device, dtype=torch.float32)
-        else:
-            dX = dX + dCr.view(B, Ci, Tn, V)
         dbt = None
         if ctx.has_bt:
             dbt = dCt.sum((0, 2)) if not ctx.training else torch.zeros(Co, device=X.device, dtype=torch.float32)

@@ -949,6 +949,20 @@ def gcn_bwd_params(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor):
     return dA, dT
 
 
+def gcn_bwd_params_dx(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor, add: Optional[Tensor] = None):
+    """(dA, dT, dX) of ConvTemporalGraphical in one pass over dZ: dX = gcn^T(dZ) (+ add, e.g. an identity residual's gradient)."""
+    N, C, T, V = x.shape
+    _chk(x, "x"); _chk(dZ, "dZ", x.shape); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T)); _chk(add, "add", x.shape, optional=True)
+    fn = _lib.lib().coskad_gcn_bwd_params_ws_bytes
+    fn.restype = ctypes.c_size_t
+    nbytes = fn(i32(T), i32(V))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dA, dT, dX = torch.empty_like(A), torch.empty_like(Tm), torch.empty_like(x)
+    call("coskad_gcn_bwd_params_dx_f32", ptr(x), ptr(dZ), ptr(A), ptr(Tm), ptr(dA), ptr(dT), ptr(dX), ptr(add), ptr(ws),
+         ctypes.c_size_t(nbytes), i32(0), i32(N * C), i32(T), i32(V), _stream())
+    return dA, dT, dX
+
+
 def adam_dev(p, g, m, v, mask, hyper, beta1, beta2, eps, gscale=1.0, reg_coef=0.0):
     """Adam with {lr, beta1^t, beta2^t} in the device tensor `hyper` (replayable in a hipGraph)."""
     for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):

@@ -327,6 +327,13 @@ int coskad_gcn_bwd_params_f32(const float* x, const float* dZ, const float* A, c
                               float* dT, void* ws, size_t ws_bytes, int accumulate, int rows, int T, int V,
                               hipStream_t stream);
 
+/* coskad_gcn_bwd_params_f32 AND the input gradient of ConvTemporalGraphical (models/graph_layers/stsgcn.py:143-156 under
+ * autograd) in one pass over dZ: dX = gcn^T(dZ) (+ dX_add, optional, same shape: the gradient an identity residual carries
+ * beside the mix) -- what coskad_gcn_f32(adjoint = 1) computes from a second read of dZ. */
+int coskad_gcn_bwd_params_dx_f32(const float* x, const float* dZ, const float* A, const float* Tm, float* dA, float* dT,
+                                 float* dX, const float* dX_add, void* ws, size_t ws_bytes, int accumulate, int rows, int T,
+                                 int V, hipStream_t stream);
+
 /* ---- bottleneck Linear (models/sts/ae.py:97-101,157) ---------------------------------- */
 
 /* z[n][j] = bias[j] + sum_k W[j][k] * PReLU_slope(U[n][k]);  slope NULL: no activation. L <= 16. */

@@ -397,3 +397,25 @@ def test_bwd_stats_kernels_vs_torch(Ci, Co, V, B):
     s = d.sum(dim=(0, 2, 3))
     want = torch.cat([P, Q, s]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("N,C,V,with_add", [(37, 64, 17, True), (5, 256, 17, False), (9, 64, 25, True), (3, 8, 18, False)])
+def test_gcn_bwd_params_dx_vs_separate_kernels(N, C, V, with_add):
+    """coskad_gcn_bwd_params_dx_f32 (dA, dT and the adjoint mix from one pass over dZ; the wide layers' backward) against
+    coskad_gcn_bwd_params_f32 + coskad_gcn_f32(adjoint) (+ the addend), ConvTemporalGraphical under autograd (stsgcn.py:143-156)."""
+    from coskad_amd import ops
+    T = 12
+    g = torch.Generator().manual_seed(N + C + V)
+    x = dev(torch.randn(N, C, T, V, generator=g))
+    dZ = dev(torch.randn(N, C, T, V, generator=g) * 0.3)
+    add = dev(torch.randn(N, C, T, V, generator=g)) if with_add else None
+    A = dev((torch.rand(T, V, V, generator=g) * 2 - 1) / V ** 0.5)
+    Tm = dev((torch.rand(V, T, T, generator=g) * 2 - 1) / T ** 0.5)
+    dA, dT, dX = ops.gcn_bwd_params_dx(x, dZ, A, Tm, add=add)
+    dA0, dT0 = ops.gcn_bwd_params(x, dZ, A, Tm)
+    dX0 = ops.gcn(dZ, A, Tm, adjoint=True)
+    if add is not None:
+        dX0 = dX0 + add
+    np.testing.assert_array_equal(dA.cpu().numpy(), dA0.cpu().numpy())
+    np.testing.assert_array_equal(dT.cpu().numpy(), dT0.cpu().numpy())
+    np.testing.assert_allclose(dX.cpu().numpy(), dX0.cpu().numpy(), rtol=1e-5, atol=1e-5)
