@@ -919,14 +919,57 @@ __global__ __launch_bounds__((Geo<T, V>::Block), (V <= 17 ? 6 : 4)) void k_bwd_g
   for (int a = 0; a < VPW; ++a) zero_acc(accT[a]);
 
   const int ntiles = ceil_div(B, NB);
+  // Wide joint layouts (V > 18: the tables + two 32-row images leave ONE block per CU, so nothing else runs while a tile's rows
+  // arrive): the NEXT tile's rows travel in registers while this tile multiplies -- dZ's from the first staging on, X's from the
+  // second (X is staged twice: the registers keep it for that) -- 24 registers for <= 32 rows per tile.
+  constexpr bool PFB = V > 18 && TV % 4 == 0;
+  constexpr int PF4 = PFB ? (32 * (TV / 4) + kBlock - 1) / kBlock : 1;
+  const bool pf = PFB && NB * Ci <= 32;
+  float4 px[PF4], pz[PF4];
+  auto pf_load = [&](const float* g, int rows_, float4 (&r)[PF4]) {
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const int n4 = (rows_ * TV) >> 2;
+#pragma unroll
+    for (int u = 0; u < PF4; ++u) {
+      const int i = threadIdx.x + u * kBlock;
+      r[u] = i < n4 ? g4[i] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto pf_store = [&](const float4 (&r)[PF4], float* img, int rows_, bool act) {
+    const int n4 = (rows_ * TV) >> 2;
+#pragma unroll
+    for (int u = 0; u < PF4; ++u) {
+      const int i = threadIdx.x + u * kBlock;
+      if (i < n4) {
+        const int e = i << 2;
+        const int row = e / TV, col = e - row * TV;
+        float4 v = r[u];
+        if (act) { v.x = prelu_f(v.x, a_in); v.y = prelu_f(v.y, a_in); v.z = prelu_f(v.z, a_in); v.w = prelu_f(v.w, a_in); }
+        float* d = img + row * LD + col;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+  };
+  auto tile_rows = [&](int tile_) { return min(NB, B - tile_ * NB) * Ci; };
+  if (pf && (int)blockIdx.x < ntiles) {
+    pf_load(in + (size_t)blockIdx.x * NB * Ci * TV, tile_rows(blockIdx.x), px);
+    pf_load(dZ + (size_t)blockIdx.x * NB * Ci * TV, tile_rows(blockIdx.x), pz);
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int clip0 = tile * NB;
     const int nb = min(NB, B - clip0);
     const int rows = nb * Ci;
     const float* gin = in + (size_t)clip0 * Ci * TV;
+    const int tnext = tile + gridDim.x;
     lds_barrier();
-    if (!(abl & 64)) stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
-    if (!(abl & 1)) stage_rows<T, V>(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
+    if (pf) {
+      pf_store(px, img1, rows, pre);
+      pf_store(pz, img2, rows, false);
+      if (tnext < ntiles) pf_load(dZ + (size_t)tnext * NB * Ci * TV, tile_rows(tnext), pz);
+    } else {
+      if (!(abl & 64)) stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
+      if (!(abl & 1)) stage_rows<T, V>(dZ + (size_t)clip0 * Ci * TV, img2, rows * TV, false, 0.f);
+    }
     lds_barrier();
     if (!(abl & 2)) temporal_mfma<T, V, false>(img1, rows, TwL);  // Y = temporal(X)
     lds_barrier();
@@ -983,7 +1026,10 @@ __global__ __launch_bounds__((Geo<T, V>::Block), (V <= 17 ? 6 : 4)) void k_bwd_g
     }
     lds_barrier();
     if (!(abl & 8)) spatial_mfma<T, V, true>(img2, rows, AwL);  // dY = spatial^T(dZ)
-    if (!(abl & 16)) stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);  // X again (img1 is free: dA is done)
+    if (pf) {                                                          // X again (img1 is free: dA is done)
+      pf_store(px, img1, rows, pre);
+      if (tnext < ntiles) pf_load(in + (size_t)tnext * NB * Ci * TV, tile_rows(tnext), px);
+    } else if (!(abl & 16)) stage_rows<T, V>(gin, img1, rows * TV, pre, a_in);
     lds_barrier();
     // dT[v][t][q] += sum_rows X[t*V+v] dY[q*V+v]
 #pragma unroll
