@@ -1254,6 +1254,10 @@ int launch_bwd_stats_flat(const float* in, const float* Zg, const float* dU, con
                           int Ci, int Co, int TV_, hipStream_t st, int* rows_out);
 int launch_bwd_stats_bpc(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
                          int Ci, int Co, hipStream_t st, int* rows_out);
+// gcn_params_bpc.hip
+bool gcn_params_bpc_ok(int T_, int V_);
+int launch_gcn_params_bpc(const float* in, const float* in_slope, const float* dz, const float* Aw, const float* Tw, float* partials,
+                          int rows_total, int T_, int V_, hipStream_t st, int* rows_out);
 // first_layer.hip
 bool first_layer_ok(int T_, int V_, int Ci, int Co);
 int launch_first_stats(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B, int Ci,
@@ -1310,6 +1314,17 @@ static int launch_layer_gcn_params(const float* in, const float* in_slope, const
   // of the [B*C_in, T*V] matrix: 16-row tiles (one MFMA row tile) keep two images + tables under a third of the LDS
   // -> three blocks per CU.  The kernel is told "C_in = 1, B = rows".
   const int rows_total = B * Ci;
+  if (gcn_params_bpc_ok(T, V)) {
+    // the 25-joint layout: one 32-row tile per four-wave workgroup, the tables as operands from L2 (gcn_params_bpc.hip)
+    int rows_p = 0, rc_;
+    {
+      ProbeScope probe(KID_GCN_PARAMS, Ci, Co_tag, st);
+      if ((rc_ = launch_gcn_params_bpc(in, in_slope, dz, Aw, Tw, partials, rows_total, T, V, st, &rows_p))) return rc_;
+    }
+    hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(E, kGcnCols) + (dap ? 1 : 0)), dim3(1024), 0, st, partials, rows_p, T * V * V,
+                       V * T * T, dA, dT, dap, ndap, dslope, accumulate);
+    return check_launch("bwd_gcn_reduce");
+  }
   const int rt = kBlock > 512 ? 32 : 16;       // (16-wave blocks, one per CU: twice the rows per barrier round; 3.20 -> 3.16 ms on the 25-joint step)
   const int RTILE = rows_total < rt ? rows_total : rt;
   const size_t lds = ((size_t)2 * RTILE * LD + (size_t)T * V * V + (size_t)V * T * T) * sizeof(float);
