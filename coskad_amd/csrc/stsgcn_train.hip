@@ -269,6 +269,10 @@ static int pick_nb_rows(int rows_per_clip, int B, int LD, int budget_bytes) {
 // first_layer.hip
 int launch_first_moments(const float* in, const float* Aw, const float* Tw, const float* in_slope, float* partials, int B, int Ci,
                          int T, int V, float* Zout, int max_rows, hipStream_t st, int* rows_out);
+// fwd_moments_bpc.hip
+bool fwd_moments_bpc_ok(int T_, int V_, int Ci);
+int launch_fwd_moments_bpc(const float* in, const float* Aw, const float* Tw, const float* in_slope, float* partials, int B, int Ci,
+                           int T_, int V_, int need_x, float* Zout, hipStream_t st, int* rows_out);
 
 size_t train_stats_ws_bytes(int Ci) {
   const size_t E = 2 * ((size_t)Ci * Ci + Ci);
@@ -330,6 +334,11 @@ static int launch_train_stats(const float* in, const float* Aw, const float* Tw,
   if (Zout && Ci <= 4 && TV % 4 == 0) {
     // a handful of input channels (the first layer): plain FMAs, one clip per wave (first_layer.hip)
     int rc1 = launch_first_moments(in, Aw, Tw, in_slope, partials, B, Ci, T, V, Zout, kMaxGrid, st, &rows);
+    if (rc1) return rc1;
+  } else if (Zout && fwd_moments_bpc_ok(T, V, Ci)) {
+    // the 25-joint layout, 16 / 32 channels: one clip per four-wave workgroup, mixing operands in registers (fwd_moments_bpc.hip)
+    ProbeScope probe(KID_FWD_MOMENTS, Ci, Co, st);
+    int rc1 = launch_fwd_moments_bpc(in, Aw, Tw, in_slope, partials, B, Ci, T, V, need_x, Zout, st, &rows);
     if (rc1) return rc1;
   } else {
 #define LAUNCH_M(NTC)                                                                           \
