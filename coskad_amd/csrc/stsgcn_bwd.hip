@@ -1254,6 +1254,11 @@ int launch_bwd_stats_flat(const float* in, const float* Zg, const float* dU, con
                           int Ci, int Co, int TV_, hipStream_t st, int* rows_out);
 int launch_bwd_stats_bpc(const float* in, const float* Zg, const float* dU, const float* in_slope, float* partials, int B,
                          int Ci, int Co, hipStream_t st, int* rows_out);
+// bwd_data_bpc.hip
+bool bwd_data_bpc_ok(int T_, int V_, int Ci, int Co);
+int launch_bwd_data_bpc(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw, const float* coef,
+                        const float* in_slope, float* dIn, float* dZout, float* dap, int B, int Ci, int Co, int T_, int V_,
+                        hipStream_t st, int* rows_out);
 // gcn_params_bpc.hip
 bool gcn_params_bpc_ok(int T_, int V_);
 int launch_gcn_params_bpc(const float* in, const float* in_slope, const float* dz, const float* Aw, const float* Tw, float* partials,
@@ -1541,7 +1546,15 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   // 3. data path
   int grid_d;
   const float* dap_sum = nullptr;   // block partials of the producer's slope gradient (summed by stage 4's reduce)
-  {
+  if (Zg && dIn && !dz_ext && bwd_data_bpc_ok(T, V, Ci, Co)) {
+    // the 25-joint layout, stored Z: one clip per four-wave workgroup (bwd_data_bpc.hip)
+    float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
+    {
+      ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
+      if ((rc = launch_bwd_data_bpc(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.dz, dap, B, Ci, Co, T, V, st, &grid_d))) return rc;
+    }
+    dap_sum = dap;
+  } else {
     int NB = Ci >= 32 ? 1 : 32 / Ci;
     if (NB > B && !(Ci == 16 && dIn != nullptr)) NB = B;   // (the two-clip single-read kernel keeps its 32-row image)
     const int CiP = round_up(Ci, 16), KZ = round_up(Ci, 4), K1 = round_up(Co, 4);

@@ -149,14 +149,17 @@ def test_first_layer_backward_stored_z_vs_oracle(Ci, Co, V, B):
         np.testing.assert_allclose(a, b, rtol=5e-4, atol=5e-5 * max(np.abs(b).max(), 1e-9) + 2e-5 * gmax, err_msg=k)
 
 
-@pytest.mark.parametrize("Ci,Co,B", [(32, 64, 1031), (16, 32, 2053), (32, 16, 1026), (16, 16, 771), (16, 64, 1537), (32, 32, 800)])
-def test_fused_backward_ragged_batch_vs_split_kernels(Ci, Co, B):
-    """Stored-Z path (csrc/fused_bwd_bpc.hip: one clip per workgroup, several clips per workgroup, ragged last round) against the
-    recompute path of the same library (k_bwd_reduce / k_bwd_data / k_bwd_gcn_params: block-per-tile kernels, no stored Z):
-    two independent implementations of stsgcn.py:94-116's autograd.  dIn sits inside a guarded buffer: the fused kernel
-    addresses clips through bounds-checked buffer descriptors and must not write a byte outside the tensor."""
+@pytest.mark.parametrize("Ci,Co,B,V", [(32, 64, 1031, 17), (16, 32, 2053, 17), (32, 16, 1026, 17), (16, 16, 771, 17), (16, 64, 1537, 17),
+                                       (32, 32, 800, 17), (32, 64, 515, 25), (16, 32, 1027, 25), (32, 16, 600, 25), (16, 16, 5, 25),
+                                       (16, 64, 40, 25), (32, 32, 513, 25)])
+def test_fused_backward_ragged_batch_vs_split_kernels(Ci, Co, B, V):
+    """Stored-Z path (17 joints: csrc/fused_bwd.hip, one kernel, one clip per workgroup; 25 joints: csrc/fused_stats.hip flat
+    reductions, bwd_data_bpc.hip, gcn_params_bpc.hip; several clips per workgroup, ragged last round) against the recompute path
+    of the same library (k_bwd_reduce / k_bwd_data / k_bwd_gcn_params: block-per-tile kernels, no stored Z): two independent
+    implementations of stsgcn.py:94-116's autograd.  dIn sits inside a guarded buffer: the clip-per-workgroup kernels must not
+    write a byte outside the tensor."""
     from coskad_amd import ops
-    T, V = 12, 17
+    T = 12
     st = make_layer_state(Ci, Co, V, seed=Ci + Co)
     g = torch.Generator().manual_seed(B)
     x_pre = dev(torch.randn(B, Ci, T, V, generator=g))
