@@ -10,7 +10,8 @@ import re
 from typing import Dict, List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoskad_hip.so")
+# COSKAD_LIB: another build of the same library (tools/ab_fused.sh: timing-only A/B variants); the shipped path otherwise
+LIB_PATH = os.environ.get("COSKAD_LIB") or os.path.join(_HERE, "libcoskad_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "coskad_hip.h")
 
 _lib = None

@@ -308,6 +308,14 @@ static int btl_chunks(int B, int K) {
   return s < 1 ? 1 : s;
 }
 
+// every reduction of the bottleneck backward in one launch (also used by btlnk_chain.hip)
+int launch_btlnk_reduce(const float* partials, int P, size_t E, float* out, const float* dz, int B, int L, float* db,
+                        const float* dap, int nda, float* dslope, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(k_btlnk_reduce, dim3((unsigned)((E + 255) / 256) + L + 1), dim3(256), 0, stream, partials, P, E, out, dz, B, L,
+                     db, dap, nda, dslope, accumulate);
+  return check_launch("btlnk_bwd_reduce");
+}
+
 }  // namespace coskad
 
 using namespace coskad;
@@ -365,10 +373,7 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
   hipLaunchKernelGGL(k_btlnk_bwd, dim3(gx, S), dim3(kBtlBlock), 0, stream, U, W, dz, slope, dU, dWp, dap, B, K, L, chunk);
   int rc = check_launch("btlnk_bwd");
   if (rc) return rc;
-  const size_t E = (size_t)L * K;
-  hipLaunchKernelGGL(k_btlnk_reduce, dim3((unsigned)((E + 255) / 256) + L + 1), dim3(256), 0, stream, dWp, S, E, dW, dz, B,
-                     L, db, dap, gx * S, (dslope && slope) ? dslope : nullptr, accumulate);
-  return check_launch("btlnk_bwd_reduce");
+  return launch_btlnk_reduce(dWp, S, (size_t)L * K, dW, dz, B, L, db, dap, gx * S, (dslope && slope) ? dslope : nullptr, accumulate, stream);
 }
 
 }  // extern "C"

@@ -210,6 +210,8 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
 STORE_Z = True
 # backward: the data kernel of layer 2 also forms the batch reductions of layer 1 (csrc/fused_bwd.hip, NS = 1) where the shapes allow
 FUSE_BELOW = True
+# backward: the bottleneck's backward also forms the batch reductions of the top layer (csrc/btlnk_chain.hip) where the shapes allow
+FUSE_TOP = False
 # with the stored-Z path: layer i's apply kernel also produces layer i+1's Z and BatchNorm moment partials where
 # csrc/fused_apply_next.hip takes the shape (tests flip it to cover the separate statistics pass)
 FUSE_NEXT = True
@@ -236,21 +238,41 @@ class SideStream:
             self.ws = torch.empty(ws_bytes, device=device, dtype=torch.uint8)
 
 
+def btlnk_backward(ctx: Optional[ChainCtx], layers: List[LayerTensors], U: Tensor, W: Tensor, dz: Tensor, slope: Optional[Tensor],
+                   dW: Tensor, db: Optional[Tensor], dslope: Optional[Tensor], ws: Workspace):
+    """Backward of the bottleneck Linear on the chain's output U (ae.py:97-101) -> (dU, top_stats).  Where the shapes allow
+    (csrc/btlnk_chain.hip: a 64-channel top layer over 16 / 32 channels, stored Z) the same pass forms the TOP layer's batch
+    reductions; `top_stats` is then chain_backward's `stats_in`, else None."""
+    B = U.shape[0]
+    K, L = U.numel() // B, W.shape[0]
+    i = len(layers) - 1 if layers else -1
+    Z = ctx.zs[i] if (ctx is not None and ctx.zs and i >= 0) else None
+    if (FUSE_TOP and Z is not None and U.dim() == 4 and layers[i].Wr is not None and L <= 16
+            and ops.btlnk_bwd_chain_ok(K, U.shape[2] * U.shape[3], layers[i].Ci)):
+        in_slope = layers[i - 1].slope if i > 0 else ctx.in_slope
+        return ops.btlnk_bwd_chain(U, W, dz, slope, dW, db, dslope, ws, ctx.inputs[i], Z, in_slope)
+    buf = ws.get(ops.btlnk_bwd_ws_bytes(B, K, L), U.device)
+    return ops.btlnk_bwd(U, W, dz, slope, dW, db, dslope, buf), None
+
+
 def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Workspace,
                    grads: List[Dict[str, Tensor]], need_dx: bool, accumulate: bool = False,
-                   side: Optional[SideStream] = None) -> Optional[Tensor]:
+                   side: Optional[SideStream] = None, stats_in=None) -> Optional[Tensor]:
     """Backward through the chain.  `grads[i]` maps A,T,Wt,bt,gt,bet,Wr,br,gr,ber,slope -> tensors to
     fill for layer i.  The slope gradient of layer i is produced while back-propagating through
     layer i+1 (its consumer); the caller owns the last layer's slope gradient.
     With `side`, dA / dT are computed on its stream (joined into the current stream before returning).
+    `stats_in`: (chain buffer, rows) of the TOP layer's batch reductions when the producer of dU formed them (btlnk_backward).
     Returns d(inputs[0]) if need_dx."""
     n = len(layers)
+    if side is not None and stats_in is not None:
+        raise ValueError("chain_backward: the side-stream path runs its own batch reductions (stats_in must be None)")
     if ctx.sync is not None and side is not None:
         raise ValueError("SyncBN runs on the main stream (side=None)")
     main = torch.cuda.current_stream() if side is not None else None
     if side is not None:
         side.done = [None, None]     # the previous call joined the side stream: nothing of it is still in flight
-    stats_in = None          # (partial rows, rows) of layer i's batch reductions, formed by layer i + 1's data kernel
+    # stats_in: (partial rows, rows) of layer i's batch reductions, formed by layer i + 1's data kernel (or by the bottleneck's)
     for i in range(n - 1, -1, -1):
         L = layers[i]
         x_in = ctx.inputs[i]
@@ -271,13 +293,15 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
                     stats_in = ops.layer_bwd_stats(x_in, dU, L.A, L.T, in_slope, L.Wr is not None, buf, Z=ctx.zs[i])
                 dist.all_reduce(ops.chain_sums(stats_in[0], stats_in[1], Ci, L.Co), group=sync)
             below = None
-            if FUSE_BELOW and ctx.zs and i > 0 and in_slope is not None and layers[i - 1].Wr is not None:
+            Zi = ctx.zs[i] if ctx.zs else None
+            if (FUSE_BELOW and Zi is not None and i > 0 and ctx.zs[i - 1] is not None and in_slope is not None
+                    and layers[i - 1].Wr is not None):
                 cb = ctx.inputs[i - 1].shape[1]
                 rows = ops.layer_bwd_below_rows(B, Ci, L.Co, cb, T, V)
                 if rows:
                     below = (ctx.inputs[i - 1], ctx.zs[i - 1], layers[i - 2].slope if i > 1 else ctx.in_slope,
                              torch.empty(ops.layer_bwd_below_floats(B, Ci, L.Co, cb, T, V), device=x_in.device, dtype=torch.float32))
-            dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate, Z=ctx.zs[i] if ctx.zs else None,
+            dIn = ops.layer_bwd(*args, need_dx=want_dx, accumulate=accumulate, Z=Zi,
                                 stats_in=stats_in, below=below, stats_count=ctx.sync_count if sync is not None else 0.0)
             stats_in = (below[3], rows) if below is not None else None
         else:

@@ -488,6 +488,43 @@ def btlnk_bwd(U, W, dz, slope, dW, db, dslope, ws, dU=None, accumulate=False):
     return dU
 
 
+def btlnk_bwd_chain_ok(K: int, TV: int, below_Ci: int) -> bool:
+    """coskad_btlnk_bwd_chain_f32 takes the shape: a 64-channel last layer over 16 / 32 input channels."""
+    fn = _lib.lib().coskad_btlnk_bwd_chain_ok
+    fn.restype = ctypes.c_int
+    return bool(fn(i32(K), i32(TV), i32(below_Ci)))
+
+
+def btlnk_bwd_chain(U, W, dz, slope, dW, db, dslope, ws, below_in, below_Z, below_in_slope, dU=None, accumulate=False):
+    """btlnk_bwd AND the top layer's backward batch reductions from one pass (csrc/btlnk_chain.hip).
+    U [B, 64, T, V]: the top layer's pre-activation; below_in / below_Z [B, Ci, T, V]: that layer's input (pre-activation of the
+    layer below + its slope) and stored gcn output.  -> (dU, (chain buffer, rows)): the second item is layer_bwd's `stats_in`.
+    `ws`: an engine.Workspace."""
+    B, Ch, T, V = U.shape
+    TV = T * V
+    K = Ch * TV
+    L = W.shape[0]
+    Ci = below_in.shape[1]
+    _chk(U, "U"); _chk(W, "W", (L, K)); _chk(dz, "dz", (B, L)); _chk(dW, "dW", (L, K))
+    _chk(db, "db", (L,), optional=True); _chk(dslope, "dslope", (1,), optional=True); _chk(slope, "slope", (1,), optional=True)
+    _chk(below_in, "below_in", (B, Ci, T, V)); _chk(below_Z, "below_Z", (B, Ci, T, V)); _chk(below_in_slope, "below_in_slope", (1,), optional=True)
+    if not btlnk_bwd_chain_ok(K, TV, Ci):
+        raise ValueError(f"btlnk_bwd_chain: shape K={K} TV={TV} Ci={Ci} not supported")
+    lib = _lib.lib()
+    lib.coskad_btlnk_bwd_chain_ws_bytes.restype = ctypes.c_size_t
+    lib.coskad_btlnk_bwd_chain_floats.restype = ctypes.c_size_t
+    need = lib.coskad_btlnk_bwd_chain_ws_bytes(i32(B), i32(K), i32(L), i32(TV))
+    buf = ws.get(need, U.device)
+    stats = torch.empty(lib.coskad_btlnk_bwd_chain_floats(i32(B), i32(TV), i32(Ci)), device=U.device, dtype=torch.float32)
+    if dU is None:
+        dU = torch.empty_like(U)
+    rows = ctypes.c_int(0)
+    call("coskad_btlnk_bwd_chain_f32", ptr(U), ptr(W), ptr(dz), ptr(slope), ptr(dU), ptr(dW), ptr(db), ptr(dslope), ptr(buf),
+         ctypes.c_size_t(_bytes(buf)), i32(1 if accumulate else 0), i32(B), i32(K), i32(L), ptr(below_in), ptr(below_Z),
+         ptr(below_in_slope), i32(Ci), i32(TV), ptr(stats), ctypes.c_size_t(_bytes(stats)), ctypes.byref(rows), _stream())
+    return dU, (stats, rows.value)
+
+
 def _cuda_f32(t: Tensor, name: str) -> None:
     if not t.is_cuda:
         raise _lib.CoskadHipError(f"{name}: expected a CUDA (ROCm) tensor, got device {t.device}; no CPU fallback")

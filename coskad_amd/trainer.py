@@ -168,15 +168,14 @@ class STSETrainStep:
             for y_in, stat, bn, lin, bname, lname in reversed(saved):
                 g = {"gamma": gv[bname + "weight"], "beta": gv[bname + "bias"], "W2": gv[lname + "weight"], "b2": gv.get(lname + "bias")}
                 dz = ops.mlp_head_bwd(y_in, stat, bn.weight, bn.bias, lin.weight, dz, g, True)
-        K = W.shape[1]
-        buf = self.ws.get(ops.btlnk_bwd_ws_bytes(B, K, W.shape[0]), x.device)
-        dU = ops.btlnk_bwd(U, W, dz, slope, gv[wname + "weight"], gv.get(wname + "bias"), self.grads[-1]["slope"], buf)
+        dU, top_stats = engine.btlnk_backward(ctx if self.side is None else None, self.layers, U, W, dz, slope, gv[wname + "weight"],
+                                              gv.get(wname + "bias"), self.grads[-1]["slope"], self.ws)
         work = None
         if self.world > 1 and self.tail_off is not None:
             # bucket 1 (87 % of the bytes: the bottleneck weight) is complete now: its all-reduce runs on the collective
             # stream while the encoder backward proceeds (SUM; the 1/W is folded into Adam)
             work = dist.all_reduce(self.fp.grad[self.tail_off:], group=self.pg, async_op=True)
-        engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False, side=self.side)
+        engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False, side=self.side, stats_in=top_stats)
         if self.world > 1:
             head = self.fp.grad if work is None else self.fp.grad[:self.tail_off]
             dist.all_reduce(head, group=self.pg)           # bucket 2: the encoder's gradients (0.12 MB)
@@ -283,15 +282,21 @@ class _FlatStack:
                 h, slope = out.detach(), None
         return h, slope, saved
 
-    def backward(self, saved, d_last: Tensor, ws: engine.Workspace, need_dx: bool) -> Optional[Tensor]:
+    def top(self, saved):
+        """(ChainCtx, layers) of the last segment when it is a tile run (engine.btlnk_backward), else (None, None)"""
+        return (saved[-1], self.segs[-1][1]) if self.segs[-1][0] == 'tile' else (None, None)
+
+    def backward(self, saved, d_last: Tensor, ws: engine.Workspace, need_dx: bool, top_stats=None) -> Optional[Tensor]:
         """d_last: gradient w.r.t. the last segment's output (pre-activation U of a tile run -- the caller owns its slope
-        gradient -- or the activated output of a wide layer)."""
+        gradient -- or the activated output of a wide layer); top_stats: the last tile run's top-layer batch reductions when
+        the producer of d_last formed them (engine.btlnk_backward)."""
         d = d_last
         for k in range(len(self.segs) - 1, -1, -1):
             seg, sv = self.segs[k], saved[k]
             first = k == 0
             if seg[0] == 'tile':
-                d = engine.chain_backward(sv, seg[1], d, ws, seg[2], need_dx=need_dx or not first)
+                d = engine.chain_backward(sv, seg[1], d, ws, seg[2], need_dx=need_dx or not first,
+                                          stats_in=top_stats if k == len(self.segs) - 1 else None)
             else:
                 xin, out, pre_u, pre_slope = sv
                 mod, prefix = seg[1], seg[2]
@@ -453,20 +458,20 @@ class STSAETrainStep:
                 for y_in, stat, bn, lin, bname, lname in reversed(mlp_saved):
                     g = {"gamma": gv[bname + "weight"], "beta": gv[bname + "bias"], "W2": gv[lname + "weight"], "b2": gv.get(lname + "bias")}
                     dHd = ops.mlp_head_bwd(y_in, stat, bn.weight, bn.bias, lin.weight, dHd, g, True)
-        K = W.shape[1]
-        buf = self.ws.get(ops.btlnk_bwd_ws_bytes(B, K, W.shape[0]), x.device)
+        tctx, tlayers = self.enc.top(enc_saved)
+        bb = lambda gW_, gb_: engine.btlnk_backward(tctx, tlayers, U, W, dHd, slope, gW_, gb_, self.enc.last_slope_grad, self.ws)
         if self.mode == 'ae':
-            dU = ops.btlnk_bwd(U, W, dHd, slope, gv["btlnk.weight"], gv.get("btlnk.bias"), self.enc.last_slope_grad, buf)
+            dU, top_stats = bb(gv["btlnk.weight"], gv.get("btlnk.bias"))
         elif graph[4] is not None:          # mlp projector: the wide first Linear of the MLP
-            dU = ops.btlnk_bwd(U, W, dHd, slope, gv["btlnk.net.0.weight"], gv.get("btlnk.net.0.bias"), self.enc.last_slope_grad, buf)
+            dU, top_stats = bb(gv["btlnk.net.0.weight"], gv.get("btlnk.net.0.bias"))
         else:
             gW = torch.empty_like(W)
             gb = torch.empty_like(b)
-            dU = ops.btlnk_bwd(U, W, dHd, slope, gW, gb, self.enc.last_slope_grad, buf)
+            dU, top_stats = bb(gW, gb)
             L = m.latent_dim
             gv["fc_mean.weight"].copy_(gW[:L]); gv["fc_var.weight"].copy_(gW[L:])
             gv["fc_mean.bias"].copy_(gb[:L]); gv["fc_var.bias"].copy_(gb[L:])
-        self.enc.backward(enc_saved, dU, self.ws, need_dx=False)
+        self.enc.backward(enc_saved, dU, self.ws, need_dx=False, top_stats=top_stats)
         if self.world > 1:
             dist.all_reduce(self.fp.grad, group=self.pg)                          # SUM; the 1 / W is folded into Adam
         ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,

@@ -351,6 +351,23 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
                          float* dW, float* db, float* dslope, void* ws, size_t ws_bytes, int accumulate,
                          int B, int K, int L, hipStream_t stream);
 
+/* The same backward AND the batch reductions of the encoder's top ST_GCNN layer (models/graph_layers/stsgcn.py:94-116 under
+ * autograd in training mode: P = sum dU Z^T, Q = sum dU PReLU(U_prev)^T, s = sum dU over clips and positions) from ONE pass
+ * (csrc/btlnk_chain.hip: K tiled position-major, so the dU tile meets Z and U_prev of the same clips and positions on chip).
+ * U is that layer's pre-activation [B, 64, TV] (K = 64 TV, TV % 4 == 0), below_in [B, below_Ci, TV] its input (pre-activation
+ * of the layer below, below_in_slope its PReLU slope or NULL), below_Z [B, below_Ci, TV] its stored gcn output; below_Ci 16 / 32.
+ * stats_out (8-byte aligned, coskad_btlnk_bwd_chain_floats(...) floats) receives the layer's backward chain buffer --
+ * *stats_rows partial rows of 2 * 64 * below_Ci + 64 floats, then their fp64 sums -- which coskad_layer_bwd_chain_f32 takes
+ * as `stats_in`.  ws: coskad_btlnk_bwd_chain_ws_bytes(B, K, L, TV) bytes.  Fixed-order sums: deterministic. */
+int coskad_btlnk_bwd_chain_ok(int K, int TV, int below_Ci);
+int coskad_btlnk_bwd_chain_rows(int B, int TV);
+size_t coskad_btlnk_bwd_chain_floats(int B, int TV, int below_Ci);
+size_t coskad_btlnk_bwd_chain_ws_bytes(int B, int K, int L, int TV);
+int coskad_btlnk_bwd_chain_f32(const float* U, const float* W, const float* dz, const float* slope, float* dU, float* dW,
+                               float* db, float* dslope, void* ws, size_t ws_bytes, int accumulate, int B, int K, int L,
+                               const float* below_in, const float* below_Z, const float* below_in_slope, int below_Ci, int TV,
+                               float* stats_out, size_t stats_out_bytes, int* stats_rows, hipStream_t stream);
+
 /* ---- batch formation from the HBM-resident window table (callers' side of the path) ----- */
 
 /* out[b, c, :] = M[t][c][0] x[s] + M[t][c][1] y[s] + M[t][c][2] with s = index[b] % N, t = index[b] / N, c < 2:

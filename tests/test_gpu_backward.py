@@ -373,6 +373,58 @@ def test_adam_and_reg():
     np.testing.assert_allclose(ph.cpu().numpy(), pt.detach().numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,Ci,V,L,with_slope,in_act", [(37, 32, 17, 16, True, True), (1031, 32, 17, 16, True, True), (5, 16, 17, 8, True, False),
+                                                        (300, 32, 25, 16, True, True), (33, 16, 25, 9, False, True), (4099, 32, 17, 16, True, True)])
+def test_bottleneck_backward_with_top_layer_reductions(B, Ci, V, L, with_slope, in_act):
+    """coskad_btlnk_bwd_chain_f32 (csrc/btlnk_chain.hip): the bottleneck backward (ae.py:97-101 under autograd) AND the top
+    layer's BatchNorm-backward batch reductions (stsgcn.py:94-116) from one position-major pass, against torch autograd for
+    dU / dW / db / dslope and fp64 einsums for P = sum dU Z^T, Q = sum dU PReLU(x)^T, s = sum dU.  Ragged chunks (B not a multiple
+    of 16), the masked last position tile (204 = 12 x 16 + 12; 300 = 18 x 16 + 12), latent sizes below 16, guard bands around dU."""
+    from coskad_amd import engine, ops
+    g = torch.Generator().manual_seed(B + Ci + V)
+    T, hid = 12, 64
+    K = hid * T * V
+    U = torch.randn(B, hid, T, V, generator=g, requires_grad=True)
+    W = (torch.randn(L, K, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(L, generator=g).requires_grad_(True)
+    a = torch.tensor([0.3], requires_grad=True)
+    X = R.prelu(U, a) if with_slope else U
+    z = R.linear(X.reshape(B, -1), W, b)
+    dz = torch.randn(B, L, generator=g)
+    (z * dz).sum().backward()
+    x_in = torch.randn(B, Ci, T, V, generator=g)
+    Zs = torch.randn(B, Ci, T, V, generator=g)
+    sl = dev(a) if with_slope else None
+    sl_in = dev(torch.tensor([0.2])) if in_act else None
+    dW = torch.full((L, K), float("nan"), device="cuda")
+    db = torch.full((L,), float("nan"), device="cuda")
+    da = torch.full((1,), float("nan"), device="cuda")
+    guard = torch.full((B + 2, hid, T, V), 7.0, device="cuda")
+    ws = engine.Workspace()
+    dU, (buf, rows) = ops.btlnk_bwd_chain(dev(U), dev(W), dev(dz), sl, dW, db, da if with_slope else None, ws, dev(x_in), dev(Zs), sl_in,
+                                          dU=guard[1:B + 1])
+    assert rows > 0
+    assert bool((guard[0] == 7.0).all()) and bool((guard[B + 1] == 7.0).all()), "dU written outside its rows"
+    close(dU, U.grad, msg="dU")
+    close(dW, W.grad, msg="dW")
+    close(db, b.grad, msg="db")
+    if with_slope:
+        close(da, a.grad, rtol=5e-4, atol_rel=1e-4, msg="dslope")
+    got = ops.chain_sums(buf, rows, Ci, hid).cpu().numpy()
+    d = U.grad.double()
+    Xb = (torch.where(x_in > 0, x_in, 0.2 * x_in) if in_act else x_in).double()
+    P = torch.einsum("botv,bctv->oc", d, Zs.double()).reshape(-1)
+    Q = torch.einsum("botv,bctv->oc", d, Xb).reshape(-1)
+    s = d.sum(dim=(0, 2, 3))
+    want = torch.cat([P, Q, s]).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+    # the same call again: bit-identical (fixed-order sums)
+    dW2 = torch.empty_like(dW)
+    dU2, (buf2, rows2) = ops.btlnk_bwd_chain(dev(U), dev(W), dev(dz), sl, dW2, None, None, ws, dev(x_in), dev(Zs), sl_in)
+    assert rows2 == rows and torch.equal(dU2, dU) and torch.equal(dW2, dW)
+    assert torch.equal(ops.chain_sums(buf2, rows, Ci, hid), ops.chain_sums(buf, rows, Ci, hid))
+
+
 @pytest.mark.parametrize("Ci,Co,V,B", [(32, 64, 25, 1027), (16, 32, 25, 515), (32, 16, 25, 1025), (16, 16, 25, 9), (32, 32, 25, 3),
                                        (16, 64, 25, 30), (32, 64, 17, 1031), (32, 32, 17, 40), (16, 32, 17, 700), (32, 16, 17, 600)])
 def test_bwd_stats_kernels_vs_torch(Ci, Co, V, B):

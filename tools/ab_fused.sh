@@ -11,13 +11,11 @@ if [ "$cmd" = build ]; then
   objs=$(ls *.o | grep -v $src.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/ff_$name.o -o ../../tools/libf_$name.so
 else
-  cp coskad_amd/libcoskad_hip.so /tmp/lib_orig.so
+  # variants are selected through COSKAD_LIB (coskad_amd/_lib.py): the shipped library is never overwritten
   for r in 1 2; do
     for v in "$@"; do
-      cp tools/libf_$v.so coskad_amd/libcoskad_hip.so
       echo -n "$v: "
-      timeout -k 10 120 python ${AB_BENCH:-tools/bench_fused.py} 2>&1 | tail -1
+      COSKAD_LIB=$PWD/tools/libf_$v.so timeout -k 10 120 python ${AB_BENCH:-tools/bench_fused.py} 2>&1 | tail -1
     done
   done
-  cp /tmp/lib_orig.so coskad_amd/libcoskad_hip.so
 fi
