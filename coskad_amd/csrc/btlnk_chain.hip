@@ -19,7 +19,13 @@
 //     position), so K is the clip axis again: A = G[clip 4 q + r][channel c][p], B = Z[clip 4 q + r][c][p] resp. the layer
 //     input's, both (row, position) ds_read_b32 of images whose position runs are 17 floats apart and whose clip stride is
 //     = 4 (mod 8) floats: conflict-free.
-//   * Z / U_prev tiles (2 C_in rows x 16 positions x 16 clips) are fetched as 64-byte runs one tile ahead, through registers.
+//   * Z / U_prev tiles (2 C_in rows x 16 positions x 16 clips) are fetched as 64-byte runs one tile ahead, through registers
+//     (at the top of phase 2); the next tile's U rows at the top of phase 1, into a second register set.  Fetching everything at
+//     one point measured 258 (top of phase 2) / 278 us (top of phase 1) against 242: the chip's workgroups run in lockstep, so
+//     what matters is that the bursts are spread over the tile.
+//   * Measured (B = 4096, 12 x 17, rocprofv3): 242 us alone against 122 + 133 us for k_btlnk_bwd + k_bwd_stats_bpc alone; in the
+//     train step 1.356 vs 1.374 ms.  MfmaUtil 31.5 % (its 76 us of fp32 MFMA issue are the floor beside 642 MB of HBM traffic),
+//     30 % of the wave cycles in s_waitcnt / barriers, 54 % waiting to issue; L2 fetch = the algorithmic bytes with the XCD remap.
 //   * Everything a workgroup sums (dW columns, P, Q, s, the slope gradient) stays in accumulators for the launch; one partial
 //     row / dW slab per workgroup, summed in fp64 in a fixed order by the reduce launches (deterministic, no atomics).
 #include "fused_ops.h"
@@ -39,6 +45,9 @@ constexpr int RSTR = 17;         // floats between the position runs of consecut
 constexpr int kThreads = 512;
 #ifndef BC_XCD
 #define BC_XCD 1    // (A/B hook: 0 = tiles dealt round-robin over the XCDs)
+#endif
+#ifndef BC_PF
+#define BC_PF 1     // U rows of the next tile fetched at the top of phase 1 (second register set) instead of the top of phase 2
 #endif
 #ifndef BC_SKIP
 #define BC_SKIP 0   // timing-only builds (tools/ab_fused.sh, AB_SRC=btlnk_chain): 1 no U loads, 2 no dU stores, 4 no Z / input loads,
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_btlnk_bwd_stats(
   // Workgroup -> (chunk, position tile).  A tile's 64-byte runs share their 128-byte lines with the neighbouring position tiles
   // (rows are 4 T V bytes, never line-aligned), so the tiles of one chunk must sit behind ONE L2: blocks b and b + 8 share an XCD
   // (observed round-robin placement: speed only), hence the bijective remap of cdna_hip_programming.md T1 -- each XCD takes a
-  // contiguous run of the chunk-major (chunk, tile) order.  Without it every line crosses the fabric twice (312 vs 2xx us).
+  // contiguous run of the chunk-major (chunk, tile) order.  Without it every line crosses the fabric twice (315 vs 254 us at B = 4096).
   const int nwg = gridDim.x, npt = (TV + PT - 1) / PT;
   int wg = blockIdx.x;
   if (BC_XCD) {
@@ -164,23 +173,26 @@ __global__ __launch_bounds__(kThreads, 1) void k_btlnk_bwd_stats(
   const float* zb = ZX + 4 * q * ZCS + c * RSTR + 8 * h;             // phase 2: ZX[clip 4 q + r][row 16 t + c][position 8 h + pl]
 
   for (int n0 = nbeg; n0 < nend; n0 += NCL) {
-    // ---- phase 1: the B-side tile into LDS; dx, dU rows, dW, the G image.  Every register set is refilled with the NEXT tile
-    // as soon as this tile has left it, so the fetches are in flight for a whole tile (issued at the top of phase 2 instead they
-    // had two thirds of one: 254 vs 2xx us) ---------------------------------------------------------------------------------------
-    zx_store(zx);
-    zx_load(n0 + NCL, zx);
+    // ---- phase 1: dx, dU rows, dW, the G image; the B-side tile into LDS ------------------------------------------------
+    float unext[8][4];
+    if (BC_PF == 2) { zx_store(zx); zx_load(n0 + NCL, zx); }
+    if (BC_PF) u_load(n0 + NCL, unext);    // in front of this tile's stores: a whole tile to arrive
     {
-      const BufRes rdu = tile_res(dU, n0, K), run = tile_res(U, n0 + NCL, K);
-      float dzb_n[4];
+      const BufRes rdu = tile_res(dU, n0, K);
+      // (eight independent MFMA chains at a time: k-step outermost for dx, clip register outermost for dW)
+      f32x4 dx[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 8; ++i) dx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) dx = mfma(dza[g], wf[i][g], dx);
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int i = 0; i < 8; ++i) dx[i] = mfma(dza[g], wf[i][g], dx[i]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
           const float u = ucur[i][r];
-          float g = dx[r], x = u;
+          float g = dx[i][r], x = u;
           if (pre) {
             da += u < 0.f ? g * u : 0.f;
             g = u > 0.f ? g : a * g;
@@ -190,16 +202,21 @@ __global__ __launch_bounds__(kThreads, 1) void k_btlnk_bwd_stats(
           if (!(BC_SKIP & 64)) gw[r * GCS + i * RSTR] = g;
           if (!(BC_SKIP & 2) || g == 123.456f) buf_store1(rdu, u_voff, (r * K + (ch0 + i) * TV) * 4, g);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ucur[i][r] = (BC_SKIP & 1) ? ((i + r) & 1 ? 1.f : -1.f) : buf_load1(run, u_voff, (r * K + (ch0 + i) * TV) * 4);
-        if (i == 7) dz_load(n0 + NCL, dza, dzb_n);       // (dza is dead behind the last dx; dzb is still the last dW's operand)
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dzb[r] = dzb_n[r];
     }
+    if (BC_PF != 2) zx_store(zx);
     lds_barrier();                         // G and the B-side tile are complete
-    // ---- phase 2: P / Q / s ---------------------------------------------------------------------------------------------------
+    // ---- phase 2: the next tile's fetches (issued from phase 1, interleaved with its stores, they measured 10 us slower), then
+    // P / Q / s ---------------------------------------------------------------------------------------------------------------
+    if (BC_PF) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ucur[i][r] = unext[i][r];
+    } else {
+      u_load(n0 + NCL, ucur);              // (dead since phase 1: the next tile travels in the same registers)
+    }
+    dz_load(n0 + NCL, dza, dzb);
+    if (BC_PF != 2) zx_load(n0 + NCL, zx);
 #pragma unroll
     for (int pl = 0; pl < 8; ++pl)
 #pragma unroll

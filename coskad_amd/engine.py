@@ -211,7 +211,7 @@ STORE_Z = True
 # backward: the data kernel of layer 2 also forms the batch reductions of layer 1 (csrc/fused_bwd.hip, NS = 1) where the shapes allow
 FUSE_BELOW = True
 # backward: the bottleneck's backward also forms the batch reductions of the top layer (csrc/btlnk_chain.hip) where the shapes allow
-FUSE_TOP = False
+FUSE_TOP = True
 # with the stored-Z path: layer i's apply kernel also produces layer i+1's Z and BatchNorm moment partials where
 # csrc/fused_apply_next.hip takes the shape (tests flip it to cover the separate statistics pass)
 FUSE_NEXT = True
