@@ -253,13 +253,43 @@ __global__ __launch_bounds__(kBtlBlock) void k_btlnk_bwd(const float* __restrict
 //   blocks [0, nE)       : out[e] (+)= sum_p partials[p][e]            (dW, 256 elements per block)
 //   blocks [nE, nE + L)  : db[j]  (+)= sum_n dz[n][j]                  (one block per latent column; db may be NULL)
 //   block  nE + L        : dslope (+)= sum of the nda block partials   (dslope may be NULL)
+//   blocks beyond        : rsum[e] = sum_p rows[p][e] in fp64, 16 columns x 16 row slices per block (the top layer's backward chain
+//                          buffer of btlnk_chain.hip: its partial rows are summed in this launch instead of one of their own)
 __global__ __launch_bounds__(256) void k_btlnk_reduce(const float* __restrict__ partials, int P, size_t E,
                                                        float* __restrict__ out, const float* __restrict__ dz,
                                                        int B, int L, float* __restrict__ db,
                                                        const float* __restrict__ dap, int nda,
-                                                       float* __restrict__ dslope, int accumulate) {
+                                                       float* __restrict__ dslope, int accumulate,
+                                                       const float* __restrict__ rows, int RP, int RE,
+                                                       double* __restrict__ rsum) {
   __shared__ double sh[256];
   const unsigned nE = (unsigned)((E + 255) / 256);
+  if (blockIdx.x > nE + L) {
+    const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = (int)(blockIdx.x - (nE + L + 1)) * 16 + col;
+    double s = 0.0;
+    if (e < RE) {
+      const float* base = rows + e;
+      int p = slice;
+      for (; p + 7 * 16 < RP; p += 8 * 16) {            // eight rows of the slice in flight, summed in row order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(p + 16 * u) * RE];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+      }
+      for (; p < RP; p += 16) s += (double)base[(size_t)p * RE];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (slice == 0 && e < RE) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += sh[col + 16 * k];
+      rsum[e] = t;
+    }
+    return;
+  }
   if (blockIdx.x < nE) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
@@ -310,9 +340,11 @@ static int btl_chunks(int B, int K) {
 
 // every reduction of the bottleneck backward in one launch (also used by btlnk_chain.hip)
 int launch_btlnk_reduce(const float* partials, int P, size_t E, float* out, const float* dz, int B, int L, float* db,
-                        const float* dap, int nda, float* dslope, int accumulate, hipStream_t stream) {
-  hipLaunchKernelGGL(k_btlnk_reduce, dim3((unsigned)((E + 255) / 256) + L + 1), dim3(256), 0, stream, partials, P, E, out, dz, B, L,
-                     db, dap, nda, dslope, accumulate);
+                        const float* dap, int nda, float* dslope, int accumulate, hipStream_t stream, const float* rows,
+                        int RP, int RE, double* rsum) {
+  const unsigned extra = rows ? (unsigned)ceil_div(RE, 16) : 0u;
+  hipLaunchKernelGGL(k_btlnk_reduce, dim3((unsigned)((E + 255) / 256) + L + 1 + extra), dim3(256), 0, stream, partials, P, E, out, dz,
+                     B, L, db, dap, nda, dslope, accumulate, rows, RP, RE, rsum);
   return check_launch("btlnk_bwd_reduce");
 }
 
@@ -373,7 +405,8 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
   hipLaunchKernelGGL(k_btlnk_bwd, dim3(gx, S), dim3(kBtlBlock), 0, stream, U, W, dz, slope, dU, dWp, dap, B, K, L, chunk);
   int rc = check_launch("btlnk_bwd");
   if (rc) return rc;
-  return launch_btlnk_reduce(dWp, S, (size_t)L * K, dW, dz, B, L, db, dap, gx * S, (dslope && slope) ? dslope : nullptr, accumulate, stream);
+  return launch_btlnk_reduce(dWp, S, (size_t)L * K, dW, dz, B, L, db, dap, gx * S, (dslope && slope) ? dslope : nullptr, accumulate, stream,
+                             nullptr, 0, 0, nullptr);
 }
 
 }  // extern "C"

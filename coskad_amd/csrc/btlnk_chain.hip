@@ -275,15 +275,6 @@ __global__ __launch_bounds__(kThreads, 1) void k_btlnk_bwd_stats(
   if (tid == 0) dap[wg] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 }
 
-// fp64 sums of the partial rows (fixed order) behind them in the chain buffer
-constexpr int kCols = 16;
-__global__ __launch_bounds__(1024) void k_chain_rows_sum(const float* __restrict__ partials, int P, int E, double* __restrict__ out) {
-  __shared__ double sh[1024];
-  const int e = blockIdx.x * kCols + (threadIdx.x % kCols);
-  const double t = column_sum_f64<kCols>(partials, P, (size_t)E, e, e < E, sh);
-  if ((int)threadIdx.x < kCols && e < E) out[e] = t;
-}
-
 struct Plan {
   int npt, S, chunk;
 };
@@ -304,7 +295,8 @@ static inline size_t sums_offset(int rows, int E) { return ((size_t)rows * E + 1
 
 // bottleneck.hip
 int launch_btlnk_reduce(const float* partials, int P, size_t E, float* out, const float* dz, int B, int L, float* db,
-                        const float* dap, int nda, float* dslope, int accumulate, hipStream_t stream);
+                        const float* dap, int nda, float* dslope, int accumulate, hipStream_t stream, const float* rows,
+                        int RP, int RE, double* rsum);
 }  // namespace coskad
 
 using namespace coskad;
@@ -368,12 +360,10 @@ int coskad_btlnk_bwd_chain_f32(const float* U, const float* W, const float* dz, 
                        below_in_slope, stats_out, B, TV, L, p.chunk);
   }
   if ((rc = check_launch("btlnk_bwd_stats"))) return rc;
-  if ((rc = launch_btlnk_reduce(dWp, p.S, (size_t)L * K, dW, dz, B, L, db, dap, rows, (dslope && slope) ? dslope : nullptr, accumulate, stream)))
-    return rc;
-  hipLaunchKernelGGL(bc::k_chain_rows_sum, dim3(ceil_div(E, bc::kCols)), dim3(1024), 0, stream, stats_out, rows, E,
-                     reinterpret_cast<double*>(stats_out + bc::sums_offset(rows, E)));
+  // one launch sums the dW slabs, the bias / slope gradients and the chain buffer's partial rows
   *stats_rows = rows;
-  return check_launch("btlnk_bwd_chain_sum");
+  return launch_btlnk_reduce(dWp, p.S, (size_t)L * K, dW, dz, B, L, db, dap, rows, (dslope && slope) ? dslope : nullptr, accumulate, stream,
+                             stats_out, rows, E, reinterpret_cast<double*>(stats_out + bc::sums_offset(rows, E)));
 }
 
 }  // extern "C"

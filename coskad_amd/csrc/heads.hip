@@ -137,7 +137,14 @@ __device__ __forceinline__ Vec hyp_embed_bwd(const Vec& u, const Embed& em, cons
 //   [0] loss term   [1..16] vector sum   [17] scalar A   [18] scalar B
 constexpr int kHeadSlots = LMAX + 3;
 
-__device__ __forceinline__ void block_partials(const float (&vals)[kHeadSlots], float* partials) {
+// A one-block launch (B <= kHeadSingleRows clips) writes the finished statistics itself -- no partial row, no k_head_finalize
+// launch behind it.  Larger batches keep one row per thread: ONE block striding over 4096 rows measured 65 us against 12 + 5 us
+// for eight blocks + k_head_finalize (eight dependent load rounds per thread).
+constexpr int kHeadSingleRows = kFlatBlock;
+__host__ __device__ inline int head_blocks(int B) { return B <= kHeadSingleRows ? 1 : ceil_div(B, kFlatBlock); }
+
+__device__ __forceinline__ void block_partials(const float (&vals)[kHeadSlots], float* partials, float scale0, float* stats,
+                                               float* acc) {
   __shared__ float sh[kFlatBlock / 64][kHeadSlots];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -149,7 +156,12 @@ __device__ __forceinline__ void block_partials(const float (&vals)[kHeadSlots], 
   if (threadIdx.x < kHeadSlots) {
     float s = 0.f;
     for (int w = 0; w < kFlatBlock / 64; ++w) s += sh[w][threadIdx.x];
-    partials[blockIdx.x * kHeadSlots + threadIdx.x] = s;
+    if (gridDim.x == 1) {
+      if (stats) stats[threadIdx.x] = threadIdx.x == 0 ? s * scale0 : s;
+      if (acc) acc[threadIdx.x] += s;
+    } else {
+      partials[blockIdx.x * kHeadSlots + threadIdx.x] = s;
+    }
   }
 }
 
@@ -158,13 +170,15 @@ __global__ __launch_bounds__(kFlatBlock) void k_mse_head(const float* __restrict
                                                     const float* __restrict__ cvec,
                                                     float* __restrict__ dz, float* __restrict__ score,
                                                     float* __restrict__ partials, int B, int L,
-                                                    float gscale) {
-  const int n = blockIdx.x * kFlatBlock + threadIdx.x;
+                                                    float gscale, float scale0, float* __restrict__ stats,
+                                                    float* __restrict__ acc) {
   float vals[kHeadSlots];
 #pragma unroll
   for (int k = 0; k < kHeadSlots; ++k) vals[k] = 0.f;
-  if (n < B) {
-    const Vec u = load_vec(z + (size_t)n * L, L), c = load_vec(cvec, L);
+  const Vec c = load_vec(cvec, L);
+#pragma unroll 4
+  for (int n = blockIdx.x * kFlatBlock + threadIdx.x; n < B; n += gridDim.x * kFlatBlock) {
+    const Vec u = load_vec(z + (size_t)n * L, L);
     Vec g;
     float sq = 0.f;
 #pragma unroll
@@ -172,15 +186,15 @@ __global__ __launch_bounds__(kFlatBlock) void k_mse_head(const float* __restrict
       const float d = j < L ? u.v[j] - c.v[j] : 0.f;
       sq = fmaf(d, d, sq);
       g.v[j] = 2.f * d * gscale;  // d mean((z-c)^2)/dz, gscale = upstream / (B*L)
-      vals[1 + j] = u.v[j];
+      vals[1 + j] += u.v[j];
     }
-    vals[0] = sq;
-    vals[LMAX + 1] = 1.f;
-    vals[LMAX + 2] = sqrtf(dot(u, u));
+    vals[0] += sq;
+    vals[LMAX + 1] += 1.f;
+    vals[LMAX + 2] += sqrtf(dot(u, u));
     if (dz) store_vec(dz + (size_t)n * L, g, L);
     if (score) score[n] = sq / (float)L;  // MSELoss(reduction='none')(c, z).mean(-1), eval_utils.py:63-64
   }
-  block_partials(vals, partials);
+  block_partials(vals, partials, scale0, stats, acc);
 }
 
 // Mahalanobis head (eval_utils.py:28-38; staticCenter.py:178-181).  slots: [0] sum dist, [1..L] sum z, [17] #clips,
@@ -190,19 +204,20 @@ __global__ __launch_bounds__(kFlatBlock) void k_mahalanobis_head(const float* __
                                                             const float* __restrict__ VI,
                                                             float* __restrict__ dz, float* __restrict__ score,
                                                             float* __restrict__ partials, int B, int L,
-                                                            float gscale) {
+                                                            float gscale, float scale0, float* __restrict__ stats,
+                                                            float* __restrict__ acc) {
   __shared__ float vi[LMAX * LMAX];
   for (int e = threadIdx.x; e < LMAX * LMAX; e += kFlatBlock) {
     const int r = e / LMAX, q = e - r * LMAX;
     vi[e] = (r < L && q < L) ? VI[r * L + q] : 0.f;
   }
   __syncthreads();
-  const int n = blockIdx.x * kFlatBlock + threadIdx.x;
   float vals[kHeadSlots];
 #pragma unroll
   for (int k = 0; k < kHeadSlots; ++k) vals[k] = 0.f;
-  if (n < B) {
-    const Vec u = load_vec(z + (size_t)n * L, L), c = load_vec(cvec, L);
+  const Vec c = load_vec(cvec, L);
+  for (int n = blockIdx.x * kFlatBlock + threadIdx.x; n < B; n += gridDim.x * kFlatBlock) {
+    const Vec u = load_vec(z + (size_t)n * L, L);
     Vec d, w, wt;
 #pragma unroll
     for (int j = 0; j < LMAX; ++j) { d.v[j] = j < L ? u.v[j] - c.v[j] : 0.f; w.v[j] = 0.f; wt.v[j] = 0.f; }
@@ -215,11 +230,11 @@ __global__ __launch_bounds__(kFlatBlock) void k_mahalanobis_head(const float* __
         wt.v[q] = fmaf(a, d.v[r], wt.v[q]);        // (VI^T d)[q]
       }
     const float dist = sqrtf(dot(d, w));
-    vals[0] = dist;
+    vals[0] += dist;
 #pragma unroll
-    for (int j = 0; j < LMAX; ++j) vals[1 + j] = u.v[j];
-    vals[LMAX + 1] = 1.f;
-    vals[LMAX + 2] = sqrtf(dot(u, u));
+    for (int j = 0; j < LMAX; ++j) vals[1 + j] += u.v[j];
+    vals[LMAX + 1] += 1.f;
+    vals[LMAX + 2] += sqrtf(dot(u, u));
     if (score) score[n] = dist;
     if (dz) {
       Vec g;
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(kFlatBlock) void k_mahalanobis_head(const float* __
       store_vec(dz + (size_t)n * L, g, L);
     }
   }
-  block_partials(vals, partials);
+  block_partials(vals, partials, scale0, stats, acc);
 }
 
 // gram (+)= sum_n z_n z_n^T  [L x L]; one block, thread (i, j), clips staged through LDS in fixed order.
@@ -260,26 +275,26 @@ __global__ __launch_bounds__(kFlatBlock) void k_poincare_head(const float* __res
                                                          float* __restrict__ dz, float* __restrict__ zh,
                                                          float* __restrict__ score,
                                                          float* __restrict__ partials, int B, int L,
-                                                         float gscale) {
-  const int n = blockIdx.x * kFlatBlock + threadIdx.x;
+                                                         float gscale, float scale0, float* __restrict__ stats,
+                                                         float* __restrict__ acc) {
   float vals[kHeadSlots];
 #pragma unroll
   for (int k = 0; k < kHeadSlots; ++k) vals[k] = 0.f;
-  if (n < B) {
+  for (int n = blockIdx.x * kFlatBlock + threadIdx.x; n < B; n += gridDim.x * kFlatBlock) {
     const Vec u = load_vec(z + (size_t)n * L, L);
     const Embed em = hyp_embed(u);
     if (zh) store_vec(zh + (size_t)n * L, em.p, L);
     const float y2 = dot(em.p, em.p);
     const float gamma = 2.f / (1.f - y2);
 #pragma unroll
-    for (int j = 0; j < LMAX; ++j) vals[1 + j] = gamma * em.p.v[j];
-    vals[LMAX + 1] = gamma - 1.f;
-    vals[LMAX + 2] = sqrtf(y2);
+    for (int j = 0; j < LMAX; ++j) vals[1 + j] += gamma * em.p.v[j];
+    vals[LMAX + 1] += gamma - 1.f;
+    vals[LMAX + 2] += sqrtf(y2);
     if (cvec) {
       const Vec c = load_vec(cvec, L);
       Vec gp;
       const float d = poincare_dist(c, em.p, dz ? &gp : nullptr);
-      vals[0] = d;
+      vals[0] += d;
       if (score) score[n] = d;
       if (dz) {
 #pragma unroll
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(kFlatBlock) void k_poincare_head(const float* __res
       }
     }
   }
-  block_partials(vals, partials);
+  block_partials(vals, partials, scale0, stats, acc);
 }
 
 // stats[k] = sum_p partials[p][k] (slot 0 additionally * scale0);  acc[k] += raw sums
@@ -433,10 +448,10 @@ int coskad_mse_head_f32(const float* z, const float* c, float* dz, float* score,
                         float upstream, float* ws, int B, int L, hipStream_t stream) {
   if (!z || !c || !ws) return fail(COSKAD_ERR_ARG, "mse_head: null pointer");
   if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "mse_head: B=%d latent=%d (max %d)", B, L, LMAX);
-  const int P = ceil_div(B, kFlatBlock);
+  const int P = head_blocks(B);
   hipLaunchKernelGGL(k_mse_head, dim3(P), dim3(kFlatBlock), 0, stream, z, c, dz, score, ws, B, L,
-                     upstream / ((float)B * (float)L));
-  if (stats || acc)
+                     upstream / ((float)B * (float)L), 1.f / ((float)B * (float)L), stats, acc);
+  if ((stats || acc) && P > 1)
     hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(64), 0, stream, ws, P, 1.f / ((float)B * (float)L), stats, acc);
   return check_launch("mse_head");
 }
@@ -449,10 +464,10 @@ int coskad_mahalanobis_head_f32(const float* z, const float* c, const float* VI,
                                 float* ws, int B, int L, hipStream_t stream) {
   if (!z || !c || !VI || !ws) return fail(COSKAD_ERR_ARG, "mahalanobis_head: null pointer");
   if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "mahalanobis_head: B=%d latent=%d (max %d)", B, L, LMAX);
-  const int P = ceil_div(B, kFlatBlock);
+  const int P = head_blocks(B);
   hipLaunchKernelGGL(k_mahalanobis_head, dim3(P), dim3(kFlatBlock), 0, stream, z, c, VI, dz, score, ws, B, L,
-                     upstream / (float)B);
-  if (stats || acc)
+                     upstream / (float)B, 1.f / (float)B, stats, acc);
+  if ((stats || acc) && P > 1)
     hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(64), 0, stream, ws, P, 1.f / (float)B, stats, acc);
   if (gram) hipLaunchKernelGGL(k_gram, dim3(1), dim3(LMAX * LMAX), 0, stream, z, gram, B, L, gram_accumulate);
   return check_launch("mahalanobis_head");
@@ -468,10 +483,10 @@ int coskad_poincare_head_f32(const float* z, const float* c, float* dz, float* z
                              hipStream_t stream) {
   if (!z || !ws) return fail(COSKAD_ERR_ARG, "poincare_head: null pointer");
   if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "poincare_head: B=%d latent=%d (max %d)", B, L, LMAX);
-  const int P = ceil_div(B, kFlatBlock);
+  const int P = head_blocks(B);
   hipLaunchKernelGGL(k_poincare_head, dim3(P), dim3(kFlatBlock), 0, stream, z, c, dz, zh, score, ws, B, L,
-                     upstream / (float)B);
-  if (stats || acc)
+                     upstream / (float)B, 1.f / (float)B, stats, acc);
+  if ((stats || acc) && P > 1)
     hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(64), 0, stream, ws, P, 1.f / (float)B, stats, acc);
   return check_launch("poincare_head");
 }
@@ -522,6 +537,17 @@ int coskad_adam_f32(float* p, const float* g, float* m, float* v, const float* m
   hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, mask, n, lr,
                      beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), gscale, reg_coef);
   return check_launch("adam");
+}
+
+/* Same update with the caller's running products b1pow = beta1^t, b2pow = beta2^t (fp32, multiplied up step by step: the arithmetic
+ * of coskad_adam_dev_f32's device-side tick, so that an eager step and a hipGraph-captured one agree bit for bit). */
+int coskad_adam_pow_f32(float* p, const float* g, float* m, float* v, const float* mask, size_t n, float lr, float beta1,
+                        float beta2, float eps, float b1pow, float b2pow, float gscale, float reg_coef, hipStream_t stream) {
+  if (!p || !g || !m || !v || n == 0) return fail(COSKAD_ERR_ARG, "adam_pow: bad argument");
+  if (!(b1pow < 1.f) || !(b2pow < 1.f)) return fail(COSKAD_ERR_ARG, "adam_pow: beta^t must be < 1 (t >= 1)");
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, g, m, v, mask, n, lr,
+                     beta1, beta2, eps, 1.f - b1pow, sqrtf(1.f - b2pow), gscale, reg_coef);
+  return check_launch("adam_pow");
 }
 
 /* Same update with lr / beta^t read from device memory: hyper = {lr, beta1^t, beta2^t} (initialise to

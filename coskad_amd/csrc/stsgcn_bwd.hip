@@ -1775,9 +1775,9 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
                                float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
                                float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                                int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z,
-                               const float* stats_in, int stats_in_rows, const float* below_in, const float* below_Z,
-                               const float* below_in_slope, int below_Ci, float* below_stats, size_t below_stats_bytes,
-                               double stats_count) {
+                               const float* stats_in, int stats_in_rows, size_t stats_in_bytes, const float* below_in,
+                               const float* below_Z, const float* below_in_slope, int below_Ci, float* below_stats,
+                               size_t below_stats_bytes, double stats_count) {
   if (!in || !dU || !A || !Tm || !stat || !Wt || !gamma_t || !dA || !dT || !dWt || !dgamma_t || !dbeta_t || !ws || !Z)
     return fail(COSKAD_ERR_ARG, "layer_bwd_chain: null pointer");
   if (Wr && (!gamma_r || !dWr || !dgamma_r || !dbeta_r)) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: residual grads missing");
@@ -1785,6 +1785,11 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
   if (B <= 0 || Ci <= 0 || Co <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: B=%d Ci=%d Co=%d", B, Ci, Co);
   if (stats_in && stats_in_rows <= 0) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: stats_in_rows=%d", stats_in_rows);
   if (stats_in && ((size_t)stats_in & 7)) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: stats_in must be 8-byte aligned");
+  if (stats_in) {   // the fold reads the fp64 sums behind the partial rows: a short buffer must not become an out-of-bounds read
+    const size_t E = 2 * (size_t)Co * Ci + Co;
+    const size_t need = chain_sums_offset(stats_in_rows, (int)E) * sizeof(float) + E * sizeof(double);
+    if (stats_in_bytes < need) return fail(COSKAD_ERR_WORKSPACE, "layer_bwd_chain: stats_in %zu < %zu bytes", stats_in_bytes, need);
+  }
   if (below_stats && ((size_t)below_stats & 7)) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: below_stats must be 8-byte aligned");
   if (below_stats) {
     if (!below_in || !below_Z) return fail(COSKAD_ERR_ARG, "layer_bwd_chain: below_in / below_Z missing");

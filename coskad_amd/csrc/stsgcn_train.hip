@@ -88,6 +88,7 @@ __device__ long long g_tfold_stamps[16];
 #define TFOLD_STAMP(k) do {} while (0)
 #endif
 
+constexpr int kFoldSelfSum = 48;   // E = 2 (Ci^2 + Ci) up to Ci = 4
 __global__ __launch_bounds__(1024) void k_train_fold(
     const double* __restrict__ red, double npos, const float* __restrict__ Wt,
     const float* __restrict__ bt, const float* __restrict__ gs, const float* __restrict__ bs,
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(1024) void k_train_fold(
     const float* __restrict__ Wr, const float* __restrict__ br, const float* __restrict__ gr,
     const float* __restrict__ brr, float* __restrict__ rm_r, float* __restrict__ rv_r,
     long long* __restrict__ nbt_r, float momentum, float* __restrict__ wfold,
-    float* __restrict__ bias, float* __restrict__ stat, int Ci, int Co, int CoP) {
+    float* __restrict__ bias, float* __restrict__ stat, int Ci, int Co, int CoP,
+    const float* __restrict__ parts, int P) {
   // One block, VALU-bound on fp64 and latency-bound on its global round trips: every input is read once at the start, the
   // phases exchange through LDS only (the stat block is written along the way, never read back), W C is register-blocked
   // (4 columns per thread: one conversion of W[o][k] per four DFMAs), per-channel sums use 8 lanes per channel.
@@ -109,10 +111,24 @@ __global__ __launch_bounds__(1024) void k_train_fold(
   float* WCl = Wl + 2 * CC;                             // [2][Co*Ci]
   float* meanl = WCl + 2 * CC;                          // [2][Co]
   float* istdl = meanl + 2 * Co;                        // [2][Co]
-  const double* MX = red;
-  const double* SX = red + Ci * Ci;
-  const double* MZ = red + Ci * Ci + Ci;
-  const double* SZ = red + 2 * Ci * Ci + Ci;
+  // parts != NULL (a handful of input channels: E <= kFoldSelfSum): every block sums the moment partials itself, in
+  // k_reduce_partials' order -- the table is a few thousand floats and its own launch cost more than the sums
+  __shared__ double red_l[kFoldSelfSum];
+  if (parts) {
+    __shared__ double shs[1024];
+    const int E = 2 * (Ci * Ci + Ci);
+    for (int e0 = 0; e0 < E; e0 += kRedCols) {
+      const int e = e0 + (int)(threadIdx.x % kRedCols);
+      const double t = column_sum_f64<kRedCols>(parts, P, (size_t)E, e, e < E, shs);
+      if ((int)threadIdx.x < kRedCols && e < E) red_l[e] = t;
+      __syncthreads();
+    }
+  }
+  const double* redp = parts ? red_l : red;
+  const double* MX = redp;
+  const double* SX = redp + Ci * Ci;
+  const double* MZ = redp + Ci * Ci + Ci;
+  const double* SZ = redp + 2 * Ci * Ci + Ci;
   float* muX = stat;
   float* muZ = stat + Ci;
   float* WCs = stat + 2 * Ci;
@@ -286,7 +302,8 @@ static int launch_reduce_fold(const float* partials, int rows, double* red, doub
                               float momentum, float* wfold, float* bias, float* stat, int Ci, int Co, hipStream_t st) {
   const int E = 2 * (Ci * Ci + Ci);
   int rc = 0;
-  if (partials) {                                        // (NULL: `red` holds the sums already -- SyncBN, summed over the ranks)
+  const bool self_sum = partials && Wt && E <= kFoldSelfSum;   // the fold sums the (tiny) table itself
+  if (partials && !self_sum) {                           // (NULL: `red` holds the sums already -- SyncBN, summed over the ranks)
     hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(E, kRedCols)), dim3(1024), 0, st, partials, rows, E, red);
     if ((rc = check_launch("reduce_partials"))) return rc;
   }
@@ -296,7 +313,7 @@ static int launch_reduce_fold(const float* partials, int rows, double* red, doub
   const int fold_blocks = Co >= 32 ? 8 : (Co >= 16 ? 4 : 1);
   hipLaunchKernelGGL(k_train_fold, dim3(fold_blocks), dim3(1024), fold_lds, st, red, npos, Wt, bt, gs, bs, rm_s,
                      rv_s, nbt_s, Wr, br, gr, brr, rm_r, rv_r, nbt_r, momentum, wfold, bias, stat, Ci,
-                     Co, round_up(Co, 16));
+                     Co, round_up(Co, 16), self_sum ? partials : (const float*)nullptr, rows);
   return check_launch("train_fold");
 }
 

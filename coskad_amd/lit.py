@@ -39,6 +39,8 @@ def _joints(args) -> int:
 
 
 class LitEncoder(nn.Module):
+    _reg_last = None      # the regulariser's value at the last logging step (training_step reuses it in between)
+
     def __init__(self, args: Namespace, hyperbolic: Optional[bool] = None) -> None:
         super().__init__()
         self.args = args
@@ -117,12 +119,16 @@ class LitEncoder(nn.Module):
     def training_step(self, batch, batch_idx: int) -> torch.Tensor:
         dev = self.model.c.device
         stats = self._engine.step(batch[0].to(dev, non_blocking=True).contiguous())
-        if batch_idx % 20 == 0:                           # log_every_n_steps=20 (train_COSKAD.py:76)
-            reg = self._engine.reg_loss()
+        # the reference returns head + alpha * reg (staticCenter.py:180-189); the regulariser is evaluated when it is logged
+        # (two launches) and that value is reused for the steps in between: at alpha ~ 1e-6 it moves in the 7th digit per step
+        if batch_idx % 20 == 0 or self._reg_last is None: # log_every_n_steps=20 (train_COSKAD.py:76)
+            self._reg_last = self._engine.reg_loss().reshape(())
+        loss = stats[0] + self._engine.alpha * self._reg_last
+        if batch_idx % 20 == 0:
             name = "poincare_loss" if self.hyperbolic else "hypersphere_loss"
-            self.log(name, stats[0]); self.log("regularization", reg)
-            self.log("loss", float(stats[0]) + self._engine.alpha * float(reg))
-        return stats[0]
+            self.log(name, stats[0]); self.log("regularization", self._reg_last)
+            self.log("loss", float(loss))
+        return loss
 
     def on_train_epoch_end(self) -> None:
         eng = self._engine
@@ -331,12 +337,13 @@ class LitAutoEncoder(_AutogradLit):
         x = batch[0].to(self.model.c.device, non_blocking=True)
         if self._flat is not None:
             out = self._flat.step(x)
-            loss = self.lambda_ * out['rec'] + out['head']
+            if batch_idx % 20 == 0 or self._reg_last is None:   # (the regulariser: evaluated when logged, reused in between)
+                self._reg_last = self._flat.reg_loss().reshape(())
+            loss = (self.lambda_ * out['rec'] + out['head']).reshape(()) + float(getattr(self.args, "alpha", 0.0)) * self._reg_last
             if batch_idx % 20 == 0:
-                loss_reg = self._flat.reg_loss()
-                self.log("loss", loss + float(getattr(self.args, "alpha", 0.0)) * loss_reg)
+                self.log("loss", loss)
                 self.log("reconstruction_loss", out['rec']); self.log("hypersphere_loss", out['head'])
-                self.log("regularization", loss_reg)
+                self.log("regularization", self._reg_last)
             return loss
         z, x_rec = self.model(x)
         loss_reco = F.mse_loss(x_rec, x)
@@ -392,12 +399,14 @@ class LitVAE(_AutogradLit):
             s = out['z'].sum(0, keepdim=True)
             self._zsum = s if self._zsum is None else self._zsum + s
             self._zn += out['z'].shape[0]
-            loss = self.phi * out['rec'] + self.beta * out['head'] + self.gamma * out['exp']
+            if batch_idx % 20 == 0 or self._reg_last is None:   # (the regulariser: evaluated when logged, reused in between)
+                self._reg_last = self._flat.reg_loss().reshape(())
+            loss = ((self.phi * out['rec'] + self.beta * out['head'] + self.gamma * out['exp']).reshape(())
+                    + float(getattr(self.args, "alpha", 0.0)) * self._reg_last)
             if batch_idx % 20 == 0:
-                loss_reg = self._flat.reg_loss()
-                self.log("loss", loss + float(getattr(self.args, "alpha", 0.0)) * loss_reg)
+                self.log("loss", loss)
                 self.log("reconstruction_loss", out['rec']); self.log("kl_loss", out['head'])
-                self.log("exp_dist_loss", out['exp']); self.log("regularization", loss_reg)
+                self.log("exp_dist_loss", out['exp']); self.log("regularization", self._reg_last)
             return loss
         z, x_rec, (q, p, kappa) = self.model(x)
         with torch.no_grad():

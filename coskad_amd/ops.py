@@ -389,7 +389,8 @@ def layer_bwd(x_in, dU, A, Tm, in_slope, stat, Wt, gt, Wr, gr, grads: dict, ws, 
         cb = xb.shape[1] if xb is not None else 0
         _chk(xb, "below x", (B, cb, T, V), optional=True); _chk(zb, "below Z", (B, cb, T, V), optional=True); _chk(bs, "below_stats", optional=True)
         _chk(sb, "below in_slope", (1,), optional=True)
-        call("coskad_layer_bwd_chain_f32", *args, ptr(Z), ptr(sp), i32(srows), ptr(xb), ptr(zb), ptr(sb), i32(cb), ptr(bs),
+        call("coskad_layer_bwd_chain_f32", *args, ptr(Z), ptr(sp), i32(srows), ctypes.c_size_t(_bytes(sp) if sp is not None else 0),
+             ptr(xb), ptr(zb), ptr(sb), i32(cb), ptr(bs),
              ctypes.c_size_t(_bytes(bs) if bs is not None else 0), ctypes.c_double(float(stats_count)))
     elif Z is None:
         call("coskad_layer_bwd_f32", *args)
@@ -892,6 +893,16 @@ def adam(p, g, m, v, mask, lr, beta1, beta2, eps, step, gscale=1.0, reg_coef=0.0
     call("coskad_adam_f32", ptr(p), ptr(g), ptr(m), ptr(v), ptr(mask), ctypes.c_size_t(p.numel()), ctypes.c_float(lr),
          ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), i32(step), ctypes.c_float(gscale),
          ctypes.c_float(reg_coef), _stream())
+
+
+def adam_pow(p, g, m, v, mask, lr, beta1, beta2, eps, b1pow, b2pow, gscale=1.0, reg_coef=0.0):
+    """Adam with the caller's fp32 running products beta^t (the arithmetic of adam_dev's device-side tick)."""
+    for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, n, p.shape)
+    _chk(mask, "mask", p.shape, optional=True)
+    call("coskad_adam_pow_f32", ptr(p), ptr(g), ptr(m), ptr(v), ptr(mask), ctypes.c_size_t(p.numel()), ctypes.c_float(lr),
+         ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_float(b1pow), ctypes.c_float(b2pow),
+         ctypes.c_float(gscale), ctypes.c_float(reg_coef), _stream())
 
 
 def prelu_fwd(u: Tensor, slope: Tensor) -> Tensor:

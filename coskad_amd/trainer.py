@@ -88,6 +88,7 @@ class STSETrainStep:
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
         self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], device=dev, dtype=torch.float32)
+        self.lr = float(lr)
         self.layers = [layer_tensors(l) for l in model.encoder.model]
         self.ws = engine.Workspace()
         self.center_acc = torch.zeros(ops.HEAD_SLOTS, device=dev, dtype=torch.float32)
@@ -112,7 +113,8 @@ class STSETrainStep:
         self.sync_group = None
         if sync_bn and self.world > 1:
             if self.mlp or side_stream or use_graph:
-                raise ValueError("sync_bn: encoder BatchNorm only (linear projector), on the main stream, outside hipGraph capture")
+                raise ValueError("sync_bn: encoder BatchNorm only (STS-GCN encoder within the tile kernels, linear projector), on the "
+                                 "main stream, outside hipGraph capture")
             self.sync_group = process_group if process_group is not None else dist.group.WORLD
         # gradient buckets for the data-parallel all-reduce: [encoder | bottleneck]; the bottleneck parameters are the
         # tail of the flat buffer (named_parameters order) and their gradients are final before the encoder backward
@@ -129,6 +131,21 @@ class STSETrainStep:
 
     def set_lr(self, lr: float) -> None:
         self.hyper[0] = lr
+        self.lr = float(lr)
+
+    def _adam(self) -> None:
+        """torch.optim.Adam step on the flat buffers with alpha * calc_reg_loss' gradient and the 1 / world of the gradient
+        all-reduce folded in.  Outside hipGraph capture lr and the running products beta^t come from the host (one launch);
+        a captured step keeps them in device memory (`hyper`: a one-thread launch advances beta^t in front of the update)."""
+        if self.use_graph:
+            ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,
+                         self.beta2, self.eps, gscale=1.0 / self.world, reg_coef=self.reg_coef)
+        else:
+            import numpy as np
+            b1p, b2p = getattr(self, "_bpow", (np.float32(1.0), np.float32(1.0)))
+            self._bpow = (np.float32(b1p * np.float32(self.beta1)), np.float32(b2p * np.float32(self.beta2)))   # fp32, as the device tick
+            ops.adam_pow(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.lr, self.beta1, self.beta2, self.eps,
+                         float(self._bpow[0]), float(self._bpow[1]), gscale=1.0 / self.world, reg_coef=self.reg_coef)
 
     # -- the step ---------------------------------------------------------------------------
     def _body(self, x: Tensor) -> Tensor:
@@ -181,8 +198,7 @@ class STSETrainStep:
             dist.all_reduce(head, group=self.pg)           # bucket 2: the encoder's gradients (0.12 MB)
             if work is not None:
                 work.wait()
-        ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,
-                     self.beta2, self.eps, gscale=1.0 / self.world, reg_coef=self.reg_coef)
+        self._adam()
         return stats
 
     def step(self, x: Tensor) -> Tensor:
@@ -347,7 +363,8 @@ class STSAETrainStep:
         dev = self.fp.flat.device
         self.m = torch.zeros_like(self.fp.flat)
         self.v = torch.zeros_like(self.fp.flat)
-        self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], device=dev, dtype=torch.float32)
+        self.lr = float(lr)
+        self.use_graph = False
         self.ws = engine.Workspace()
         self.enc = _FlatStack(list(model.encoder.model), self.fp, "encoder.model.")
         self.dec = _FlatStack(list(model.decoder.model), self.fp, "decoder.model.")
@@ -368,7 +385,9 @@ class STSAETrainStep:
         return isinstance(model.btlnk, torch.nn.Linear) and model.latent_dim <= 16
 
     def set_lr(self, lr: float) -> None:
-        self.hyper[0] = lr
+        self.lr = float(lr)
+
+    _adam = STSETrainStep._adam
 
     def reg_loss(self) -> Tensor:
         return ops.sqnorm(self.fp.flat, self.fp.reg_mask, self.reg_scale)
@@ -474,8 +493,7 @@ class STSAETrainStep:
         self.enc.backward(enc_saved, dU, self.ws, need_dx=False, top_stats=top_stats)
         if self.world > 1:
             dist.all_reduce(self.fp.grad, group=self.pg)                          # SUM; the 1 / W is folded into Adam
-        ops.adam_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.fp.reg_mask, self.hyper, self.beta1,
-                     self.beta2, self.eps, gscale=1.0 / self.world, reg_coef=self.reg_coef)
+        self._adam()
         self.last = out
         return out
 
@@ -556,5 +574,8 @@ def make_train_step(model, **kw):
         return STSETrainStep(model, **kw)
     kw.pop('use_graph', None); kw.pop('side_stream', None)
     if kw.pop('sync_bn', False):
-        raise ValueError("sync_bn needs the flat-buffer step (STS-GCN encoder within the tile kernels + linear / mlp projector)")
+        # the optional key `sync_batchnorm` (absent in the reference): with one rank there is nothing to synchronise
+        world = dist.get_world_size(kw.get('process_group')) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1:
+            raise ValueError("sync_bn: encoder BatchNorm only (STS-GCN encoder within the tile kernels, linear projector)")
     return AutogradTrainStep(model, **kw)

@@ -256,9 +256,9 @@ int coskad_layer_bwd_chain_f32(const float* in, const float* dU, const float* A,
                                float* dbt, float* dgamma_t, float* dbeta_t, float* dWr, float* dbr,
                                float* dgamma_r, float* dbeta_r, float* dslope_in, void* ws, size_t ws_bytes,
                                int accumulate, int B, int Ci, int Co, int T, int V, hipStream_t stream, const float* Z,
-                               const float* stats_in, int stats_in_rows, const float* below_in, const float* below_Z,
-                               const float* below_in_slope, int below_Ci, float* below_stats, size_t below_stats_bytes,
-                               double stats_count);
+                               const float* stats_in, int stats_in_rows, size_t stats_in_bytes, const float* below_in,
+                               const float* below_Z, const float* below_in_slope, int below_Ci, float* below_stats,
+                               size_t below_stats_bytes, double stats_count);
 
 /* ---- SyncBN (optional: the reference trains with per-rank BatchNorm statistics, train_COSKAD.py:75-78) -------------
  * The batch reductions and the folds behind them as separate calls, so that a data-parallel caller can add the other ranks'
@@ -414,6 +414,11 @@ int coskad_sqnorm_f32(const float* p, const float* mask, size_t n, float scale, 
 int coskad_adam_f32(float* p, const float* g, float* m, float* v, const float* mask, size_t n, float lr,
                     float beta1, float beta2, float eps, int step, float gscale, float reg_coef,
                     hipStream_t stream);
+
+/* coskad_adam_f32 with the caller's fp32 running products b1pow = beta1^t, b2pow = beta2^t instead of the step count: the
+ * arithmetic of coskad_adam_dev_f32's device-side tick (an eager step and a hipGraph-captured one then agree bit for bit). */
+int coskad_adam_pow_f32(float* p, const float* g, float* m, float* v, const float* mask, size_t n, float lr, float beta1,
+                        float beta2, float eps, float b1pow, float b2pow, float gscale, float reg_coef, hipStream_t stream);
 
 /* Adam with {lr, beta1^t, beta2^t} in device memory (hipGraph-replayable; init hyper = {lr, 1, 1}). */
 int coskad_adam_dev_f32(float* p, const float* g, float* m, float* v, const float* mask, size_t n, float* hyper,
