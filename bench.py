@@ -9,11 +9,14 @@ form), or, when WORLD_SIZE is unset, this script starts those N ranks itself as 
 GPU, forwards their output and exits with the child's code.
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.
 
-roofline  : layer 4's backward (the layer that owns the dominant kernel): SURVEY 8d's ALGORITHMIC bytes of that layer's
-            backward / the time of EVERY kernel that shares them (batch reductions, folds, the fused data / dA / dT kernel,
-            partial-row sums), measured with HIP events on the launch stream inside the timed region, against 8 TB/s
-            (MI355X_MICROARCH.md).  `kernel_only` prices the dominant kernel alone against the same bytes (flattering by
-            construction: reported, not the headline).
+roofline  : the step's dominant kernel -- k_layer_bwd_bpc<2,4,2,1>, layer 4's backward data path + dA / dT -- priced on SURVEY 8d's
+            ALGORITHMIC bytes of that layer's backward (read dOut, read the saved input, write dIn: 104 448 B per clip) over its
+            average launch time, measured with HIP events on the launch stream inside the timed region, against 8 TB/s
+            (MI355X_MICROARCH.md).  Operands the kernel moves beyond 8d (the stored Z, the layer below's rows for the backward
+            chain) are listed as `extra_operand_bytes`, never added to the numerator.  `roofline.layer` = every launch of the
+            layer's backward call on the same bytes, `roofline.step` = the whole step on 8d's 590 976 B per clip,
+            `roofline.kernels` = the per-kernel table (8d bytes, us, fraction) of the step's main kernels; the committed
+            rocprofv3 version of that table is profiles/r04_roofline.json (tools/summarize_profiles.py).
 legs      : the other shapes BASELINE.json / north_star name, each its own small timed loop (same protocol: warm-up,
             barrier + synchronize, K steps): wide 2-64-128-256-256, V = 25 encoder, V = 25 spherical VAE (config 4's
             model), Poincare head (config 3), `projector: mlp` (what 5 of the reference's 7 yamls select).
@@ -237,6 +240,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra workloads (wide, V=25, VAE, Poincare, mlp)")
     ap.add_argument("--leg-steps", type=int, default=20)
+    ap.add_argument("--dry-collectives", action="store_true", help="rehearsal of the N-rank data-parallel step (any backend; `--gpus 2 "
+                    "--backend gloo` runs on ONE GPU): after every step all ranks compare the two gradient buckets' element counts, the "
+                    "1 / world folded into Adam and the step count, and at the end a checksum of the parameters (ranks train on different "
+                    "clips: equal parameters mean the all-reduces did their job); prints backend / world / devices as the N-GPU line does")
+    ap.add_argument("--profile-only", action="store_true", help="warm-up + the timed steps only, no probes (rocprofv3 passes of "
+                    "tools/collect_profiles.sh: every kernel then runs exactly once per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to "
                     "rehearse the multi-rank control flow on a single GPU)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="clips per CPU-baseline train step (SURVEY 8d protocol leg)")
@@ -290,28 +299,58 @@ def main():
             dist.barrier(device_ids=[dev]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
+    if args.dry_collectives:
+        if world < 2:
+            raise SystemExit("--dry-collectives needs >= 2 ranks: python bench.py --gpus 2 --backend gloo --dry-collectives")
+        n_total, tail = eng.fp.grad.numel(), eng.tail_off
+        desc = {"bucket_bottleneck_elems": n_total - tail, "bucket_encoder_elems": tail, "gscale": 1.0 / eng.world, "world": eng.world}
+        for _ in range(args.warmup + args.steps):
+            eng.step(x)
+            got = [None] * world
+            dist.all_gather_object(got, dict(desc, steps=eng.steps))
+            assert all(g == got[0] for g in got), f"ranks disagree on the step's collectives: {got}"
+        sums = [None] * world
+        dist.all_gather_object(sums, (float(eng.fp.flat.double().sum()), float(eng.fp.flat.double().abs().sum())))
+        assert all(s_ == sums[0] for s_ in sums), f"parameters differ across ranks after {eng.steps} steps: {sums}"
+        devs = [None] * world
+        dist.all_gather_object(devs, f"rank {rank} pid {os.getpid()} cuda:{dev} {torch.cuda.get_device_name(dev)}")
+        if rank == 0:
+            print(json.dumps({"dry_collectives": "ok", "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
+                              "world": world, "devices": devs, "steps_checked": eng.steps, **desc,
+                              "allreduce_bytes_per_step": {"bucket_bottleneck (async, behind the bottleneck backward)": 4 * (n_total - tail),
+                                                           "bucket_encoder (at the end of the backward)": 4 * tail},
+                              "parameter_checksums_equal_on_all_ranks": True}), flush=True)
+        dist.destroy_process_group()
+        return
     for _ in range(args.warmup):
         eng.step(x)
     sync()
-    # Layer 4's backward (32 -> 64 channels) owns the step's dominant kernel (rocprof: profiles/*_kernel_instances.csv).  The
-    # library brackets every coskad_layer_bwd*_f32 call of that shape -- all its launches together -- with HIP events on the
-    # launch stream (coskad_probe_*), inside the timed region.
+    # The step's dominant kernel is layer 4's fused backward (k_layer_bwd_bpc<2,4,2,1>: rocprof, profiles/*_kernel_instances.csv).
+    # The library brackets every launch of it with HIP events on the launch stream (coskad_probe_*), inside the timed region.
     import ctypes
     lib = _lib.lib()
-    KID_LAYER_APPLY, KID_BWD_DATA, KID_LAYER_BWD, KID_FUSED = 1, 2, 6, 7
-    probing = not args.graph
+    KID_LAYER_APPLY, KID_BWD_DATA, KID_LAYER_BWD, KID_FUSED, KID_BTLNK_BWD = 1, 2, 6, 7, 8
+    probing = not args.graph and not args.profile_only
     if probing:
-        lib.coskad_probe_stride(8)                   # every 8th step's layer backward: a probed launch costs ~5 us of stream time
-        lib.coskad_probe_begin(KID_LAYER_BWD, CHANNELS[-1], HID)
+        lib.coskad_probe_stride(8)                   # every 8th step's launch: a probed launch costs ~5 us of stream time
+        lib.coskad_probe_begin(KID_BWD_DATA, CHANNELS[-1], HID)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = eng.step(x)
     sync()
     dt = time.perf_counter() - t0
-    lbw_ms, lbw_n = ctypes.c_float(0), ctypes.c_int(0)
+    dom_ms_c, dom_n_c = ctypes.c_float(0), ctypes.c_int(0)
     if probing:
-        lib.coskad_probe_end(ctypes.byref(lbw_ms), ctypes.byref(lbw_n))
+        lib.coskad_probe_end(ctypes.byref(dom_ms_c), ctypes.byref(dom_n_c))
         lib.coskad_probe_stride(1)
+    dom_ms, dom_n = dom_ms_c.value, dom_n_c.value
+    if args.profile_only:
+        if rank == 0:
+            print(json.dumps({"metric": "pose_clips_per_sec_fwd_bwd", "value": round(world * B * args.steps / dt, 1), "unit": "clips/s",
+                              "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps, "profile_only": True}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     def probe_steps(kid, ci, co, n=5):
         # every rank runs these steps (they contain the gradient all-reduce); only rank 0 reads its probe
@@ -324,9 +363,28 @@ def main():
             lib.coskad_probe_end(ctypes.byref(ms), ctypes.byref(cnt))
         return ms.value, cnt.value
 
-    # secondary (outside the timed region): the dominant kernel alone, and the layer-4 forward kernel
-    dom_ms, dom_n = probe_steps(KID_BWD_DATA, CHANNELS[-1], HID)
-    fwd_ms, fwd_n = probe_steps(KID_LAYER_APPLY, CHANNELS[-1], HID)
+    # secondary (outside the timed region): the per-kernel table -- every main kernel of the step through the same probe
+    chans = [C_IN] + CHANNELS + [HID]
+    probes = {}
+    for li in range(4):
+        probes[f"fwd L{li + 1}"] = probe_steps(KID_LAYER_APPLY, chans[li], chans[li + 1])
+        probes[f"bwd L{li + 1}"] = probe_steps(KID_BWD_DATA, chans[li], chans[li + 1])
+    probes["bwd bottleneck"] = probe_steps(KID_BTLNK_BWD, CHANNELS[-1], LATENT)
+    lbw_ms, lbw_n = probe_steps(KID_LAYER_BWD, CHANNELS[-1], HID)
+    fwd_ms, fwd_n = probes["fwd L4"]
+    # training forward alone (chain + bottleneck: what runs in front of the head), outside the timed region
+    from coskad_amd import engine as _engine, ops as _opsf
+    def train_fwd():
+        U, _ = _engine.chain_forward(x, eng.layers, True, eng.ws, want_ctx=True)
+        return _opsf.btlnk_fwd(U, model.btlnk.weight, model.btlnk.bias, eng.layers[-1].slope, ws=eng.ws)
+    for _ in range(3):
+        train_fwd()
+    sync()
+    tf0 = time.perf_counter()
+    for _ in range(20):
+        train_fwd()
+    sync()
+    train_fwd_dt = (time.perf_counter() - tf0) / 20
     # forward-only (eval-mode encoder + bottleneck; SURVEY 8d's forward roofline target), outside the timed region
     model.eval()
     fz_ms, fz_n = ctypes.c_float(0), ctypes.c_int(0)
@@ -369,7 +427,7 @@ def main():
         tvb = 4 * T * V
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this script)
         traffic, traffic_src = {}, None
-        for tag in ("r03", "r02"):
+        for tag in ("r04", "r03", "r02"):
             try:
                 with open(os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")) as f:
                     traffic, traffic_src = json.load(f), f"profiles/{tag}_hbm_traffic.json"
@@ -379,46 +437,62 @@ def main():
         roof = roof_fwd = None
         ci, co = CHANNELS[-1], HID
         layer_bytes = B * tvb * (co + 2 * ci)      # SURVEY 8d, backward of one layer: read dOut (C_out), read the saved input (C_in), write dIn (C_in)
-        # backward chain (engine.FUSE_BELOW): layer 4's data kernel also forms the batch reductions of layer 3 from the dU3 rows it
-        # holds -- that folded work must read layer 3's stored Z and input (2 x C_in(3) rows); its share of the probed time is included
         from coskad_amd import engine as _eng, ops as _ops
         cb = CHANNELS[-2]
         chained = bool(_eng.FUSE_BELOW and _ops.layer_bwd_below_rows(B, ci, co, cb, T, V))
-        below_bytes = B * tvb * 2 * cb if chained else 0
-        layer_bytes += below_bytes
-        if lbw_n.value:
-            ach = layer_bytes / (lbw_ms.value * 1e-3) / 1e9
-            roof = {"bound": "hbm",
-                    "what": "layer 4 backward (64 -> 32 channels), ALL its kernels (batch reductions k_bwd_stats_bpc, fp64 folds, "
-                            "k_layer_bwd_bpc<2,4,..> = data path + dA / dT, partial-row sums) against the layer's algorithmic bytes"
-                            + (f"; the data kernel also forms layer 3's batch reductions (backward chain): + {below_bytes} bytes "
-                               "(layer 3's stored Z and input) in algorithmic_bytes_per_launch, its time in avg_launch_us" if chained else ""),
+        # operands beyond 8d that the dominant kernel moves: the stored Z of its own layer, and (backward chain) the stored Z and
+        # input of the layer below, whose batch reductions it forms from the dU rows it holds
+        extra_bytes = B * tvb * ci + (B * tvb * 2 * cb if chained else 0)
+        step_bytes = B * (fwd_b + bwd_b)
+        step_s = dt / args.steps
+        tr = lambda key: (traffic.get(key, {}).get("hbm_bytes_per_launch") if B == 4096 else None)
+        if dom_n:
+            ach = layer_bytes / (dom_ms * 1e-3) / 1e9
+            # the same launches against the fp32 MFMA roof: convs Bt.dU, Br.dU (C_in x C_out each), Kt.Z, Kr.X
+            # (C_in x C_in each) + forward temporal mix, both adjoint mixes, dA and dT (3 T + 2 V per element)
+            flops = B * (2 * T * V * (2 * ci * co + 2 * ci * ci) + 2 * ci * T * V * (3 * T + 2 * V))
+            if chained:
+                flops += B * 2 * T * V * 2 * ci * cb          # P and Q of the layer below: C_in x C_in(below) each
+            tf = flops / (dom_ms * 1e-3) / 1e12
+            roof = {"bound": "hbm", "kernel": "k_layer_bwd_bpc<2,4,2,1>",
+                    "what": "the step's dominant kernel (layer 4 backward, 64 -> 32 channels: dZ, dA, dT, adjoint mixing, dXres, PReLU' "
+                            "in one pass" + (", + the batch reductions of layer 3: backward chain" if chained else "") + ") on SURVEY 8d's "
+                            "bytes of that layer's backward (read dOut 64 ch, read the saved input 32 ch, write dIn 32 ch = 104 448 B per clip)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": (traffic.get("layer4 backward", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
-                    "traffic_source": f"{traffic_src} (PMC FETCH_SIZE/WRITE_SIZE summed over the layer's kernels, B=4096)",
-                    "algorithmic_bytes_per_launch": layer_bytes, "avg_launch_us": round(lbw_ms.value * 1e3, 2),
-                    "launches": lbw_n.value, "probe": "HIP events around every 8th step's layer backward, inside the timed region"}
-            if dom_n:
-                ach1 = layer_bytes / (dom_ms * 1e-3) / 1e9
-                # the same launches against the fp32 MFMA roof: convs Bt.dU, Br.dU (C_in x C_out each),
-                # Kt.Z, Kr.X (C_in x C_in each) + forward temporal mix, both adjoint mixes, dA and dT (3 T + 2 V per element)
-                flops = B * (2 * T * V * (2 * ci * co + 2 * ci * ci) + 2 * ci * T * V * (3 * T + 2 * V))
-                if chained:
-                    flops += B * 2 * T * V * 2 * ci * cb          # P and Q of the layer below: C_in x C_in(below) each
-                tf = flops / (dom_ms * 1e-3) / 1e12
-                roof["kernel_only"] = {"kernel": "k_layer_bwd_bpc<2,4,2,1>", "note": "the layer's bytes charged to its dominant kernel alone",
-                                       "achieved": round(ach1, 1), "frac": round(ach1 / HBM_PEAK_GBS, 4),
-                                       "avg_launch_us": round(dom_ms * 1e3, 2), "launches": dom_n,
-                                       "traffic": (traffic.get("bwd_fused layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
-                                       "mfma_f32": {"achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                    "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": flops}}
+                    "traffic": tr("bwd_fused layer4"),
+                    "traffic_source": f"{traffic_src} (PMC: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, B=4096)",
+                    "algorithmic_bytes_per_launch": layer_bytes, "extra_operand_bytes": extra_bytes,
+                    "avg_launch_us": round(dom_ms * 1e3, 2), "launches": dom_n,
+                    "probe": "HIP events on the launch stream around every 8th step's launch, inside the timed region",
+                    "mfma_f32": {"achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "flops_per_launch": flops},
+                    "step": {"bytes": step_bytes, "bytes_per_clip": fwd_b + bwd_b, "ms": round(step_s * 1e3, 4),
+                             "achieved": round(step_bytes / step_s / 1e9, 1), "frac": round(step_bytes / step_s / (HBM_PEAK_GBS * 1e9), 4),
+                             "what": "whole train step (driver-timed) on SURVEY 8d's 590 976 B per clip"}}
+            if lbw_n:
+                achl = layer_bytes / (lbw_ms * 1e-3) / 1e9
+                roof["layer"] = {"what": "every launch of layer 4's backward call (fp64 fold, the dominant kernel, partial-row sums) on the "
+                                         "same 8d bytes; the layer's batch reductions ride on the bottleneck backward's kernel "
+                                         "(kernels['bwd bottleneck'])" if _eng.FUSE_TOP else
+                                         "every launch of layer 4's backward call (batch reductions, fp64 fold, the dominant kernel, "
+                                         "partial-row sums) on the same 8d bytes",
+                                 "avg_us": round(lbw_ms * 1e3, 2), "launches": lbw_n, "achieved": round(achl, 1),
+                                 "frac": round(achl / HBM_PEAK_GBS, 4)}
+            # per-kernel table: SURVEY 8d's bytes of each layer's forward / backward against the layer's main kernel
+            kb = {"bwd bottleneck": 2 * 4 * HID * T * V + 4 * LATENT}
+            for li in range(4):
+                kb[f"fwd L{li + 1}"] = tvb * (chans[li] + chans[li + 1])
+                kb[f"bwd L{li + 1}"] = tvb * (chans[li + 1] + chans[li] + (chans[li] if li > 0 else 0))
+            roof["kernels"] = {k: {"bytes_8d": B * kb[k], "avg_us": round(ms * 1e3, 2),
+                                   "frac": round(B * kb[k] / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+                               for k, (ms, n) in probes.items() if n}
         if fwd_n:
             byts = B * tvb * (ci + co)        # layer 4 forward: read 32 channels, write 64
             ach = byts / (fwd_ms * 1e-3) / 1e9
             roof_fwd = {"bound": "hbm", "kernel": "k_layer_apply_bpc<2> (layer 4 training forward from the stored Z, 32 -> 64 channels: one clip per workgroup)",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": byts,
-                        "traffic": (traffic.get("layer_apply layer4", {}).get("hbm_bytes_per_launch") if B == 4096 else None),
+                        "traffic": tr("layer_apply layer4"),
                         "avg_launch_us": round(fwd_ms * 1e3, 2), "launches": fwd_n}
         kp_bytes = 13 * 4 * 64 * 4 * 4        # tile-major activation the fused encoder writes and the bottleneck reads back
         fused_actual = 4 * C_IN * T * V + 2 * kp_bytes + 4 * LATENT
@@ -453,6 +527,10 @@ def main():
                                                  "hbm_frac": round(B / fwd_dt * (4 * C_IN * T * V + 4 * LATENT) / (HBM_PEAK_GBS * 1e9), 5),
                                                  "flops_per_clip": 3946992,
                                                  "mfma_f32_frac": round(B / fwd_dt * 3946992 / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)}},
+            "train_forward": {"ms": round(train_fwd_dt * 1e3, 4), "clips_per_s": round(B / train_fwd_dt, 1),
+                              "layerwise_hbm_frac": round(B / train_fwd_dt * fwd_b / (HBM_PEAK_GBS * 1e9), 4),
+                              "what": "training-mode forward (batch-statistics BatchNorm: statistics, folds, apply kernels, bottleneck) on "
+                                      "SURVEY 8d's 236 704 B per clip -- the layer-materialised schedule that bound describes"},
             "roofline": roof,
             "roofline_fwd_layer4": roof_fwd,
             "legs": legs,

@@ -402,7 +402,10 @@ int coskad_btlnk_bwd_f32(const float* U, const float* W, const float* dz, const 
   const int gx = ceil_div(K, 256);
   float* dWp = reinterpret_cast<float*>(ws);
   float* dap = dWp + (size_t)S * L * K;
-  hipLaunchKernelGGL(k_btlnk_bwd, dim3(gx, S), dim3(kBtlBlock), 0, stream, U, W, dz, slope, dU, dWp, dap, B, K, L, chunk);
+  {
+    ProbeScope probe(KID_BTLNK_BWD, 0, L, stream);
+    hipLaunchKernelGGL(k_btlnk_bwd, dim3(gx, S), dim3(kBtlBlock), 0, stream, U, W, dz, slope, dU, dWp, dap, B, K, L, chunk);
+  }
   int rc = check_launch("btlnk_bwd");
   if (rc) return rc;
   return launch_btlnk_reduce(dWp, S, (size_t)L * K, dW, dz, B, L, db, dap, gx * S, (dslope && slope) ? dslope : nullptr, accumulate, stream,

@@ -348,6 +348,8 @@ int coskad_btlnk_bwd_chain_f32(const float* U, const float* W, const float* dz, 
   float* dap = dWp + (size_t)p.S * L * K;
   const size_t lds = (size_t)bc::NCL * ((bc::HID * bc::RSTR + 4) + (2 * below_Ci * bc::RSTR + 4)) * sizeof(float);
   int rc;
+  {
+  ProbeScope probe(KID_BTLNK_BWD, below_Ci, L, stream);
   if (below_Ci == 32) {
     auto k = bc::k_btlnk_bwd_stats<2>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -358,6 +360,7 @@ int coskad_btlnk_bwd_chain_f32(const float* U, const float* W, const float* dz, 
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(p.npt * p.S), dim3(bc::kThreads), lds, stream, U, W, dz, slope, dU, dWp, dap, below_in, below_Z,
                        below_in_slope, stats_out, B, TV, L, p.chunk);
+  }
   }
   if ((rc = check_launch("btlnk_bwd_stats"))) return rc;
   // one launch sums the dW slabs, the bias / slope gradients and the chain buffer's partial rows

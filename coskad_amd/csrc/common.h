@@ -48,7 +48,8 @@ struct Geo {
 
 // kernel ids of the timing probe (api.hip)
 enum { KID_LAYER_APPLY = 1, KID_BWD_DATA = 2, KID_BWD_REDUCE = 3, KID_FWD_MOMENTS = 4, KID_GCN_PARAMS = 5,
-       KID_LAYER_BWD = 6 /* every launch of one coskad_layer_bwd*_f32 call together */, KID_FUSED_FWD = 7 };
+       KID_LAYER_BWD = 6 /* every launch of one coskad_layer_bwd*_f32 call together */, KID_FUSED_FWD = 7,
+       KID_BTLNK_BWD = 8 /* the bottleneck backward's main kernel (Ci = channels below or 0, Co = latent) */ };
 struct ProbeScope {   // brackets ONE kernel launch with events when the probe is armed for it
   ProbeScope(int kernel, int ci, int co, hipStream_t st);
   ~ProbeScope();

@@ -108,6 +108,64 @@ def test_layer_backward(Ci, Co, V, B, first, identity):
         close(grads["slope_in"], so.grad, rtol=5e-4, atol_rel=1e-4, msg="dslope_in")
 
 
+@pytest.mark.parametrize("Ci,Co,V,B", [(32, 16, 17, 1031), (16, 32, 17, 1026), (32, 64, 17, 1033), (32, 32, 17, 515),
+                                       (32, 16, 25, 1029), (16, 32, 25, 1025), (32, 64, 25, 1027), (16, 16, 25, 771)])
+def test_layer_stored_z_ragged_batches_vs_oracle(Ci, Co, V, B):
+    """The stored-Z training path of one layer -- statistics pass (k_fwd_moments / k_fwd_moments_bpc) writing Z, apply from the
+    stored Z (k_layer_apply_bpc / _ring / _flat), backward (k_bwd_stats_bpc / _flat / _ring, fold, k_layer_bwd_bpc or
+    k_bwd_data_bpc + k_gcn_params_bpc) -- against the CPU oracle's autograd of stsgcn.py:94-116 at B ~ 1000 clips, not a
+    multiple of anything the kernels tile by: several rounds of every persistent workgroup and a partial last one."""
+    from coskad_amd import ops
+    T = 12
+    st = make_layer_state(Ci, Co, V, seed=Ci * 100 + Co + V)
+    g = torch.Generator().manual_seed(11)
+    x_pre = torch.randn(B, Ci, T, V, generator=g)
+    probe = torch.randn(B, Co, T, V, generator=g) / (B * T * V) ** 0.5
+    slope = torch.tensor([0.2])
+    pk = [k for k in st if R.is_param_key(k) and st[k].is_floating_point()]
+    stc = {k: v.clone() for k, v in st.items()}
+    for k in pk:
+        stc[k].requires_grad_(True)
+    xo = x_pre.clone().requires_grad_(True)
+    so = slope.clone().requires_grad_(True)
+    U = R.st_gcnn_layer(R.prelu(xo, so), stc, "L", training=True, return_preact=True)
+    (U * probe).sum().backward()
+    d = {k[2:]: dev(v) for k, v in st.items()}
+    ws = torch.empty(max(ops.train_stats_ws_bytes(Ci), ops.layer_bwd_ws_bytes(B, Ci, Co, T, V)), dtype=torch.uint8, device="cuda")
+    sl, xd = dev(slope), dev(x_pre)
+    Wt, Wr = d["tcn.0.weight"].reshape(Co, Ci), d["residual.0.weight"].reshape(Co, Ci)
+    guard = torch.full((B + 2, Ci, T, V), 7.0, device="cuda")
+    Z = guard[1:B + 1]
+    wfold, bias, stat = ops.layer_train_stats(
+        xd, d["gcn.A"], d["gcn.T"], sl, Wt, d["tcn.0.bias"], d["tcn.1.weight"], d["tcn.1.bias"],
+        d["tcn.1.running_mean"], d["tcn.1.running_var"], d["tcn.1.num_batches_tracked"],
+        Wr, d["residual.0.bias"], d["residual.1.weight"], d["residual.1.bias"],
+        d["residual.1.running_mean"], d["residual.1.running_var"], d["residual.1.num_batches_tracked"], ws, Z=Z)
+    assert bool((guard[0] == 7.0).all()) and bool((guard[B + 1] == 7.0).all()), "Z written outside its rows"
+    with torch.no_grad():
+        close(Z, R.gcn(R.prelu(x_pre, slope), st["L.gcn.A"], st["L.gcn.T"]), rtol=1e-4, atol_rel=1e-5, msg="stored Z")
+    u_hip = ops.layer_apply_z(Z, xd, d["gcn.A"], d["gcn.T"], wfold, bias, Co, in_slope=sl)
+    close(u_hip, U, rtol=1e-4, atol_rel=1e-5, msg="forward preact")
+    z = lambda *s: torch.full(s, float("nan"), device="cuda")  # poison: kernels must overwrite
+    grads = {"A": z(T, V, V), "T": z(V, T, T), "Wt": z(Co, Ci), "bt": z(Co), "gt": z(Co), "bet": z(Co),
+             "Wr": z(Co, Ci), "br": z(Co), "gr": z(Co), "ber": z(Co), "slope_in": z(1)}
+    gd = torch.full((B + 2, Ci, T, V), 7.0, device="cuda")
+    dIn = ops.layer_bwd(xd, dev(probe), d["gcn.A"], d["gcn.T"], sl, stat, Wt, d["tcn.1.weight"], Wr, d["residual.1.weight"], grads, ws,
+                        need_dx=True, dIn=gd[1:B + 1], Z=Z)
+    assert bool((gd[0] == 7.0).all()) and bool((gd[B + 1] == 7.0).all()), "dIn written outside its rows"
+    gmax = max(float(stc[k].grad.abs().max()) for k in pk if stc[k].grad is not None)
+    ref = {"A": stc["L.gcn.A"].grad, "T": stc["L.gcn.T"].grad, "Wt": stc["L.tcn.0.weight"].grad.reshape(Co, Ci),
+           "bt": stc["L.tcn.0.bias"].grad, "gt": stc["L.tcn.1.weight"].grad, "bet": stc["L.tcn.1.bias"].grad,
+           "Wr": stc["L.residual.0.weight"].grad.reshape(Co, Ci), "br": stc["L.residual.0.bias"].grad,
+           "gr": stc["L.residual.1.weight"].grad, "ber": stc["L.residual.1.bias"].grad}
+    for k, r in ref.items():
+        a, b = grads[k].cpu().numpy(), r.numpy()
+        assert np.isfinite(a).all(), k
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * max(np.abs(b).max(), 1e-9) + 5e-5 * gmax, err_msg=k)
+    close(dIn, xo.grad, rtol=1e-3, atol_rel=1e-4, msg="dIn")
+    close(grads["slope_in"], so.grad, rtol=1e-3, atol_rel=2e-4, msg="dslope_in")
+
+
 @pytest.mark.parametrize("Ci,Co,V,B", [(2, 32, 17, 37), (2, 32, 17, 1500), (3, 32, 25, 21), (2, 64, 14, 9), (4, 8, 18, 5)])
 def test_first_layer_backward_stored_z_vs_oracle(Ci, Co, V, B):
     """The few-channel layer (no dIn, raw input) on the stored-Z path = csrc/first_layer.hip (k_first_stats, k_first_bwd)

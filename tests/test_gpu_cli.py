@@ -119,3 +119,19 @@ def test_train_eval_cli_autoencoder_and_vae(tmp_path):
         assert ckpts
         auc = _eval_cli(tmp_path, cfg, ckpts[-1])
         assert 0.0 <= auc <= 1.0
+
+
+def test_bench_dry_collectives_two_ranks_on_one_gpu():
+    """bench.py --dry-collectives: two ranks (gloo, one GPU) run the data-parallel step on different clips; every step the ranks
+    compare the gradient buckets' element counts, the 1 / world folded into Adam and the step count, at the end a parameter
+    checksum (train_COSKAD.py:75-78: DDP keeps the replicas equal) -- the rehearsal of the first N-GPU RCCL run."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--dry-collectives", "--steps", "3", "--warmup", "1",
+                        "--batch", "96"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dry_collectives"] == "ok" and out["world"] == 2 and len(out["devices"]) == 2
+    assert out["bucket_bottleneck_elems"] == 16 * 64 * 12 * 17 + 16 and out["gscale"] == 0.5 and out["steps_checked"] == 4
+    assert out["bucket_bottleneck_elems"] + out["bucket_encoder_elems"] >= 239716        # every parameter is in one of the two buckets

@@ -21,16 +21,20 @@ def make_args(**kw):
     return Namespace(**a)
 
 
-@pytest.mark.parametrize("mode", ["euclid_dynamic", "euclid_static", "hyperbolic", "mahalanobis_static", "euclid_mlp"])
+# `default_*`: the reference yamls' widths (channels 32-16-32, h_dim 64, latent 16): the eval forward is then the ONE-kernel fused
+# encoder (csrc/fused_fwd.hip) + the split-K bottleneck (+ csrc/mlp_head.hip for `mlp`), the training step the flat engine
+@pytest.mark.parametrize("mode", ["euclid_dynamic", "euclid_static", "hyperbolic", "mahalanobis_static", "euclid_mlp",
+                                  "default_linear", "default_mlp", "default_hyperbolic"])
 def test_train_score_auc_parity(mode, tmp_path):
     from coskad_amd.lit import LitEncoder, Trainer, load_checkpoint
     from coskad_amd.utils.synthetic import batches, make_dataset
     torch.manual_seed(0)
     train, _ = make_dataset(n_scenes=2, n_clips=3, n_persons=2, clip_len=100, num_transform=2, anomaly=False, seed=1)
     test, gts = make_dataset(n_scenes=1, n_clips=3, n_persons=2, clip_len=100, num_transform=2, anomaly=True, seed=2)
-    args = make_args(hyperbolic=(mode == "hyperbolic"), static_center=mode in ("euclid_static", "mahalanobis_static"),
+    wide = dict(channels=[32, 16, 32], h_dim=64, latent_dim=16) if mode.startswith("default_") else {}
+    args = make_args(hyperbolic=mode.endswith("hyperbolic"), static_center=mode in ("euclid_static", "mahalanobis_static"),
                      distance="mahalanobis" if mode == "mahalanobis_static" else "euclidean",
-                     projector="mlp" if mode == "euclid_mlp" else "linear")   # 'mlp': what 5 of the 7 reference yamls select
+                     projector="mlp" if mode.endswith("_mlp") else "linear", **wide)   # 'mlp': what 5 of the 7 reference yamls select
     lit = LitEncoder(args).cuda()
     lit.gts = gts
     tr = Trainer(max_epochs=3, ckpt_dir=str(tmp_path))
@@ -42,7 +46,7 @@ def test_train_score_auc_parity(mode, tmp_path):
     x, trans, meta, frames = test
     with torch.no_grad():
         z = R.stse_encode(x, st, training=False)
-        if mode == "hyperbolic":
+        if mode.endswith("hyperbolic"):
             s_ref = R.dist(st["c"][None], R.project(R.expmap0(z)))
         elif mode == "mahalanobis_static":
             s_ref = R.mahalanobis(z, st["c"][None], st["inv_cov_matrix"])           # eval_utils.py:41-47
@@ -54,8 +58,12 @@ def test_train_score_auc_parity(mode, tmp_path):
     with torch.no_grad():
         z_hip = lit.model(x.cuda())
         s_hip = lit.window_scores(z_hip).cpu()
+    if mode.startswith("default_"):
+        from coskad_amd import engine
+        from coskad_amd.models.graph_layers.stsgcn import layer_tensors
+        assert engine.fused_encoder_supported([layer_tensors(l) for l in lit.model.encoder.model], 12, 17)   # the fused eval kernel ran
     np.testing.assert_allclose(z_hip.cpu().numpy(), z.numpy(), rtol=1e-4, atol=1e-4)           # latents: 1e-4
-    if mode == "hyperbolic":
+    if mode.endswith("hyperbolic"):
         # the Poincare distance amplifies latent rounding by ~1/(1-|zh|^2) near the ball boundary: check the head
         # on the HIP latents tightly, and the full chain at the amplified tolerance
         # (fp32 conditioning of the reference formula itself: a centre close to the boundary makes the Moebius

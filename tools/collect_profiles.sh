@@ -10,7 +10,7 @@ tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-args="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-legs"
+args="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-legs --profile-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $args > $out/stats.log 2>&1
 echo "stats pass done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o run -- python3 $args > $out/fetch.log 2>&1

@@ -4,6 +4,9 @@
   profiles/<tag>_hbm_traffic_pmc.csv      FETCH_SIZE / WRITE_SIZE per instance (KB, averaged over dispatches)
   profiles/<tag>_hbm_traffic.json         HBM bytes / launch for the kernels bench.py prices: (2*FETCH_SIZE + WRITE_SIZE) * 1024
                                           (gfx950: FETCH_SIZE reports half of a wide coalesced stream; guide's correction)
+  profiles/<tag>_roofline.json            per in-step kernel: SURVEY 8d's algorithmic bytes of the layer pass it carries (0 for the
+                                          statistics / fold / reduce / head / optimiser launches), rocprofv3 avg us, fraction of
+                                          8 TB/s, PMC traffic and its ratio to the algorithmic bytes; the step's totals and its tail
 """
 import csv
 import glob
@@ -38,7 +41,8 @@ def main(tag: str) -> None:
     # the k-th launch of a symbol in every step is the same layer ("slot" k; steps = number of k_adam_tick launches)
     def slotted(rows, name_col):
         rows = sorted(rows, key=lambda r: int(r["Start_Timestamp"]))
-        steps = max(1, sum(1 for r in rows if short(r[name_col]) == "k_adam_tick"))
+        # one optimiser launch per step: k_adam (eager: beta^t from the host), k_adam_dev (+ k_adam_tick) under graph capture
+        steps = max([1] + [sum(1 for r in rows if short(r[name_col]) == m) for m in ("k_adam", "k_adam_dev", "k_adam_tick")])
         count = defaultdict(int)
         for r in rows:
             count[short(r[name_col])] += 1
@@ -132,7 +136,9 @@ def main(tag: str) -> None:
     for label, prefix in (("bwd_data layer4", "k_bwd_data_f<12,17,2,1>"), ("bwd_fused layer4", "k_layer_bwd_bpc<2,4"),
                           ("bwd_fused layer3", "k_layer_bwd_bpc<1,2"), ("bwd_fused layer2", "k_layer_bwd_bpc<2,1"),
                           ("layer_apply layer4", "k_layer_apply_bpc<2>"), ("fused_encoder", "k_fused_encoder"),
-                          ("bwd_stats layer4", "k_bwd_stats_bpc<2,4>"), ("apply_next layer1", "k_layer_apply_next_bpc<0,2>"),
+                          ("bwd_stats layer4", "k_bwd_stats_bpc<2,4>"), ("btlnk_bwd_stats", "k_btlnk_bwd_stats<2>"),
+                          ("btlnk_fwd", "k_btlnk_fwd_t"), ("first_bwd", "k_first_bwd"), ("first_moments", "k_first_moments"),
+                          ("apply_next layer1", "k_layer_apply_next_bpc<0,2>"),
                           ("apply_next layer2", "k_layer_apply_next_bpc<2,1>"), ("apply_next layer3", "k_layer_apply_next_bpc<1,2>")):
         b = biggest(prefix)
         if b:
@@ -145,8 +151,55 @@ def main(tag: str) -> None:
                                   "hbm_bytes_per_launch": out["bwd_stats layer4"]["hbm_bytes_per_launch"] + out["bwd_fused layer4"]["hbm_bytes_per_launch"]}
     with open(f"{dst}/{tag}_hbm_traffic.json", "w") as f:
         json.dump(out, f, indent=1)
+
+    # ---- per-kernel roofline table of the default stack's train step (B = 4096, 2-32-16-32-64, T V = 204, latent 16) --------------
+    # a layer's forward reads its input once and writes its output once; its backward reads dOut and the saved input and
+    # writes dIn (no dIn for layer 1); bottleneck forward reads U and writes z, backward reads U and dz and writes dU.
+    B, TVB, chans, lat = 4096, 4 * 204, [2, 32, 16, 32, 64], 16
+    fwd = {i: TVB * (chans[i] + chans[i + 1]) for i in range(4)}
+    bwd = {i: TVB * (chans[i + 1] + chans[i] + (chans[i] if i else 0)) for i in range(4)}
+    carries = {   # kernel prefix -> (what, 8d bytes per clip)
+        "k_layer_apply_next_bpc<0,2>": ("forward layer 1 (+ statistics of layer 2)", fwd[0]),
+        "k_layer_apply_next_bpc<2,1>": ("forward layer 2 (+ statistics of layer 3)", fwd[1]),
+        "k_layer_apply_next_bpc<1,2>": ("forward layer 3 (+ statistics of layer 4)", fwd[2]),
+        "k_layer_apply_bpc<2>": ("forward layer 4", fwd[3]),
+        "k_btlnk_fwd_t": ("bottleneck forward", 4 * 64 * 204 + 4 * lat),
+        "k_btlnk_bwd_stats<2>": ("bottleneck backward + batch reductions of layer 4", 2 * 4 * 64 * 204 + 4 * lat),
+        "k_btlnk_bwd": ("bottleneck backward", 2 * 4 * 64 * 204 + 4 * lat),
+        "k_layer_bwd_bpc<2,4": ("backward layer 4 (+ batch reductions of layer 3)", bwd[3]),
+        "k_layer_bwd_bpc<1,2": ("backward layer 3 (+ batch reductions of layer 2)", bwd[2]),
+        "k_layer_bwd_bpc<2,1": ("backward layer 2 (+ batch reductions of layer 1)", bwd[1]),
+        "k_first_bwd": ("backward layer 1", bwd[0]),
+    }
+    table, step_us, tail_us, tail_n = [], 0.0, 0.0, 0
+    for (k, slot, wg), d in rows:
+        if slot < 0 or not k.startswith("k_"):
+            continue                              # not one launch per step: eval forwards, set-up copies
+        avg = sum(d) / len(d)
+        what, bpc = next(((w, b) for pre, (w, b) in carries.items() if k.startswith(pre)), ("statistics / fold / partial sums / head / optimiser", 0))
+        byts = B * bpc
+        tr = summary.get((k, slot, wg))
+        table.append({"kernel": k, "launch_slot_in_step": slot, "workgroups": wg, "carries": what, "bytes_8d": byts, "avg_us": round(avg, 1),
+                      "frac_of_8TBs": round(byts / (avg * 1e-6) / 8e12, 4) if byts else 0.0,
+                      "traffic_bytes": int(tr[2]) if tr else None,
+                      "traffic_ratio": round(tr[2] / byts, 2) if (tr and byts) else None})
+        step_us += avg
+        if avg < 25.0:
+            tail_us += avg
+            tail_n += 1
+    total_8d = sum(r["bytes_8d"] for r in table)
+    roof = {"note": "rocprofv3 --kernel-trace averages per in-step kernel instance (tools/collect_profiles.sh: python bench.py --steps 10, "
+                    "B = 4096); bytes_8d = SURVEY 8d's algorithmic bytes of the layer pass the kernel carries x 4096 clips (0: a launch "
+                    "8d does not count); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from the PMC passes",
+            "step": {"sum_of_kernel_avgs_us": round(step_us, 1), "bytes_8d": total_8d, "bytes_8d_per_clip": total_8d // B,
+                     "frac_of_8TBs": round(total_8d / (step_us * 1e-6) / 8e12, 4)},
+            "tail": {"launches_under_25us": tail_n, "their_sum_us": round(tail_us, 1)},
+            "kernels": sorted(table, key=lambda r: -r["avg_us"])}
+    with open(f"{dst}/{tag}_roofline.json", "w") as f:
+        json.dump(roof, f, indent=1)
     print(open(f"{dst}/{tag}_kernel_instances.csv").read())
     print(json.dumps(out, indent=1))
+    print(json.dumps({k: roof[k] for k in ("step", "tail")}, indent=1))
 
 
 if __name__ == "__main__":
