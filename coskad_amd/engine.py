@@ -210,6 +210,8 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
 STORE_Z = True
 # backward: the data kernel of layer 2 also forms the batch reductions of layer 1 (csrc/fused_bwd.hip, NS = 1) where the shapes allow
 FUSE_BELOW = True
+# (A/B hook, tools/ab_chain.py) layer indices whose data kernel does NOT form the reductions of the layer below although it could
+CHAIN_SKIP = frozenset()
 # backward: the bottleneck's backward also forms the batch reductions of the top layer (csrc/btlnk_chain.hip) where the shapes allow
 FUSE_TOP = True
 # with the stored-Z path: layer i's apply kernel also produces layer i+1's Z and BatchNorm moment partials where
@@ -294,8 +296,8 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
                 dist.all_reduce(ops.chain_sums(stats_in[0], stats_in[1], Ci, L.Co), group=sync)
             below = None
             Zi = ctx.zs[i] if ctx.zs else None
-            if (FUSE_BELOW and Zi is not None and i > 0 and ctx.zs[i - 1] is not None and in_slope is not None
-                    and layers[i - 1].Wr is not None):
+            if (FUSE_BELOW and i not in CHAIN_SKIP and Zi is not None and i > 0 and ctx.zs[i - 1] is not None
+                    and in_slope is not None and layers[i - 1].Wr is not None):
                 cb = ctx.inputs[i - 1].shape[1]
                 rows = ops.layer_bwd_below_rows(B, Ci, L.Co, cb, T, V)
                 if rows:
