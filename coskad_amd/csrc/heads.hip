@@ -328,6 +328,20 @@ __global__ __launch_bounds__(kFlatBlock) void k_poincare_dist(const float* __res
   score[n] = poincare_dist(c, p, nullptr);
 }
 
+// logmap0(y) = y / |y| * artanh(|y|) at curvature -1 (hyper_math.py:367-370: norm clamp 1e-5, artanh on the clamped argument)
+__global__ __launch_bounds__(kFlatBlock) void k_poincare_logmap0(const float* __restrict__ y, float* __restrict__ out, int B, int L) {
+  const int n = blockIdx.x * kFlatBlock + threadIdx.x;
+  if (n >= B) return;
+  const Vec p = load_vec(y + (size_t)n * L, L);
+  const float yn = fmaxf(sqrtf(dot(p, p)), kMinNorm);
+  const float yc = fminf(fmaxf(yn, -1.f + kArtanhEps), 1.f - kArtanhEps);
+  const float at = 0.5f * (log1pf(yc) - log1pf(-yc));
+  Vec o;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) o.v[j] = p.v[j] / yn * at;
+  store_vec(out + (size_t)n * L, o, L);
+}
+
 // Gyromidpoint from the running sums: m = S / s ; centre = (1/2) (x) m  (Mobius scalar mul)
 //   acc: head slot layout, [1..L] = sum gamma*zh, [17] = sum (gamma-1)
 __global__ void k_midpoint_finalize(const float* __restrict__ acc, float* __restrict__ cvec, int L) {
@@ -497,6 +511,13 @@ int coskad_poincare_dist_f32(const float* zh, const float* c, float* score, int 
   if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "poincare_dist: B=%d latent=%d", B, L);
   hipLaunchKernelGGL(k_poincare_dist, dim3(ceil_div(B, kFlatBlock)), dim3(kFlatBlock), 0, stream, zh, c, score, B, L);
   return check_launch("poincare_dist");
+}
+
+int coskad_poincare_logmap0_f32(const float* y, float* out, int B, int L, hipStream_t stream) {
+  if (!y || !out) return fail(COSKAD_ERR_ARG, "poincare_logmap0: null pointer");
+  if (B <= 0 || L <= 0 || L > LMAX) return fail(COSKAD_ERR_SHAPE, "poincare_logmap0: B=%d latent=%d", B, L);
+  hipLaunchKernelGGL(k_poincare_logmap0, dim3(ceil_div(B, kFlatBlock)), dim3(kFlatBlock), 0, stream, y, out, B, L);
+  return check_launch("poincare_logmap0");
 }
 
 /* Euclidean centre from accumulated sums (acc layout of coskad_mse_head_f32): c = S/n with n = acc[17],

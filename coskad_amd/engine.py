@@ -44,6 +44,7 @@ class LayerTensors:
     nbt_r: Optional[Tensor]
     slope: Tensor           # prelu.weight [1]
     momentum: float = 0.1
+    bn: object = None       # the tcn BatchNorm module when its momentum is None (cumulative moving average: the factor changes per step)
     cache: Optional[dict] = None   # owned by the layer module: eval-mode folded weights, keyed by tensor versions
 
     def fold_key(self):
@@ -51,6 +52,10 @@ class LayerTensors:
         the versions; a training forward clears the cache because this library's kernels write through raw pointers)."""
         ts = (self.Wt, self.bt, self.gt, self.bet, self.rm_t, self.rv_t, self.Wr, self.br, self.gr, self.ber, self.rm_r, self.rv_r)
         return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+
+    def step_momentum(self) -> float:
+        """exponential_average_factor of this training forward (both BatchNorms of a layer count their batches in lockstep)"""
+        return ops.bn_momentum(self.bn) if self.bn is not None else self.momentum
 
     @property
     def Co(self) -> int:
@@ -121,6 +126,8 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
     B, C, T, V = x.shape
     ctx = ChainCtx(in_slope=in_slope) if want_ctx else None
     sync_count = None
+    # BatchNorm with track_running_stats=False normalises with batch statistics in eval mode too (nothing to update: NULL buffers)
+    batch_stats = [training or L.rm_t is None for L in layers]
     if sync is not None and training:
         import torch.distributed as dist
         if not STORE_Z:
@@ -136,7 +143,7 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
     # layer i+1 needs no statistics pass of its own
     fuse = [False] * n
     ftab = None
-    if training and STORE_Z and FUSE_NEXT:
+    if all(batch_stats) and STORE_Z and FUSE_NEXT:
         for i in range(n - 1):
             fuse[i] = layers[i + 1].Ci == layers[i].Co and ops.layer_apply_next_ok(layers[i].Ci, layers[i].Co, T, V)
         nxt = [i + 1 for i in range(n - 1) if fuse[i]]
@@ -150,7 +157,7 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
         if h.shape[1] != L.Ci:
             raise ValueError(f"layer expects {L.Ci} input channels, got {h.shape[1]}")
         Z = None
-        if training:
+        if batch_stats[i]:
             if L.cache:
                 L.cache.clear()   # running stats (and, after the optimiser, the weights) change through raw-pointer kernels
                                   # that do not bump torch's version counters: drop the eval-mode fold
@@ -165,18 +172,18 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
                 dist.all_reduce(sums, group=sync)
                 wfold, bias, stat = ops.layer_train_fold_sums(
                     sums, sync_count, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
-                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, momentum=L.momentum)
+                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, momentum=L.step_momentum())
             elif pending is not None:
                 Z, partials, rows = pending
                 wfold, bias, stat = ops.layer_train_fold(
                     partials, rows, B, T, V, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
-                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum)
+                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.step_momentum())
             else:
                 if STORE_Z:
                     Z = torch.empty_like(h)     # gcn(PReLU(h)): written by the statistics pass, read by everything after
                 wfold, bias, stat = ops.layer_train_stats(
                     h, L.A, L.T, slope, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
-                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.momentum, Z=Z)
+                    L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.step_momentum(), Z=Z)
         else:
             key = L.fold_key() if L.cache is not None else None
             if key is not None and L.cache.get("key") == key:
@@ -385,5 +392,7 @@ class FusedEncoderPlan:
 def fused_encoder_supported(layers: List[LayerTensors], n_frames: int, n_joints: int) -> bool:
     from . import fused_plan as FP
     if any(L.Wr is None for L in layers):
+        return False
+    if any(L.rm_t is None or L.rm_r is None for L in layers):   # no running statistics: batch statistics even in eval mode
         return False
     return FP.supports((layers[0].Ci,) + tuple(L.Co for L in layers), n_frames, n_joints)

@@ -75,8 +75,9 @@ class _MLPHeadFn(torch.autograd.Function):
         y1 = y1.contiguous()
         if training and y1.shape[0] == 1:        # nn.BatchNorm1d's own check (torch/nn/functional.py: _verify_batch_size)
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y1.shape)}")
+        training = ops.bn_batch_stats(bn, training)      # track_running_stats=False: batch statistics in eval mode too
         z, stat = ops.mlp_head_fwd(y1, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, W2.contiguous(), b2,
-                                   training, momentum=bn.momentum, eps=bn.eps)
+                                   training, momentum=ops.bn_momentum(bn) if training else 0.0, eps=bn.eps)
         ctx.save_for_backward(y1, stat, gamma, beta, W2)
         ctx.training, ctx.has_b2 = training, b2 is not None
         return z
@@ -118,10 +119,8 @@ class MLP(nn.Module):
     @property
     def hip_ok(self) -> bool:
         hs = self.hidden_layers
-        # the kernels implement BatchNorm1d's default configuration (fixed momentum, tracked running statistics); anything
-        # else composes the torch modules (`forward`)
-        bns_ok = all(bn.momentum is not None and bn.track_running_stats and bn.running_mean is not None for bn, _ in self.blocks())
-        return bns_ok and len(hs) >= 1 and hs[0] <= 16 and all(h <= 64 for h in hs[1:]) and self.output_size <= 64
+        # (BatchNorm1d with momentum=None or without running statistics stays on the kernels: ops.bn_momentum / ops.bn_batch_stats)
+        return len(hs) >= 1 and hs[0] <= 16 and all(h <= 64 for h in hs[1:]) and self.output_size <= 64
 
     def blocks(self):
         """[(bn, linear), ...]: the [BatchNorm1d, ReLU, Linear] blocks behind the first Linear."""

@@ -78,24 +78,28 @@ class ConvTemporalGraphical(nn.Module):
         return _GcnFn.apply(X, self.A, self.T)
 
 
-def check_bn(bn) -> None:
-    """The kernels implement nn.BatchNorm's default configuration (what the reference builds, stsgcn.py:65,76 and
-    components.py:221): an exponential running average with a fixed momentum and tracked running statistics.  Anything
-    else fails loudly instead of computing something subtly different."""
-    if bn is None:
+def check_bn(tb, rb=None) -> None:
+    """The two BatchNorms of a layer share one statistics / fold kernel: they must agree on HOW they average (fixed momentum
+    or momentum=None, the cumulative moving average) and on whether they track running statistics at all.  nn.BatchNorm's
+    non-default configurations themselves are on the HIP path (ops.bn_momentum / ops.bn_batch_stats); the reference builds the
+    default one (stsgcn.py:65,76)."""
+    if rb is None:
         return
-    if bn.momentum is None:
-        raise NotImplementedError("coskad_amd: BatchNorm with momentum=None (cumulative moving average) is not on the HIP path")
-    if not bn.track_running_stats or bn.running_mean is None:
-        raise NotImplementedError("coskad_amd: BatchNorm with track_running_stats=False is not on the HIP path")
+    if (tb.momentum is None) != (rb.momentum is None) or (tb.momentum is not None and tb.momentum != rb.momentum):
+        raise NotImplementedError("coskad_amd: the tcn and residual BatchNorm of a layer must use the same momentum")
+    if (tb.running_mean is None) != (rb.running_mean is None):
+        raise NotImplementedError("coskad_amd: the tcn and residual BatchNorm of a layer must both (or neither) track running statistics")
+    if tb.momentum is None and tb.num_batches_tracked is not None and rb.num_batches_tracked is not None:
+        a, b = tb.__dict__.get("_coskad_nbt"), rb.__dict__.get("_coskad_nbt")
+        if a is None and b is None and int(tb.num_batches_tracked) != int(rb.num_batches_tracked):
+            raise NotImplementedError("coskad_amd: momentum=None with different num_batches_tracked on the two BatchNorms of a layer")
 
 
 def layer_tensors(layer: "ST_GCNN_layer") -> engine.LayerTensors:
     tc, tb = layer.tcn[0], layer.tcn[1]
     has_res = not isinstance(layer.residual, nn.Identity)
     rc, rb = (layer.residual[0], layer.residual[1]) if has_res else (None, None)
-    check_bn(tb)
-    check_bn(rb)
+    check_bn(tb, rb)
     return engine.LayerTensors(
         A=layer.gcn.A, T=layer.gcn.T, Wt=tc.weight, bt=tc.bias, gt=tb.weight, bet=tb.bias,
         rm_t=tb.running_mean, rv_t=tb.running_var, nbt_t=tb.num_batches_tracked,
@@ -103,7 +107,7 @@ def layer_tensors(layer: "ST_GCNN_layer") -> engine.LayerTensors:
         gr=rb.weight if has_res else None, ber=rb.bias if has_res else None,
         rm_r=rb.running_mean if has_res else None, rv_r=rb.running_var if has_res else None,
         nbt_r=rb.num_batches_tracked if has_res else None, slope=layer.prelu.weight,
-        momentum=tb.momentum if tb.momentum is not None else 0.1,
+        momentum=tb.momentum if tb.momentum is not None else 0.1, bn=tb if tb.momentum is None else None,
         cache=layer.__dict__.setdefault("_fold_cache", {}))
 
 
@@ -183,6 +187,7 @@ class _WideLayerFn(torch.autograd.Function):
         Co, P = Wt.shape[0], Tn * V
         Z = ops.gcn(X, A.contiguous(), T.contiguous(), adjoint=False)
         Wt2 = Wt.view(Co, Ci)
+        training = ops.bn_batch_stats(bn_t, training)   # batch statistics: training mode, or BatchNorms without running statistics
         # 1x1 convolutions: the layout-specialised MFMA kernel (csrc/conv1x1.hip) where the shape allows, with the train-mode
         # BatchNorm sums formed in its epilogue (no statistics pass over the conv output); the strided GEMM otherwise
         Ct, pt = ops.conv1x1(Wt2, Z.view(B, Ci, P), bias=bt, want_stats=training)
@@ -287,8 +292,7 @@ class ST_GCNN_layer(nn.Module):
         has_res = not isinstance(self.residual, nn.Identity)
         tc, tb = self.tcn[0], self.tcn[1]
         rc, rb = (self.residual[0], self.residual[1]) if has_res else (None, None)
-        check_bn(tb)
-        check_bn(rb)
+        check_bn(tb, rb)
         return _WideLayerFn.apply(X, self.gcn.A, self.gcn.T, tc.weight, tc.bias, tb.weight, tb.bias,
                                   rc.weight if has_res else None, rc.bias if has_res else None,
                                   rb.weight if has_res else None, rb.bias if has_res else None, self.prelu.weight,

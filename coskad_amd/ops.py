@@ -672,13 +672,35 @@ def conv1x1_wgrad(G: Tensor, x: Tensor, out: Tensor, target_chunks: int = 64, ac
     return out
 
 
+def bn_momentum(bn) -> float:
+    """nn.BatchNorm's `exponential_average_factor` for ONE training-mode forward (torch/nn/modules/batchnorm.py, _BatchNorm.forward):
+    the fixed `momentum`, or with momentum=None the cumulative moving average 1 / num_batches_tracked, counted after this batch.  The
+    kernels increment the device counter through its raw pointer; the host keeps a mirror of it so that no forward waits for the
+    device -- re-read (one .item()) whenever torch itself wrote the tensor (load_state_dict, fill_: its version counter moves).
+    Call exactly once per BatchNorm and training forward."""
+    if bn.momentum is not None:
+        return float(bn.momentum)
+    nbt = bn.num_batches_tracked
+    if nbt is None:                       # track_running_stats=False: nothing to average
+        return 0.0
+    st = bn.__dict__.get("_coskad_nbt")
+    n = st[2] if (st is not None and st[0] is nbt and st[1] == nbt._version) else int(nbt.item())
+    bn.__dict__["_coskad_nbt"] = (nbt, nbt._version, n + 1)
+    return 1.0 / (n + 1)
+
+
+def bn_batch_stats(bn, training: bool) -> bool:
+    """does this BatchNorm normalise with batch statistics in this mode? (track_running_stats=False: always, batchnorm.py's `bn_training`)"""
+    return bool(training) or bn.running_mean is None or bn.running_var is None
+
+
 def bn2_stats_parts(parts: Tensor, bn, count: int) -> Tensor:
     """Train-mode statistics of nn.BatchNorm2d `bn` from the partial sums a conv1x1 epilogue wrote (+ running update)."""
     rows, C, _ = parts.shape
     _chk(parts, "parts", (rows, C, 2), dtype=torch.float64)
     stat = torch.empty(2 * C, device=parts.device, dtype=torch.float32)
     call("coskad_bn2_stats_parts_f32", ptr(parts), i32(rows), ptr(stat), ptr(bn.running_mean), ptr(bn.running_var),
-         ptr(bn.num_batches_tracked), ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps),
+         ptr(bn.num_batches_tracked), ctypes.c_float(bn_momentum(bn)), ctypes.c_float(bn.eps),
          ctypes.c_double(float(count)), i32(C), _stream())
     return stat
 
@@ -726,7 +748,7 @@ def bn2_stats(x: Tensor, bn, training: bool) -> Tensor:
     stat = torch.empty(2 * C, device=x.device, dtype=torch.float32)
     ws = _bn2_ws(Nb, C, x.device)
     call("coskad_bn2_stats_f32", ptr(x), ptr(stat), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
-         ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), ctypes.c_float(bn.eps), i32(1 if training else 0),
+         ctypes.c_float(bn_momentum(bn) if training else 0.0), ctypes.c_float(bn.eps), i32(1 if training else 0),
          ptr(ws), ctypes.c_size_t(ws.numel()), i32(Nb), i32(C), i32(P), _stream())
     return stat
 
@@ -862,6 +884,15 @@ def poincare_dist(zh, c):
     score = torch.empty(B, device=zh.device, dtype=torch.float32)
     call("coskad_poincare_dist_f32", ptr(zh), ptr(c), ptr(score), i32(B), i32(L), _stream())
     return score
+
+
+def poincare_logmap0(y):
+    """logmap0 on the unit Poincare ball (reference utils/hyper_math.py:367-370, c = 1): tangent vector at the origin."""
+    B, L = y.shape
+    _chk(y, "y")
+    out = torch.empty_like(y)
+    call("coskad_poincare_logmap0_f32", ptr(y), ptr(out), i32(B), i32(L), _stream())
+    return out
 
 
 def center_finalize(acc, eps: float, L: int):

@@ -123,6 +123,9 @@ class STSETrainStep:
         self.tail_off = None
         if first_tail is not None and all(n.startswith("btlnk.") for n in names[first_tail:]):
             self.tail_off = self.fp.offsets[names[first_tail]]
+        if use_graph and any(isinstance(b, torch.nn.modules.batchnorm._BatchNorm) and b.momentum is None for b in model.modules()):
+            raise ValueError("use_graph: BatchNorm with momentum=None changes its averaging factor every step (a launch argument here); "
+                             "capture needs a fixed momentum")
         self.use_graph = use_graph
         self._graph = None
         self._x_static: Optional[Tensor] = None
@@ -165,7 +168,7 @@ class STSETrainStep:
                 raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d of the mlp projector)")
             for i, (bn, lin) in enumerate(m.btlnk.blocks()):
                 z, stat = ops.mlp_head_fwd(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                           lin.weight, lin.bias, True, momentum=bn.momentum, eps=bn.eps)
+                                           lin.weight, lin.bias, True, momentum=ops.bn_momentum(bn), eps=bn.eps)
                 saved.append((y, stat, bn, lin, f"btlnk.net.{3 * i + 1}.", f"btlnk.net.{3 * i + 3}."))
                 y = z
             z = y
@@ -426,7 +429,7 @@ class STSAETrainStep:
                 mlp_saved = []
                 for i, (bn, lin) in enumerate(m.btlnk.blocks()):
                     zz, stat = ops.mlp_head_fwd(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                                lin.weight, lin.bias, True, momentum=bn.momentum, eps=bn.eps)
+                                                lin.weight, lin.bias, True, momentum=ops.bn_momentum(bn), eps=bn.eps)
                     mlp_saved.append((y, stat, bn, lin, f"btlnk.net.{3 * i + 1}.", f"btlnk.net.{3 * i + 3}."))
                     y = zz
                 Hd = y.requires_grad_(True)

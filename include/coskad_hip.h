@@ -401,6 +401,10 @@ int coskad_poincare_head_f32(const float* z, const float* c, float* dz, float* z
                              float* stats, float* acc, float upstream, float* ws, int B, int L,
                              hipStream_t stream);
 int coskad_poincare_dist_f32(const float* zh, const float* c, float* score, int B, int L, hipStream_t stream);
+/* out[n] = logmap0(y[n]) = y / |y| * artanh(|y|) for points on the unit Poincare ball (utils/hyper_math.py:367-370 at c = 1, with its
+ * 1e-5 norm floor and Artanh's +-(1 - 1e-5) clamp, :18-24): the inverse of expmap0 that north_star names; the reference's wrappers
+ * never call it, so it stands alone (no gradient entry). */
+int coskad_poincare_logmap0_f32(const float* y, float* out, int B, int L, hipStream_t stream);
 
 /* c = acc[1..L] / acc[17], then |c| < eps -> +-eps (staticCenter.py:118-121). */
 int coskad_center_finalize_f32(const float* acc, float* c, float eps, int L, hipStream_t stream);

@@ -396,6 +396,22 @@ def test_poincare_head_matches_oracle_and_golden(golden):
     np.testing.assert_allclose(sc2.numpy(), g["dist_bcast"], rtol=2e-4, atol=2e-5)
 
 
+def test_poincare_logmap0_vs_reference_golden(golden):
+    """logmap0 (hyper_math.py:367-370) on the reference's own points and values; expmap0 -> logmap0 returns the tangent vector
+    wherever neither the tanh clamp nor the ball projection has cut it."""
+    from coskad_amd import ops
+    g = golden("hyper_math.npz")
+    p = torch.from_numpy(g["project_expmap0"])
+    out = ops.poincare_logmap0(dev(p)).cpu()
+    np.testing.assert_allclose(out.numpy(), g["logmap0"], rtol=2e-5, atol=1e-7)
+    close(dev(out), R.logmap0(p), rtol=2e-5, atol_rel=1e-6)
+    u = torch.from_numpy(g["u"])
+    inner = (u.norm(dim=-1) > 1e-4) & (u.norm(dim=-1) < 2.0)
+    _, _, zh, _ = ops.poincare_head(dev(u), None, need_zh=True, need_grad=False)
+    back = ops.poincare_logmap0(zh).cpu()
+    np.testing.assert_allclose(back[inner].numpy(), u[inner].numpy(), rtol=2e-4, atol=1e-6)
+
+
 def test_poincare_center(golden):
     from coskad_amd import ops
     g = golden("stse_default.npz")

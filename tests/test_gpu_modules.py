@@ -612,3 +612,101 @@ def test_train_step_captured_in_a_hip_graph_equals_the_eager_step(golden):
     np.testing.assert_allclose(l1, l0, rtol=1e-6)
     for k in s0:
         np.testing.assert_allclose(s1[k].numpy(), s0[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def _torch_twin(layer):
+    """pure-torch CPU twin of an ST_GCNN_layer (reference composition, stsgcn.py:94-116) sharing its BatchNorm configuration"""
+    import copy
+    from oracle import ref_cpu as R
+    tcn, res, prelu = copy.deepcopy(layer.tcn).cpu(), copy.deepcopy(layer.residual).cpu(), copy.deepcopy(layer.prelu).cpu()
+    A, T = layer.gcn.A.detach().cpu().clone().requires_grad_(True), layer.gcn.T.detach().cpu().clone().requires_grad_(True)
+
+    def fwd(x):
+        return prelu(tcn(R.gcn(x, A, T)) + res(x))
+    return fwd, tcn, res, (A, T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ci,Co,V", [(16, 32, 17), (32, 16, 25), (64, 128, 17)])
+@pytest.mark.parametrize("mode", ["cumulative", "untracked"])
+def test_layer_batchnorm_non_default_configurations(Ci, Co, V, mode):
+    """nn.BatchNorm2d(momentum=None) (cumulative moving average: factor 1 / num_batches_tracked) and track_running_stats=False
+    (batch statistics in eval mode too) on the tile kernels (16 -> 32, 32 -> 16) and the wide path (64 -> 128), against torch's
+    own modules composed as the reference composes them (stsgcn.py:56-80,94-116; torch/nn/modules/batchnorm.py)."""
+    from coskad_amd.models.graph_layers.stsgcn import ST_GCNN_layer
+    torch.manual_seed(3)
+    layer = ST_GCNN_layer(Ci, Co, [1, 1], 1, 12, V, 0.0)
+    kw = dict(momentum=None) if mode == "cumulative" else dict(track_running_stats=False)
+    for seq in (layer.tcn, layer.residual):
+        bn = torch.nn.BatchNorm2d(Co, **kw)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+        seq[1] = bn
+    fwd, tcn, res, _ = _torch_twin(layer)
+    layer.cuda().train()
+    for m in (tcn, res):
+        m.train()
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):                                     # the averaging factor changes every step: 1, 1/2, 1/3
+        x = torch.randn(6 + step, Ci, 12, V, generator=g) * (1.0 + step)
+        out = layer(x.cuda())
+        ref = fwd(x)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+        for mine, theirs in ((layer.tcn[1], tcn[1]), (layer.residual[1], res[1])):
+            if mode == "cumulative":
+                assert int(mine.num_batches_tracked) == int(theirs.num_batches_tracked) == step + 1
+                np.testing.assert_allclose(mine.running_mean.cpu().numpy(), theirs.running_mean.numpy(), rtol=1e-4, atol=1e-5)
+                np.testing.assert_allclose(mine.running_var.cpu().numpy(), theirs.running_var.numpy(), rtol=1e-4, atol=1e-5)
+            else:
+                assert mine.running_mean is None and mine.num_batches_tracked is None
+    # gradients of the last training forward
+    xg = torch.randn(5, Ci, 12, V, generator=g)
+    w = torch.randn(5, Co, 12, V, generator=g)
+    xa = xg.clone().cuda().requires_grad_(True)
+    (layer(xa) * w.cuda()).sum().backward()
+    xb = xg.clone().requires_grad_(True)
+    (fwd(xb) * w).sum().backward()
+    scale = float(xb.grad.abs().max())
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
+    np.testing.assert_allclose(layer.tcn[0].weight.grad.cpu().numpy(), tcn[0].weight.grad.numpy(), rtol=2e-3,
+                               atol=2e-4 * float(tcn[0].weight.grad.abs().max()))
+    # eval mode: running statistics (cumulative) / batch statistics (untracked)
+    layer.eval(); tcn.eval(); res.eval()
+    xe = torch.randn(7, Ci, 12, V, generator=g)
+    with torch.no_grad():
+        np.testing.assert_allclose(layer(xe.cuda()).cpu().numpy(), fwd(xe).numpy(), rtol=1e-4, atol=1e-4)
+    # load_state_dict (torch writes num_batches_tracked: its version moves) restarts the host's mirror of the counter
+    if mode == "cumulative":
+        sd = {k: v.clone() for k, v in layer.state_dict().items()}
+        sd["tcn.1.num_batches_tracked"].fill_(9); sd["residual.1.num_batches_tracked"].fill_(9)
+        layer.load_state_dict(sd)
+        tcn[1].num_batches_tracked.fill_(9); res[1].num_batches_tracked.fill_(9)
+        layer.train(); tcn.train(); res.train()
+        out, ref = layer(xe.cuda()), fwd(xe)
+        np.testing.assert_allclose(layer.tcn[1].running_var.cpu().numpy(), tcn[1].running_var.numpy(), rtol=1e-4, atol=1e-5)
+        assert int(layer.tcn[1].num_batches_tracked) == 10
+
+
+@pytest.mark.gpu
+def test_mlp_projector_batchnorm_momentum_none_stays_on_the_kernels():
+    """BatchNorm1d(momentum=None) inside the `mlp` projector: HIP path (hip_ok), values and running statistics as torch's"""
+    from coskad_amd.models.common.components import MLP
+    torch.manual_seed(1)
+    mlp = MLP(64 * 12 * 17, 16, [16])
+    mlp.net[1] = torch.nn.BatchNorm1d(16, momentum=None)
+    assert mlp.hip_ok
+    import copy
+    twin = copy.deepcopy(mlp.net).train()
+    mlp.cuda().train()
+    from coskad_amd.models.sts.ae import _BottleneckFn
+    from coskad_amd import engine
+    ws = engine.Workspace()
+    g = torch.Generator().manual_seed(2)
+    for step in range(2):
+        U = torch.randn(9, 64, 12, 17, generator=g)
+        z = mlp.forward_preact(U.cuda(), None, ws, _BottleneckFn.apply)
+        ref = twin(U.reshape(9, -1))
+        np.testing.assert_allclose(z.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(mlp.net[1].running_var.cpu().numpy(), twin[1].running_var.numpy(), rtol=1e-4, atol=1e-6)
+        assert int(mlp.net[1].num_batches_tracked) == step + 1

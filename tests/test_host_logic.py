@@ -241,3 +241,21 @@ def test_reference_yaml_files_drive_the_wrappers():
             assert type(m.model.encoder).__name__.lower().startswith("encoder" + str(raw["encoder_type"]).lower().split("_")[0]), f
         built += 1
     assert built >= 6 and broken == ["UBnormal/euclidean_autoencoder.yaml"], (built, broken)
+
+
+def test_bn_momentum_host_mirror_of_num_batches_tracked():
+    """ops.bn_momentum: nn.BatchNorm's exponential_average_factor per training forward -- the fixed momentum, or (momentum=None)
+    1 / num_batches_tracked counted after this batch, from a host mirror that is re-read when torch writes the counter
+    (torch/nn/modules/batchnorm.py, _BatchNorm.forward)."""
+    import torch
+    from coskad_amd import ops
+    assert ops.bn_momentum(torch.nn.BatchNorm2d(4, momentum=0.3)) == pytest.approx(0.3)
+    bn = torch.nn.BatchNorm2d(4, momentum=None)
+    assert [ops.bn_momentum(bn) for _ in range(3)] == [1.0, 0.5, pytest.approx(1 / 3)]   # the kernels advance the device counter
+    bn.num_batches_tracked.fill_(9)                       # torch-side write (load_state_dict does the same): version moves
+    assert ops.bn_momentum(bn) == pytest.approx(0.1)
+    assert ops.bn_momentum(bn) == pytest.approx(1 / 11)
+    free = torch.nn.BatchNorm1d(4, track_running_stats=False)
+    assert ops.bn_momentum(free) == pytest.approx(0.1) and ops.bn_batch_stats(free, False) and not ops.bn_batch_stats(bn, False)
+    free2 = torch.nn.BatchNorm1d(4, momentum=None, track_running_stats=False)
+    assert ops.bn_momentum(free2) == 0.0
