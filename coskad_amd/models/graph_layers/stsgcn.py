@@ -177,57 +177,72 @@ class _PReLUFn(torch.autograd.Function):
         return du, dslope
 
 
+def wide_forward(X, A, T, Wt, bt, gt, bet, Wr, br, gr, ber, slope, bn_t, bn_r, training, drop_p=0.0, drop_seed=0):
+    """out = PReLU(BN_t(Wt . gcn(X) + bt) + BN_r(Wr . X + br))  (identity residual when Wr is None) for one wide layer
+    (reference stsgcn.py:106-110) -> (out [B, Co, T, V], saved, meta) for wide_backward; no autograd involved."""
+    X = X.contiguous()
+    B, Ci, Tn, V = X.shape
+    Co, P = Wt.shape[0], Tn * V
+    Z = ops.gcn(X, A.contiguous(), T.contiguous(), adjoint=False)
+    Wt2 = Wt.view(Co, Ci)
+    training = ops.bn_batch_stats(bn_t, training)   # batch statistics: training mode, or BatchNorms without running statistics
+    # 1x1 convolutions: the layout-specialised MFMA kernel (csrc/conv1x1.hip) where the shape allows, with the train-mode
+    # BatchNorm sums formed in its epilogue (no statistics pass over the conv output); the strided GEMM otherwise
+    Ct, pt = ops.conv1x1(Wt2, Z.view(B, Ci, P), bias=bt, want_stats=training)
+    st_t = ops.bn2_stats_parts(pt, bn_t, B * P) if pt is not None else ops.bn2_stats(Ct, bn_t, training)
+    if Wr is not None:
+        Cr, pr = ops.conv1x1(Wr.view(Co, Ci), X.view(B, Ci, P), bias=br, want_stats=training)
+        st_r = ops.bn2_stats_parts(pr, bn_r, B * P) if pr is not None else ops.bn2_stats(Cr, bn_r, training)
+    else:
+        Cr, st_r = X.view(B, Ci, P), None
+    out = ops.bn2_apply_prelu(Ct, Cr, st_t, gt, bet, st_r, gr, ber, slope, drop_p, drop_seed)
+    saved = (X, Z, A, T, Wt, gt, bet, Wr, gr, ber, slope, Ct, Cr if Wr is not None else None, st_t, st_r)
+    meta = (training, bt is not None, br is not None, (drop_p, drop_seed))
+    return out.view(B, Co, Tn, V), saved, meta
+
+
+def wide_backward(saved, meta, dOut, need_dx: bool = True):
+    """-> (dX, dA, dT, dWt, dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope) of wide_forward (None where the layer has no such tensor)."""
+    X, Z, A, T, Wt, gt, bet, Wr, gr, ber, slope, Ct, Cr, st_t, st_r = saved
+    training, has_bt, has_br, drop = meta
+    B, Ci, Tn, V = X.shape
+    Co, P = Wt.shape[0], Tn * V
+    Xv = X.view(B, Ci, P)
+    Crv = Cr if Cr is not None else Xv
+    dCt, dCr, dgt, dbet, dgr, dber, dslope = ops.bn2_bwd(Ct, Crv, dOut.contiguous().view(B, Co, P), st_t, gt, bet, st_r, gr, ber,
+                                                         slope, training, *drop)
+    Wt2 = Wt.view(Co, Ci)
+    dWt = ops.conv1x1_wgrad(dCt, Z.view(B, Ci, P), torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
+    dZ = ops.conv1x1(Wt2.t(), dCt)[0].view(B, Ci, Tn, V)
+    # dA, dT and dX = gcn^T(dZ) from ONE pass over dZ (csrc/stsgcn_bwd.hip: k_bwd_gcn_params writes the adjoint mix too); an
+    # identity residual's gradient joins it there instead of in an add of its own
+    dA, dT, dX = ops.gcn_bwd_params_dx(X, dZ, A, T, add=None if Wr is not None else dCr.view(B, Ci, Tn, V))
+    dWr = dbr = None
+    if Wr is not None:
+        dWr = ops.conv1x1_wgrad(dCr, Xv, torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
+        if need_dx:
+            ops.conv1x1(Wr.view(Co, Ci).t(), dCr, out=dX.view(B, Ci, P), accumulate=True)
+        if has_br:      # a bias in front of a BatchNorm: its gradient is the sum of a mean-free tensor (exactly 0 in training)
+            dbr = dCr.sum((0, 2)) if not training else torch.zeros(Co, device=X.device, dtype=torch.float32)
+    dbt = None
+    if has_bt:
+        dbt = dCt.sum((0, 2)) if not training else torch.zeros(Co, device=X.device, dtype=torch.float32)
+    return dX, dA, dT, dWt.view_as(Wt), dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope.view_as(slope)
+
+
 class _WideLayerFn(torch.autograd.Function):
-    """out = PReLU(BN_t(Wt . gcn(X) + bt) + BN_r(Wr . X + br))  (identity residual when Wr is None) for one wide layer."""
+    """wide_forward / wide_backward as one autograd node (the module surface; the flat train steps call the two functions directly)."""
 
     @staticmethod
     def forward(ctx, X, A, T, Wt, bt, gt, bet, Wr, br, gr, ber, slope, bn_t, bn_r, training, drop_p=0.0, drop_seed=0):
-        X = X.contiguous()
-        B, Ci, Tn, V = X.shape
-        Co, P = Wt.shape[0], Tn * V
-        Z = ops.gcn(X, A.contiguous(), T.contiguous(), adjoint=False)
-        Wt2 = Wt.view(Co, Ci)
-        training = ops.bn_batch_stats(bn_t, training)   # batch statistics: training mode, or BatchNorms without running statistics
-        # 1x1 convolutions: the layout-specialised MFMA kernel (csrc/conv1x1.hip) where the shape allows, with the train-mode
-        # BatchNorm sums formed in its epilogue (no statistics pass over the conv output); the strided GEMM otherwise
-        Ct, pt = ops.conv1x1(Wt2, Z.view(B, Ci, P), bias=bt, want_stats=training)
-        st_t = ops.bn2_stats_parts(pt, bn_t, B * P) if pt is not None else ops.bn2_stats(Ct, bn_t, training)
-        if Wr is not None:
-            Cr, pr = ops.conv1x1(Wr.view(Co, Ci), X.view(B, Ci, P), bias=br, want_stats=training)
-            st_r = ops.bn2_stats_parts(pr, bn_r, B * P) if pr is not None else ops.bn2_stats(Cr, bn_r, training)
-        else:
-            Cr, st_r = X.view(B, Ci, P), None
-        out = ops.bn2_apply_prelu(Ct, Cr, st_t, gt, bet, st_r, gr, ber, slope, drop_p, drop_seed)
-        ctx.drop = (drop_p, drop_seed)
-        ctx.save_for_backward(X, Z, A, T, Wt, gt, bet, Wr, gr, ber, slope, Ct, Cr if Wr is not None else None, st_t, st_r)
-        ctx.training, ctx.has_bt, ctx.has_br = training, bt is not None, br is not None
-        return out.view(B, Co, Tn, V)
+        out, saved, meta = wide_forward(X, A, T, Wt, bt, gt, bet, Wr, br, gr, ber, slope, bn_t, bn_r, training, drop_p, drop_seed)
+        ctx.save_for_backward(*saved)
+        ctx.meta = meta
+        return out
 
     @staticmethod
     def backward(ctx, dOut):
-        X, Z, A, T, Wt, gt, bet, Wr, gr, ber, slope, Ct, Cr, st_t, st_r = ctx.saved_tensors
-        B, Ci, Tn, V = X.shape
-        Co, P = Wt.shape[0], Tn * V
-        Xv = X.view(B, Ci, P)
-        Crv = Cr if Cr is not None else Xv
-        dCt, dCr, dgt, dbet, dgr, dber, dslope = ops.bn2_bwd(Ct, Crv, dOut.contiguous().view(B, Co, P), st_t, gt, bet, st_r, gr, ber,
-                                                             slope, ctx.training, *ctx.drop)
-        Wt2 = Wt.view(Co, Ci)
-        dWt = ops.conv1x1_wgrad(dCt, Z.view(B, Ci, P), torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
-        dZ = ops.conv1x1(Wt2.t(), dCt)[0].view(B, Ci, Tn, V)
-        # dA, dT and dX = gcn^T(dZ) from ONE pass over dZ (csrc/stsgcn_bwd.hip: k_bwd_gcn_params writes the adjoint mix too); an
-        # identity residual's gradient joins it there instead of in an add of its own
-        dA, dT, dX = ops.gcn_bwd_params_dx(X, dZ, A, T, add=None if Wr is not None else dCr.view(B, Ci, Tn, V))
-        dWr = dbr = None
-        if Wr is not None:
-            dWr = ops.conv1x1_wgrad(dCr, Xv, torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
-            ops.conv1x1(Wr.view(Co, Ci).t(), dCr, out=dX.view(B, Ci, P), accumulate=True)
-            if ctx.has_br:      # a bias in front of a BatchNorm: its gradient is the sum of a mean-free tensor (exactly 0 in training)
-                dbr = dCr.sum((0, 2)) if not ctx.training else torch.zeros(Co, device=X.device, dtype=torch.float32)
-        dbt = None
-        if ctx.has_bt:
-            dbt = dCt.sum((0, 2)) if not ctx.training else torch.zeros(Co, device=X.device, dtype=torch.float32)
-        return (dX, dA, dT, dWt.view_as(Wt), dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope.view_as(slope), None, None, None, None, None)
+        return wide_backward(ctx.saved_tensors, ctx.meta, dOut) + (None, None, None, None, None)
 
 
 class ST_GCNN_layer(nn.Module):
@@ -289,14 +304,18 @@ class ST_GCNN_layer(nn.Module):
         native NCHW layout -- mixing (coskad_gcn_f32 + adjoint + dA/dT), both 1x1 convolutions and their gradients on the
         strided MFMA GEMM (csrc/gemm.hip), BatchNorm statistics / normalise + residual add + PReLU and their backward on
         csrc/wide.hip.  X is the post-activation input; returns the activated output."""
+        return _WideLayerFn.apply(X, *self.wide_args())
+
+    def wide_args(self):
+        """the arguments of wide_forward behind X, for this layer in its current mode"""
         has_res = not isinstance(self.residual, nn.Identity)
         tc, tb = self.tcn[0], self.tcn[1]
         rc, rb = (self.residual[0], self.residual[1]) if has_res else (None, None)
         check_bn(tb, rb)
-        return _WideLayerFn.apply(X, self.gcn.A, self.gcn.T, tc.weight, tc.bias, tb.weight, tb.bias,
-                                  rc.weight if has_res else None, rc.bias if has_res else None,
-                                  rb.weight if has_res else None, rb.bias if has_res else None, self.prelu.weight,
-                                  tb, rb, self.training, *self._dropout_args())
+        return (self.gcn.A, self.gcn.T, tc.weight, tc.bias, tb.weight, tb.bias,
+                rc.weight if has_res else None, rc.bias if has_res else None,
+                rb.weight if has_res else None, rb.bias if has_res else None, self.prelu.weight,
+                tb, rb, self.training, *self._dropout_args())
 
     def _dropout_args(self):
         """(p, seed) of this forward's train-mode Dropout mask: the seed is drawn from torch's CPU generator, so

@@ -89,7 +89,11 @@ class STSETrainStep:
         self.v = torch.zeros_like(self.fp.flat)
         self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], device=dev, dtype=torch.float32)
         self.lr = float(lr)
-        self.layers = [layer_tensors(l) for l in model.encoder.model]
+        # an encoder with layers beyond the LDS tile kernels (the wide C = 2 -> 256 stack, dropout) runs as a _FlatStack: tile runs
+        # through engine.chain_*, wide layers through their explicit forward / backward -- same flat buffers, same fused Adam
+        self.wide = any(l.is_wide for l in model.encoder.model)
+        self.layers = [] if self.wide else [layer_tensors(l) for l in model.encoder.model]
+        self.stack = _FlatStack(list(model.encoder.model), self.fp, "encoder.model.") if self.wide else None
         self.ws = engine.Workspace()
         self.center_acc = torch.zeros(ops.HEAD_SLOTS, device=dev, dtype=torch.float32)
         L = model.latent_dim
@@ -111,8 +115,10 @@ class STSETrainStep:
         # optional SyncBN of the encoder's BatchNorm2d layers (the reference's DDP keeps per-rank statistics): every
         # BatchNorm boundary of the forward and the backward adds the other ranks' fp64 sums (engine.chain_forward / _backward)
         self.sync_group = None
+        if self.wide and (side_stream or use_graph):
+            raise ValueError("an encoder with wide layers runs on the main stream, outside hipGraph capture")
         if sync_bn and self.world > 1:
-            if self.mlp or side_stream or use_graph:
+            if self.mlp or side_stream or use_graph or self.wide:
                 raise ValueError("sync_bn: encoder BatchNorm only (STS-GCN encoder within the tile kernels, linear projector), on the "
                                  "main stream, outside hipGraph capture")
             self.sync_group = process_group if process_group is not None else dist.group.WORLD
@@ -154,8 +160,14 @@ class STSETrainStep:
     def _body(self, x: Tensor) -> Tensor:
         m = self.model
         B = x.shape[0]
-        U, ctx = engine.chain_forward(x, self.layers, True, self.ws, want_ctx=True, sync=self.sync_group)
-        slope = self.layers[-1].slope
+        if self.stack is None:
+            U, ctx = engine.chain_forward(x, self.layers, True, self.ws, want_ctx=True, sync=self.sync_group)
+            slope, top_layers, last_slope_grad = self.layers[-1].slope, self.layers, self.grads[-1]["slope"]
+        else:
+            U, slope, saved_stack = self.stack.forward(x, self.ws)      # slope None: the stack ended in a wide layer (activated output)
+            ctx, top_layers = self.stack.top(saved_stack)
+            top_layers = top_layers or []
+            last_slope_grad = self.stack.last_slope_grad
         gv = self.fp.gviews
         if self.mlp:
             # mlp projector (components.py:209-226): wide Linear on the bottleneck kernel (PReLU on load), then every
@@ -188,14 +200,17 @@ class STSETrainStep:
             for y_in, stat, bn, lin, bname, lname in reversed(saved):
                 g = {"gamma": gv[bname + "weight"], "beta": gv[bname + "bias"], "W2": gv[lname + "weight"], "b2": gv.get(lname + "bias")}
                 dz = ops.mlp_head_bwd(y_in, stat, bn.weight, bn.bias, lin.weight, dz, g, True)
-        dU, top_stats = engine.btlnk_backward(ctx if self.side is None else None, self.layers, U, W, dz, slope, gv[wname + "weight"],
-                                              gv.get(wname + "bias"), self.grads[-1]["slope"], self.ws)
+        dU, top_stats = engine.btlnk_backward(ctx if self.side is None else None, top_layers, U, W, dz, slope, gv[wname + "weight"],
+                                              gv.get(wname + "bias"), last_slope_grad, self.ws)
         work = None
         if self.world > 1 and self.tail_off is not None:
             # bucket 1 (87 % of the bytes: the bottleneck weight) is complete now: its all-reduce runs on the collective
             # stream while the encoder backward proceeds (SUM; the 1/W is folded into Adam)
             work = dist.all_reduce(self.fp.grad[self.tail_off:], group=self.pg, async_op=True)
-        engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False, side=self.side, stats_in=top_stats)
+        if self.stack is None:
+            engine.chain_backward(ctx, self.layers, dU, self.ws, self.grads, need_dx=False, side=self.side, stats_in=top_stats)
+        else:
+            self.stack.backward(saved_stack, dU, self.ws, need_dx=False, top_stats=top_stats)
         if self.world > 1:
             head = self.fp.grad if work is None else self.fp.grad[:self.tail_off]
             dist.all_reduce(head, group=self.pg)           # bucket 2: the encoder's gradients (0.12 MB)
@@ -265,7 +280,8 @@ class _FlatStack:
     """A stack of ST_GCNN layers (Encoder / Decoder `model`, components.py:70-105,143-179) on flat parameter / gradient
     buffers: runs of layers the LDS tile kernels take go through engine.chain_forward / chain_backward (no autograd);
     a layer beyond them (`is_wide`: 64 input channels on the 25-joint layout, > 64 channels, dropout) runs its composed
-    HIP path under a LOCAL autograd graph whose gradients are copied into the flat buffer."""
+    HIP path (stsgcn.wide_forward / wide_backward: explicit forward and backward, no autograd), gradients written to the flat
+    buffer's views."""
 
     def __init__(self, modules, fp: "FlatParams", prefix: str) -> None:
         self.segs = []                 # ('tile', [LayerTensors], [grad dicts]) | ('wide', module, names)
@@ -293,12 +309,12 @@ class _FlatStack:
                 saved.append(ctx)
                 h, slope = u, seg[1][-1].slope
             else:
+                from .models.graph_layers.stsgcn import wide_forward
                 pre_u, pre_slope = (h, slope) if slope is not None else (None, None)
-                xin = (ops.prelu_fwd(h, slope) if slope is not None else h).detach().requires_grad_(True)
-                with torch.enable_grad():
-                    out = seg[1].forward_wide(xin)
-                saved.append((xin, out, pre_u, pre_slope))
-                h, slope = out.detach(), None
+                xin = ops.prelu_fwd(h, slope) if slope is not None else h
+                out, wsaved, wmeta = wide_forward(xin, *seg[1].wide_args())
+                saved.append((wsaved, wmeta, pre_u, pre_slope))
+                h, slope = out, None
         return h, slope, saved
 
     def top(self, saved):
@@ -317,14 +333,16 @@ class _FlatStack:
                 d = engine.chain_backward(sv, seg[1], d, ws, seg[2], need_dx=need_dx or not first,
                                           stats_in=top_stats if k == len(self.segs) - 1 else None)
             else:
-                xin, out, pre_u, pre_slope = sv
-                mod, prefix = seg[1], seg[2]
-                named = [(n, p) for n, p in mod.named_parameters()]
+                from .models.graph_layers.stsgcn import wide_backward
+                wsaved, wmeta, pre_u, pre_slope = sv
+                prefix = seg[2]
                 want_x = need_dx or not first
-                res = torch.autograd.grad(out, ([xin] if want_x else []) + [p for _, p in named], d)
-                off = 1 if want_x else 0
-                for (n, _), g in zip(named, res[off:]):
-                    self.fp.gviews[prefix + n].copy_(g)
+                res = wide_backward(wsaved, wmeta, d, need_dx=want_x)
+                names = ("gcn.A", "gcn.T", "tcn.0.weight", "tcn.0.bias", "tcn.1.weight", "tcn.1.bias", "residual.0.weight",
+                         "residual.0.bias", "residual.1.weight", "residual.1.bias", "prelu.weight")
+                for n, g in zip(names, res[1:]):
+                    if g is not None:
+                        self.fp.gviews[prefix + n].copy_(g.view_as(self.fp.gviews[prefix + n]))
                 d = res[0] if want_x else None
                 if d is not None and pre_u is not None:
                     # the wide layer consumed PReLU(pre_u): back through it, into the producing tile run's last slope
@@ -502,8 +520,8 @@ class STSAETrainStep:
 
 
 class AutogradTrainStep:
-    """Same interface as STSETrainStep for models the flat-buffer fast path does not take: the `mlp` projector (what 5
-    of the reference's 7 yamls select), the plain-GCN encoders, wide stacks.  Forward / backward go through the module
+    """Same interface as STSETrainStep for models the flat-buffer path does not take: the plain-GCN encoders, `mlp` projectors and
+    latents beyond the bottleneck kernels' widths.  Forward / backward go through the module
     surface (autograd nodes around the HIP kernels, library GEMMs where the module uses them); the one-class head and
     its gradient are the HIP head kernels (`z.backward(dz)`), the regulariser gradient is added to `.grad`, the
     optimiser is torch's Adam (calc_reg_loss / configure_optimizers of the reference wrappers)."""
@@ -566,14 +584,19 @@ class AutogradTrainStep:
 
 
 def make_train_step(model, **kw):
-    """STSETrainStep when the model is the fused STS-GCN encoder + linear projector, AutogradTrainStep otherwise."""
+    """STSETrainStep (flat buffers, fused Adam, no autograd) for every STS-GCN encoder -- tile kernels and wide layers alike -- with a
+    linear or in-width mlp projector; AutogradTrainStep for what is left: the plain-GCN encoders, projectors / latents beyond the
+    bottleneck kernels."""
     from .models.common.components import Encoder
     from .models.common.components import MLP
     btl = getattr(model, 'btlnk', None)
     proj_ok = isinstance(btl, torch.nn.Linear) or (isinstance(btl, MLP) and btl.hip_ok)
-    fast = (proj_ok and isinstance(getattr(model, 'encoder', None), Encoder)
-            and not any(l.is_wide for l in model.encoder.model) and model.latent_dim <= 16)
+    fast = proj_ok and isinstance(getattr(model, 'encoder', None), Encoder) and model.latent_dim <= 16
     if fast:
+        if any(l.is_wide for l in model.encoder.model):     # wide layers: main stream, eager launches
+            kw.pop('use_graph', None); kw.pop('side_stream', None)
+            if kw.get('sync_bn') and not (dist.is_available() and dist.is_initialized() and dist.get_world_size(kw.get('process_group')) > 1):
+                kw.pop('sync_bn')
         return STSETrainStep(model, **kw)
     kw.pop('use_graph', None); kw.pop('side_stream', None)
     if kw.pop('sync_bn', False):

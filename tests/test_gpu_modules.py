@@ -274,7 +274,7 @@ def test_wide_stack_c256_vs_oracle():
 
 def test_autograd_train_step_matches_fast_path_and_handles_mlp():
     """AutogradTrainStep (module surface + torch Adam) == STSETrainStep (flat buffers + HIP Adam) on a model both take;
-    make_train_step routes the `mlp` projector and the plain-GCN encoders to it."""
+    make_train_step routes the plain-GCN encoders to it (the `mlp` projector and wide stacks stay on the flat step)."""
     from coskad_amd.models.sts.ae import STSE
     from coskad_amd.trainer import AutogradTrainStep, STSETrainStep, make_train_step
     from oracle import ref_cpu as R
@@ -710,3 +710,52 @@ def test_mlp_projector_batchnorm_momentum_none_stays_on_the_kernels():
         np.testing.assert_allclose(z.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-4)
         np.testing.assert_allclose(mlp.net[1].running_var.cpu().numpy(), twin[1].running_var.numpy(), rtol=1e-4, atol=1e-6)
         assert int(mlp.net[1].num_batches_tracked) == step + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chans,hid", [((64, 128, 256), 256), ((32, 128, 16), 64)])
+def test_flat_train_step_on_wide_stacks(chans, hid):
+    """STSETrainStep (flat buffers, fused Adam, explicit wide_forward / wide_backward) on stacks with layers beyond the tile
+    kernels -- the C = 2 -> 256 stack (wide layers last) and a stack with a wide layer BETWEEN tile runs: the gradients it leaves in
+    the flat buffer equal the oracle's autograd (reference components.py:70-105, stsgcn.py:94-116), and three steps equal
+    AutogradTrainStep's (module surface + torch Adam) parameters and running statistics; make_train_step selects it."""
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.trainer import AutogradTrainStep, STSETrainStep, make_train_step
+    from oracle import ref_cpu as R
+    st = R.init_stse_state(2, chans, hid, 16, 12, 17, seed=2)
+    st["c"] = torch.full((16,), 0.05)
+    x = R.synthetic_clips(6, seed=8)
+
+    def build():
+        m = STSE(2, list(chans), hid, 16, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0)
+        m.load_state_dict({k: v.clone() for k, v in st.items()}, strict=True)
+        return m.cuda().train()
+
+    m = build()
+    assert any(l.is_wide for l in m.encoder.model)
+    eng = make_train_step(m, lr=0.0, alpha=0.0, head='euclidean')           # lr 0: the step leaves the gradients, not an update
+    assert isinstance(eng, STSETrainStep) and eng.stack is not None
+    stats = eng.step(x.cuda())
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if R.is_param_key(k) and v.is_floating_point()}
+    sto = dict(st)
+    sto.update(params)
+    lref = R.mse_to_center(R.stse_encode(x, sto, training=True), st["c"])
+    lref.backward()
+    np.testing.assert_allclose(float(stats[0]), float(lref.detach()), rtol=1e-4)
+    for k in eng.fp.names:
+        if k.endswith(("tcn.0.bias", "residual.0.bias")):
+            continue
+        ref = params[k].grad.numpy()
+        np.testing.assert_allclose(eng.fp.gviews[k].cpu().numpy(), ref, rtol=5e-3, atol=1e-3 * np.abs(ref).max() + 1e-9, err_msg=k)
+    outs = []
+    for cls in (STSETrainStep, AutogradTrainStep):
+        m = build()
+        e = cls(m, lr=1e-3, alpha=1e-4, head='euclidean')
+        losses = [float(e.step(x.cuda())[0]) for _ in range(3)]
+        outs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-4)
+    for k in outs[0][1]:
+        if k.endswith(("tcn.0.bias", "residual.0.bias")):
+            continue
+        a, b = outs[0][1][k].float().numpy(), outs[1][1][k].float().numpy()
+        np.testing.assert_allclose(a, b, rtol=5e-3, atol=5e-3 * 1e-3 + 1e-4 * np.abs(b).max(), err_msg=k)
