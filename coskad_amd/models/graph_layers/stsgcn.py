@@ -201,32 +201,41 @@ def wide_forward(X, A, T, Wt, bt, gt, bet, Wr, br, gr, ber, slope, bn_t, bn_r, t
     return out.view(B, Co, Tn, V), saved, meta
 
 
-def wide_backward(saved, meta, dOut, need_dx: bool = True):
-    """-> (dX, dA, dT, dWt, dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope) of wide_forward (None where the layer has no such tensor)."""
+def wide_backward(saved, meta, dOut, need_dx: bool = True, into: Optional[dict] = None):
+    """-> (dX, dA, dT, dWt, dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope) of wide_forward (None where the layer has no such tensor).
+    `into`: destinations keyed by the layer's state_dict names ('gcn.A', 'tcn.0.weight', ...: views of a flat gradient buffer) --
+    the kernels then write there (conv biases in front of a train-mode BatchNorm are not written: their gradient is exactly 0)."""
+    into = into or {}
     X, Z, A, T, Wt, gt, bet, Wr, gr, ber, slope, Ct, Cr, st_t, st_r = saved
     training, has_bt, has_br, drop = meta
     B, Ci, Tn, V = X.shape
     Co, P = Wt.shape[0], Tn * V
     Xv = X.view(B, Ci, P)
     Crv = Cr if Cr is not None else Xv
-    dCt, dCr, dgt, dbet, dgr, dber, dslope = ops.bn2_bwd(Ct, Crv, dOut.contiguous().view(B, Co, P), st_t, gt, bet, st_r, gr, ber,
-                                                         slope, training, *drop)
+    dst = lambda n, shape=None: None if into.get(n) is None else (into[n] if shape is None else into[n].view(shape))
+    dCt, dCr, dgt, dbet, dgr, dber, dslope = ops.bn2_bwd(
+        Ct, Crv, dOut.contiguous().view(B, Co, P), st_t, gt, bet, st_r, gr, ber, slope, training, *drop,
+        into={"gt": dst("tcn.1.weight"), "bt": dst("tcn.1.bias"), "gr": dst("residual.1.weight"), "br": dst("residual.1.bias"),
+              "slope": dst("prelu.weight", (1,))})
     Wt2 = Wt.view(Co, Ci)
-    dWt = ops.conv1x1_wgrad(dCt, Z.view(B, Ci, P), torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
+    dWt_out = dst("tcn.0.weight", (Co, Ci))
+    dWt = ops.conv1x1_wgrad(dCt, Z.view(B, Ci, P), dWt_out if dWt_out is not None else torch.empty(Co, Ci, device=X.device, dtype=torch.float32))
     dZ = ops.conv1x1(Wt2.t(), dCt)[0].view(B, Ci, Tn, V)
     # dA, dT and dX = gcn^T(dZ) from ONE pass over dZ (csrc/stsgcn_bwd.hip: k_bwd_gcn_params writes the adjoint mix too); an
     # identity residual's gradient joins it there instead of in an add of its own
-    dA, dT, dX = ops.gcn_bwd_params_dx(X, dZ, A, T, add=None if Wr is not None else dCr.view(B, Ci, Tn, V))
+    dA, dT, dX = ops.gcn_bwd_params_dx(X, dZ, A, T, add=None if Wr is not None else dCr.view(B, Ci, Tn, V),
+                                       dA=dst("gcn.A"), dT=dst("gcn.T"))
     dWr = dbr = None
     if Wr is not None:
-        dWr = ops.conv1x1_wgrad(dCr, Xv, torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
+        dWr_out = dst("residual.0.weight", (Co, Ci))
+        dWr = ops.conv1x1_wgrad(dCr, Xv, dWr_out if dWr_out is not None else torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
         if need_dx:
             ops.conv1x1(Wr.view(Co, Ci).t(), dCr, out=dX.view(B, Ci, P), accumulate=True)
         if has_br:      # a bias in front of a BatchNorm: its gradient is the sum of a mean-free tensor (exactly 0 in training)
-            dbr = dCr.sum((0, 2)) if not training else torch.zeros(Co, device=X.device, dtype=torch.float32)
+            dbr = dCr.sum((0, 2)) if not training else (None if into else torch.zeros(Co, device=X.device, dtype=torch.float32))
     dbt = None
     if has_bt:
-        dbt = dCt.sum((0, 2)) if not training else torch.zeros(Co, device=X.device, dtype=torch.float32)
+        dbt = dCt.sum((0, 2)) if not training else (None if into else torch.zeros(Co, device=X.device, dtype=torch.float32))
     return dX, dA, dT, dWt.view_as(Wt), dbt, dgt, dbet, dWr, dbr, dgr, dber, dslope.view_as(slope)
 
 

@@ -771,15 +771,21 @@ def dropout_mask(shape, drop_p: float, drop_seed: int, device) -> Tensor:
     return out
 
 
-def bn2_bwd(Ct, Cr, dOut, stat_t, gt, bt, stat_r, gr, br, slope, training: bool, drop_p: float = 0.0, drop_seed: int = 0):
-    """-> (dCt, dCr, dgt, dbt, dgr, dbr, dslope) (residual gradients None for an identity residual)."""
+def bn2_bwd(Ct, Cr, dOut, stat_t, gt, bt, stat_r, gr, br, slope, training: bool, drop_p: float = 0.0, drop_seed: int = 0,
+            into: Optional[dict] = None):
+    """-> (dCt, dCr, dgt, dbt, dgr, dbr, dslope) (residual gradients None for an identity residual).  `into`: destinations for the
+    parameter gradients ('gt', 'bt', 'gr', 'br', 'slope': e.g. views of a flat gradient buffer) instead of fresh tensors."""
     Nb, C, P = Ct.shape
     _chk(dOut, "dOut", (Nb, C, P))
+    into = into or {}
     dCt, dCr = torch.empty_like(Ct), torch.empty_like(Ct)
-    dgt, dbt = torch.empty_like(gt), torch.empty_like(bt)
-    dgr = torch.empty_like(gr) if stat_r is not None else None
-    dbr = torch.empty_like(br) if stat_r is not None else None
-    dslope = torch.empty(1, device=Ct.device, dtype=torch.float32)
+    dgt = into.get("gt") if into.get("gt") is not None else torch.empty_like(gt)
+    dbt = into.get("bt") if into.get("bt") is not None else torch.empty_like(bt)
+    dgr = (into.get("gr") if into.get("gr") is not None else torch.empty_like(gr)) if stat_r is not None else None
+    dbr = (into.get("br") if into.get("br") is not None else torch.empty_like(br)) if stat_r is not None else None
+    dslope = into.get("slope") if into.get("slope") is not None else torch.empty(1, device=Ct.device, dtype=torch.float32)
+    _chk(dgt, "dgt", (C,)); _chk(dbt, "dbt", (C,)); _chk(dgr, "dgr", (C,), optional=True); _chk(dbr, "dbr", (C,), optional=True)
+    _chk(dslope, "dslope", (1,))
     ws = _bn2_ws(Nb, C, Ct.device, bwd=True)
     call("coskad_bn2_bwd_f32", ptr(Ct), ptr(Cr), ptr(dOut), ptr(stat_t), ptr(gt), ptr(bt), ptr(stat_r), ptr(gr), ptr(br), ptr(slope),
          ptr(dCt), ptr(dCr), ptr(dgt), ptr(dbt), ptr(dgr), ptr(dbr), ptr(dslope), i32(1 if training else 0), ptr(ws),
@@ -1028,15 +1034,20 @@ def gcn_bwd_params(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor):
     return dA, dT
 
 
-def gcn_bwd_params_dx(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor, add: Optional[Tensor] = None):
-    """(dA, dT, dX) of ConvTemporalGraphical in one pass over dZ: dX = gcn^T(dZ) (+ add, e.g. an identity residual's gradient)."""
+def gcn_bwd_params_dx(x: Tensor, dZ: Tensor, A: Tensor, Tm: Tensor, add: Optional[Tensor] = None, dA: Optional[Tensor] = None,
+                      dT: Optional[Tensor] = None):
+    """(dA, dT, dX) of ConvTemporalGraphical in one pass over dZ: dX = gcn^T(dZ) (+ add, e.g. an identity residual's gradient);
+    dA / dT: destinations (e.g. views of a flat gradient buffer) instead of fresh tensors."""
     N, C, T, V = x.shape
     _chk(x, "x"); _chk(dZ, "dZ", x.shape); _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T)); _chk(add, "add", x.shape, optional=True)
     fn = _lib.lib().coskad_gcn_bwd_params_ws_bytes
     fn.restype = ctypes.c_size_t
     nbytes = fn(i32(T), i32(V))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    dA, dT, dX = torch.empty_like(A), torch.empty_like(Tm), torch.empty_like(x)
+    dA = torch.empty_like(A) if dA is None else dA
+    dT = torch.empty_like(Tm) if dT is None else dT
+    _chk(dA, "dA", (T, V, V)); _chk(dT, "dT", (V, T, T))
+    dX = torch.empty_like(x)
     call("coskad_gcn_bwd_params_dx_f32", ptr(x), ptr(dZ), ptr(A), ptr(Tm), ptr(dA), ptr(dT), ptr(dX), ptr(add), ptr(ws),
          ctypes.c_size_t(nbytes), i32(0), i32(N * C), i32(T), i32(V), _stream())
     return dA, dT, dX

@@ -337,12 +337,15 @@ class _FlatStack:
                 wsaved, wmeta, pre_u, pre_slope = sv
                 prefix = seg[2]
                 want_x = need_dx or not first
-                res = wide_backward(wsaved, wmeta, d, need_dx=want_x)
                 names = ("gcn.A", "gcn.T", "tcn.0.weight", "tcn.0.bias", "tcn.1.weight", "tcn.1.bias", "residual.0.weight",
                          "residual.0.bias", "residual.1.weight", "residual.1.bias", "prelu.weight")
+                # the kernels write straight into the flat gradient buffer's views; conv biases in front of a train-mode BatchNorm keep
+                # the exact 0 the buffer was created with (nothing ever writes them)
+                into = {n: self.fp.gviews[prefix + n] for n in names if prefix + n in self.fp.gviews}
+                res = wide_backward(wsaved, wmeta, d, need_dx=want_x, into=into)
                 for n, g in zip(names, res[1:]):
-                    if g is not None:
-                        self.fp.gviews[prefix + n].copy_(g.view_as(self.fp.gviews[prefix + n]))
+                    if g is not None and g.data_ptr() != into[n].data_ptr():      # (eval-statistics layers: bias sums)
+                        into[n].copy_(g.view_as(into[n]))
                 d = res[0] if want_x else None
                 if d is not None and pre_u is not None:
                     # the wide layer consumed PReLU(pre_u): back through it, into the producing tile run's last slope
