@@ -901,6 +901,55 @@ def poincare_logmap0(y):
     return out
 
 
+def _rows(t: Tensor, name: str, cols: int):
+    """a [B, cols] fp32 device view with unit column stride (a column block of a wider row-major tensor is fine) -> its row stride"""
+    _cuda_f32(t, name)
+    if t.dim() != 2 or t.shape[1] != cols or (cols > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: expected a [B, {cols}] view with contiguous columns, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0)
+
+
+def ps_head_forward(mean_raw: Tensor, var_raw: Tensor, generator=None):
+    """The spherical VAE's latent head on csrc/vae_head.hip (reference models/sts/vae.py:79-91,104-118; PowerSpherical restated in
+    coskad_amd/models/sts/vae.py): mean_raw [B, L], var_raw [B, 1] (views of one tensor are fine) -> (z [B, L] sampled latent,
+    kl [B], inv_kappa [B], saved) with saved = what ps_head_backward needs.  The Beta draw and the Gaussian direction are torch's
+    (torch._sample_dirichlet, torch.randn): the noise streams are the module path's."""
+    B, L = mean_raw.shape
+    ldm, ldv = _rows(mean_raw, "mean_raw", L), _rows(var_raw, "var_raw", 1)
+    dev = mean_raw.device
+    mu = torch.empty(B, L, device=dev, dtype=torch.float32)
+    kappa = torch.empty(B, device=dev, dtype=torch.float32)
+    conc = torch.empty(B, 2, device=dev, dtype=torch.float32)
+    total = torch.empty(B, device=dev, dtype=torch.float32)
+    call("coskad_ps_head_prep_f32", ptr(mean_raw), i32(ldm), ptr(var_raw), i32(ldv), ptr(mu), ptr(kappa), ptr(conc), ptr(total),
+         i32(B), i32(L), _stream())
+    x = torch._sample_dirichlet(conc, generator) if generator is not None else torch._sample_dirichlet(conc)
+    eps = torch.randn(B, L - 1, device=dev, dtype=torch.float32, generator=generator)
+    z = torch.empty(B, L, device=dev, dtype=torch.float32)
+    kl = torch.empty(B, device=dev, dtype=torch.float32)
+    ik = torch.empty(B, device=dev, dtype=torch.float32)
+    call("coskad_ps_head_sample_f32", ptr(x), ptr(eps), ptr(mu), ptr(kappa), ptr(z), ptr(kl), ptr(ik), i32(B), i32(L), _stream())
+    return z, kl, ik, (mean_raw, var_raw, mu, kappa, conc, total, x, eps)
+
+
+def ps_head_backward(saved, dz: Tensor, w_kl: float, w_exp: float, d_mean_raw: Optional[Tensor] = None,
+                     d_var_raw: Optional[Tensor] = None):
+    """-> (d_mean_raw [B, L], d_var_raw [B, 1]) for loss = <dz, z> + w_kl * sum kl + w_exp * sum inv_kappa; the destinations may be
+    column views of one [B, L + 1] tensor."""
+    mean_raw, var_raw, mu, kappa, conc, total, x, eps = saved
+    B, L = mean_raw.shape
+    _chk(dz, "dz", (B, L))
+    g = torch._dirichlet_grad(x, conc, total.unsqueeze(-1).expand(B, 2).contiguous())
+    if d_mean_raw is None:
+        d_mean_raw = torch.empty(B, L, device=dz.device, dtype=torch.float32)
+    if d_var_raw is None:
+        d_var_raw = torch.empty(B, 1, device=dz.device, dtype=torch.float32)
+    call("coskad_ps_head_bwd_f32", ptr(dz), ptr(x), ptr(g), ptr(eps), ptr(mu), ptr(kappa), ptr(mean_raw), i32(_rows(mean_raw, "mean_raw", L)),
+         ptr(var_raw), i32(_rows(var_raw, "var_raw", 1)), ctypes.c_float(w_kl), ctypes.c_float(w_exp), ptr(d_mean_raw),
+         i32(_rows(d_mean_raw, "d_mean_raw", L)), ptr(d_var_raw), i32(_rows(d_var_raw, "d_var_raw", 1)), i32(B), i32(L), _stream())
+    return d_mean_raw, d_var_raw
+
+
 def center_finalize(acc, eps: float, L: int):
     _chk(acc, "acc", (HEAD_SLOTS,))
     c = torch.empty(L, device=acc.device, dtype=torch.float32)

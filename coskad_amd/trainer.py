@@ -453,27 +453,39 @@ class STSAETrainStep:
                                                 lin.weight, lin.bias, True, momentum=ops.bn_momentum(bn), eps=bn.eps)
                     mlp_saved.append((y, stat, bn, lin, f"btlnk.net.{3 * i + 1}.", f"btlnk.net.{3 * i + 3}."))
                     y = zz
-                Hd = y.requires_grad_(True)
+                Hd = y
                 head_params = [m.fc_mean.weight, m.fc_mean.bias, m.fc_var.weight, m.fc_var.bias]
             else:
                 W = torch.cat([m.fc_mean.weight, m.fc_var.weight], 0)             # heads stacked: one pass over U
                 b = torch.cat([m.fc_mean.bias, m.fc_var.bias], 0)
-                Hd = ops.btlnk_fwd(U, W, b, slope, ws=self.ws).requires_grad_(True)
-            with torch.enable_grad():                                             # [B, latent] tensors: vae.py:79-91,104-118
+                Hd = ops.btlnk_fwd(U, W, b, slope, ws=self.ws)
+            if m.distribution == 'ps':
+                # the PowerSpherical head on csrc/vae_head.hip (normalise, softplus + 1, Householder sample, KL, 1 / kappa: three
+                # launches + torch's Beta draw instead of ~80 element-wise launches under autograd); the two small Linears of the
+                # `mlp` projector's heads ride on the strided GEMM with the weights stacked
                 if mlp:
-                    Z_mean, Z_var = m._finish_heads(m.fc_mean(Hd), m.fc_var(Hd), None, False)
+                    Wc = torch.cat([m.fc_mean.weight, m.fc_var.weight], 0)            # [L + 1, L]
+                    bc = torch.cat([m.fc_mean.bias, m.fc_var.bias], 0)
+                    H2 = ops.gemm(Hd, Wc.t(), bias=bc, bias_mode=2)
                 else:
-                    Z_mean, Z_var = m._finish_heads(Hd[:, :L], Hd[:, L:], None, False)
-                q, p = m.reparameterize(Z_mean, Z_var)
-                zs = q.rsample()
-                if m.distribution == 'normal':
+                    Wc, H2 = None, Hd
+                zs, kl_rows, ik_rows, ps_saved = ops.ps_head_forward(H2[:, :L], H2[:, L:L + 1])
+                out['head'], out['exp'] = kl_rows.mean().reshape(1), ik_rows.mean().reshape(1)
+                z_dec, graph = zs, ('ps', Hd, H2, Wc, ps_saved, mlp_saved)
+            else:
+                Hd.requires_grad_(True)
+                with torch.enable_grad():                                         # [B, latent] tensors: vae.py:79-91,104-118
+                    if mlp:
+                        Z_mean, Z_var = m._finish_heads(m.fc_mean(Hd), m.fc_var(Hd), None, False)
+                    else:
+                        Z_mean, Z_var = m._finish_heads(Hd[:, :L], Hd[:, L:], None, False)
+                    q, p = m.reparameterize(Z_mean, Z_var)
+                    zs = q.rsample()
                     loss_kl = torch.distributions.kl.kl_divergence(q, p).sum(-1).mean()
-                else:
-                    loss_kl = kl_ps_uniform(q, p).mean()
-                loss_exp = (1 / Z_var).mean()
-                small = self.beta * loss_kl + self.gamma * loss_exp
-            out['head'], out['exp'] = loss_kl.detach().reshape(1), loss_exp.detach().reshape(1)
-            z_dec, graph = zs.detach().contiguous(), (Hd, zs, small, head_params, mlp_saved)
+                    loss_exp = (1 / Z_var).mean()
+                    small = self.beta * loss_kl + self.gamma * loss_exp
+                out['head'], out['exp'] = loss_kl.detach().reshape(1), loss_exp.detach().reshape(1)
+                z_dec, graph = zs.detach().contiguous(), ('autograd', Hd, zs, small, head_params, mlp_saved)
             dz = None
         out['z'] = z_dec
         # rev_btlnk (ae.py:223-227): H = z Wr^T + br on the strided MFMA GEMM, straight into the decoder's [B, hid, T, V] view
@@ -491,13 +503,29 @@ class STSAETrainStep:
         if self.mode == 'ae':
             dHd = ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"], dz=dz)   # dz = d MSE(z, c) + dH Wr
         else:
-            Hd, zs, small, head_params, mlp_saved = graph
             dz_dec = ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"])
-            res = torch.autograd.grad([zs, small], [Hd] + head_params, [dz_dec, torch.ones_like(small)])
-            dHd = res[0].contiguous()
+            L = m.latent_dim
+            if graph[0] == 'ps':
+                _, Hd, H2, Wc, ps_saved, mlp_saved = graph
+                dH2 = torch.empty_like(H2)
+                ops.ps_head_backward(ps_saved, dz_dec, self.beta / B, self.gamma / B, dH2[:, :L], dH2[:, L:L + 1])
+                if mlp_saved is not None:
+                    # the two heads' Linears (weights stacked): dWc = dH2^T Hd, db = column sums, dHd = dH2 Wc
+                    dWc = ops.gemm_rows_outer(dH2, Hd.contiguous(), torch.empty(L + 1, L, device=dH2.device, dtype=torch.float32))
+                    dbc = dH2.sum(0)
+                    gv["fc_mean.weight"].copy_(dWc[:L]); gv["fc_var.weight"].copy_(dWc[L:])
+                    gv["fc_mean.bias"].copy_(dbc[:L]); gv["fc_var.bias"].copy_(dbc[L:])
+                    dHd = ops.gemm(dH2, Wc)
+                else:
+                    dHd = dH2
+            else:
+                _, Hd, zs, small, head_params, mlp_saved = graph
+                res = torch.autograd.grad([zs, small], [Hd] + head_params, [dz_dec, torch.ones_like(small)])
+                dHd = res[0].contiguous()
+                if mlp_saved is not None:
+                    for n, g_ in zip(("fc_mean.weight", "fc_mean.bias", "fc_var.weight", "fc_var.bias"), res[1:]):
+                        gv[n].copy_(g_)
             if mlp_saved is not None:
-                for n, g_ in zip(("fc_mean.weight", "fc_mean.bias", "fc_var.weight", "fc_var.bias"), res[1:]):
-                    gv[n].copy_(g_)
                 for y_in, stat, bn, lin, bname, lname in reversed(mlp_saved):
                     g = {"gamma": gv[bname + "weight"], "beta": gv[bname + "bias"], "W2": gv[lname + "weight"], "b2": gv.get(lname + "bias")}
                     dHd = ops.mlp_head_bwd(y_in, stat, bn.weight, bn.bias, lin.weight, dHd, g, True)
@@ -505,7 +533,7 @@ class STSAETrainStep:
         bb = lambda gW_, gb_: engine.btlnk_backward(tctx, tlayers, U, W, dHd, slope, gW_, gb_, self.enc.last_slope_grad, self.ws)
         if self.mode == 'ae':
             dU, top_stats = bb(gv["btlnk.weight"], gv.get("btlnk.bias"))
-        elif graph[4] is not None:          # mlp projector: the wide first Linear of the MLP
+        elif mlp_saved is not None:          # mlp projector: the wide first Linear of the MLP
             dU, top_stats = bb(gv["btlnk.net.0.weight"], gv.get("btlnk.net.0.bias"))
         else:
             gW = torch.empty_like(W)

@@ -406,6 +406,25 @@ int coskad_poincare_dist_f32(const float* zh, const float* c, float* score, int 
  * never call it, so it stands alone (no gradient entry). */
 int coskad_poincare_logmap0_f32(const float* y, float* out, int B, int L, hipStream_t stream);
 
+/* The spherical VAE's latent head between the raw outputs of fc_mean / fc_var and the decoder's input (models/sts/vae.py:79-91,
+ * 104-118; loss terms of models/spherical_vae.py:86-94; PowerSpherical of the un-vendored `power_spherical` package, restated in
+ * coskad_amd/models/sts/vae.py).  Rows are clips; mean_raw [B, L] and var_raw [B] are addressed with row strides ld_* (floats), so both
+ * may be columns of ONE [B, L + 1] tensor.  L <= 16.
+ *   prep  : mu = mean_raw / |mean_raw|, kappa = softplus(var_raw) + 1, concentration [B, 2] = ((L-1)/2 + kappa, (L-1)/2), total [B]
+ *   (the caller draws x ~ Dirichlet(concentration) [B, 2] and eps ~ N(0, I) [B, L-1]; torch._dirichlet_grad gives the sampler's
+ *    implicit reparameterisation gradient [B, 2] for the backward)
+ *   sample: z [B, L] = Householder(e1 -> mu) applied to [2 x_0 - 1, sqrt(1 - t^2) eps / |eps|]; kl [B] = KL(PowerSpherical(mu, kappa) ||
+ *           uniform on the sphere) per clip; inv_kappa [B] = 1 / kappa
+ *   bwd   : d_mean_raw, d_var_raw from dz (gradient w.r.t. z) and the weights w_kl = d loss / d kl[n], w_exp = d loss / d inv_kappa[n] */
+int coskad_ps_head_prep_f32(const float* mean_raw, int ld_mean, const float* var_raw, int ld_var, float* mu, float* kappa,
+                            float* concentration, float* total, int B, int L, hipStream_t stream);
+int coskad_ps_head_sample_f32(const float* x, const float* eps, const float* mu, const float* kappa, float* z, float* kl,
+                              float* inv_kappa, int B, int L, hipStream_t stream);
+int coskad_ps_head_bwd_f32(const float* dz, const float* x, const float* dirichlet_grad, const float* eps, const float* mu,
+                           const float* kappa, const float* mean_raw, int ld_mean, const float* var_raw, int ld_var, float w_kl,
+                           float w_exp, float* d_mean_raw, int ld_dmean, float* d_var_raw, int ld_dvar, int B, int L,
+                           hipStream_t stream);
+
 /* c = acc[1..L] / acc[17], then |c| < eps -> +-eps (staticCenter.py:118-121). */
 int coskad_center_finalize_f32(const float* acc, float* c, float eps, int L, hipStream_t stream);
 /* gyromidpoint from acc of coskad_poincare_head_f32 (hyperbolic_encoder.py:122,179). */

@@ -167,3 +167,68 @@ def test_flat_autoencoder_step_default_widths_vs_oracle():
     for k, v in so.items():
         if "running" in k:
             np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+class _GivenDirichlet(torch.autograd.Function):
+    """torch.distributions.dirichlet._Dirichlet with the draw handed in: forward returns x, backward is _Dirichlet_backward."""
+
+    @staticmethod
+    def forward(ctx, conc, x):
+        ctx.save_for_backward(x, conc)
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        x, conc = ctx.saved_tensors
+        total = conc.sum(-1, True).expand_as(conc)
+        grad = torch._dirichlet_grad(x, conc, total)
+        return grad * (go - (x * go).sum(-1, True)), None
+
+
+@pytest.mark.parametrize("L", [2, 8, 16])
+def test_power_spherical_head_kernels_vs_torch_autograd(L):
+    """csrc/vae_head.hip against the torch restatement it replaces in the flat VAE step (coskad_amd/models/sts/vae.py: _finish_heads,
+    PowerSpherical.rsample / entropy, kl_ps_uniform; reference vae.py:79-91,104-118, spherical_vae.py:86-94) on the SAME noise: sample,
+    per-clip KL and 1 / kappa, and the gradients of  <w, z> + w_kl sum kl + w_exp sum 1/kappa  w.r.t. the raw head outputs (columns
+    of one [B, L + 1] tensor), incl. rows near the poles and large / small concentrations."""
+    import torch.nn.functional as F
+    from coskad_amd import ops
+    from coskad_amd.models.sts.vae import HypersphericalUniform, PowerSpherical, kl_ps_uniform
+    g = torch.Generator().manual_seed(5 + L)
+    B = 700
+    H2 = torch.randn(B, L + 1, generator=g)
+    H2[:, L] = torch.linspace(-6, 25, B)                 # softplus region, identity region (> 20)
+    H2[0, :L] = 0.0; H2[0, 0] = 3.0                       # mu = e1: the Householder vector degenerates (F.normalize's eps)
+    H2[1, :L] = 0.0; H2[1, 0] = -2.0                      # mu = -e1
+    w = torch.randn(B, L, generator=g)
+    w_kl, w_exp = 0.3 / B, 0.2 / B
+    dev = torch.device("cuda")
+    H2d = H2.to(dev)
+    z, kl, ik, saved = ops.ps_head_forward(H2d[:, :L], H2d[:, L:L + 1])
+    dH2 = torch.empty_like(H2d)
+    ops.ps_head_backward(saved, w.to(dev), w_kl, w_exp, dH2[:, :L], dH2[:, L:L + 1])
+    x, eps = saved[6], saved[7]
+    # ---- the torch restatement on the same draws -----------------------------------------------------------------------------------
+    Hr = H2d.clone().requires_grad_(True)
+    Z_mean = Hr[:, :L] / torch.norm(Hr[:, :L], dim=-1, keepdim=True)
+    Z_var = F.softplus(Hr[:, L:]) + 1
+    q = PowerSpherical(loc=Z_mean, scale=Z_var.squeeze(-1))
+    zb = _GivenDirichlet.apply(torch.stack([q.alpha, q.beta], -1), x)[..., 0]
+    t = (2 * zb - 1).unsqueeze(-1)
+    v = F.normalize(eps, dim=-1)
+    y = torch.cat([t, torch.sqrt(torch.clamp(1 - t * t, min=0)) * v], -1)
+    e1 = torch.zeros_like(Z_mean)
+    e1[..., 0] = 1
+    u = F.normalize(e1 - Z_mean, dim=-1)
+    z_ref = y - 2 * (y * u).sum(-1, keepdim=True) * u
+    kl_ref = kl_ps_uniform(q, HypersphericalUniform(L - 1, device=dev))
+    ik_ref = (1 / Z_var).squeeze(-1)
+    ((z_ref * w.to(dev)).sum() + w_kl * kl_ref.sum() + w_exp * ik_ref.sum()).backward()
+    np.testing.assert_allclose(z.cpu().numpy(), z_ref.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(kl.cpu().numpy(), kl_ref.detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(ik.cpu().numpy(), ik_ref.detach().cpu().numpy(), rtol=1e-6)
+    ref = Hr.grad.cpu().numpy()
+    got = dH2.cpu().numpy()
+    ok = np.isfinite(ref).all(axis=1)                     # (mu = e1 exactly: torch's own gradient is 0 / 0 there)
+    assert ok.sum() >= B - 2
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-3, atol=2e-6 + 2e-4 * np.abs(ref[ok]).max())
