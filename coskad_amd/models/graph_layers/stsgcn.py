@@ -177,6 +177,10 @@ class _PReLUFn(torch.autograd.Function):
         return du, dslope
 
 
+import os as _os
+WIDE_RES_ADD = _os.environ.get("COSKAD_WIDE_RES_ADD", "1") != "0"   # (A/B hook: 0 = accumulate Wr^T dCr into dX behind the adjoint mix)
+
+
 def wide_forward(X, A, T, Wt, bt, gt, bet, Wr, br, gr, ber, slope, bn_t, bn_r, training, drop_p=0.0, drop_seed=0):
     """out = PReLU(BN_t(Wt . gcn(X) + bt) + BN_r(Wr . X + br))  (identity residual when Wr is None) for one wide layer
     (reference stsgcn.py:106-110) -> (out [B, Co, T, V], saved, meta) for wide_backward; no autograd involved."""
@@ -223,13 +227,20 @@ def wide_backward(saved, meta, dOut, need_dx: bool = True, into: Optional[dict] 
     dZ = ops.conv1x1(Wt2.t(), dCt)[0].view(B, Ci, Tn, V)
     # dA, dT and dX = gcn^T(dZ) from ONE pass over dZ (csrc/stsgcn_bwd.hip: k_bwd_gcn_params writes the adjoint mix too); an
     # identity residual's gradient joins it there instead of in an add of its own
-    dA, dT, dX = ops.gcn_bwd_params_dx(X, dZ, A, T, add=None if Wr is not None else dCr.view(B, Ci, Tn, V),
-                                       dA=dst("gcn.A"), dT=dst("gcn.T"))
+    # the residual branch's data gradient joins the adjoint mix as its `add` input (an identity residual: dCr itself; a conv residual:
+    # Wr^T dCr formed first) instead of a read-modify-write pass over dX behind it
+    if Wr is None:
+        add = dCr.view(B, Ci, Tn, V)
+    elif need_dx and WIDE_RES_ADD:
+        add = ops.conv1x1(Wr.view(Co, Ci).t(), dCr)[0].view(B, Ci, Tn, V)
+    else:
+        add = None
+    dA, dT, dX = ops.gcn_bwd_params_dx(X, dZ, A, T, add=add, dA=dst("gcn.A"), dT=dst("gcn.T"))
     dWr = dbr = None
     if Wr is not None:
         dWr_out = dst("residual.0.weight", (Co, Ci))
         dWr = ops.conv1x1_wgrad(dCr, Xv, dWr_out if dWr_out is not None else torch.empty(Co, Ci, device=X.device, dtype=torch.float32)).view_as(Wr)
-        if need_dx:
+        if need_dx and add is None:
             ops.conv1x1(Wr.view(Co, Ci).t(), dCr, out=dX.view(B, Ci, P), accumulate=True)
         if has_br:      # a bias in front of a BatchNorm: its gradient is the sum of a mean-free tensor (exactly 0 in training)
             dbr = dCr.sum((0, 2)) if not training else (None if into else torch.zeros(Co, device=X.device, dtype=torch.float32))
