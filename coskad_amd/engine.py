@@ -266,12 +266,14 @@ def btlnk_backward(ctx: Optional[ChainCtx], layers: List[LayerTensors], U: Tenso
 
 def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Workspace,
                    grads: List[Dict[str, Tensor]], need_dx: bool, accumulate: bool = False,
-                   side: Optional[SideStream] = None, stats_in=None) -> Optional[Tensor]:
+                   side: Optional[SideStream] = None, stats_in=None, in_slope_grad: Optional[Tensor] = None) -> Optional[Tensor]:
     """Backward through the chain.  `grads[i]` maps A,T,Wt,bt,gt,bet,Wr,br,gr,ber,slope -> tensors to
     fill for layer i.  The slope gradient of layer i is produced while back-propagating through
     layer i+1 (its consumer); the caller owns the last layer's slope gradient.
     With `side`, dA / dT are computed on its stream (joined into the current stream before returning).
     `stats_in`: (chain buffer, rows) of the TOP layer's batch reductions when the producer of dU formed them (btlnk_backward).
+    `in_slope_grad`: where the gradient of ctx.in_slope goes (the PReLU weight of a layer in front of this chain that handed over
+    its pre-activation: coskad_amd/lowrank.py); None: nobody owns it.
     Returns d(inputs[0]) if need_dx."""
     n = len(layers)
     if side is not None and stats_in is not None:
@@ -291,6 +293,8 @@ def chain_backward(ctx: ChainCtx, layers: List[LayerTensors], dU: Tensor, ws: Wo
         g.pop("slope", None)
         if i > 0:
             g["slope_in"] = grads[i - 1]["slope"]
+        elif in_slope_grad is not None and in_slope is not None:
+            g["slope_in"] = in_slope_grad
         want_dx = need_dx or i > 0
         buf = ws.get(ops.layer_bwd_ws_bytes(B, Ci, L.Co, T, V), x_in.device)
         args = (x_in, dU, L.A, L.T, in_slope, ctx.stats[i], L.w2(L.Wt), L.gt, L.w2(L.Wr), L.gr, _as2d(g), buf)

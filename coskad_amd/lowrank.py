@@ -1,0 +1,145 @@
+"""The decoder's first ST_GCNN layer behind `rev_btlnk`, folded into ONE streaming pass (training mode).
+
+`rev_btlnk` (reference models/sts/ae.py:223-227) maps the latent z [B, Lz] LINEARLY to the decoder's input H = Wrev z + brev, and
+everything the first layer does in front of its BatchNorms is linear too (mixing and 1x1 convolutions: models/graph_layers/
+stsgcn.py:106-110,154-155).  With zt = [z, 1] in R^K, K = Lz + 1, and the K "basis images" Hb = (columns of Wrev, brev):
+
+    t[n] = Wt gcn(H[n]) + bt = sum_l zt_l[n] P_l,   P_l = Wt gcn(Hb_l) (+ bt on the last)
+    r[n] = Wr H[n] + br      = sum_l zt_l[n] Q_l,   Q_l = Wr Hb_l      (+ br on the last;  Q = Hb for an identity residual)
+
+The training-mode batch statistics of t and r over (clips, positions) follow from the K x K Gram matrix G = sum_n zt zt^T alone:
+
+    mean_c = 1/N sum_l G[l, K-1] sum_p X_l[c, p],      E[x^2]_c = 1/N sum_{l,m} G[l, m] sum_p X_l[c, p] X_m[c, p]       (X = P, Q)
+
+so the layer's pre-activation output is  U1[n] = sum_l zt_l[n] M_l  with the folded images  M_l = a_t P_l + a_r Q_l  (+ the BatchNorm
+shifts on the last): the rev_btlnk forward kernel (csrc/rev_btlnk.hip) with M as its weight -- one pass that writes [B, C_out, T, V] --
+instead of rev_btlnk, the mixing, two convolutions and a BatchNorm / add pass over [B, 64, T, V] tensors (the layer is `wide` on the
+25-joint layout: 64 input channels do not fit the LDS tile kernels).  Backward: the rev_btlnk backward kernel with M as its weight
+returns dM_l = sum_n zt_l[n] dU1[n] and the direct part of dz; how M depends on the layer's parameters, on Wrev / brev (K images: tiny
+tensors) and on G is differentiated by torch autograd on [K, C, T V] tensors; dz += zt (dG + dG^T).  Same function, same gradients
+(tests/test_gpu_ae_step.py holds it against the REFERENCE's gradients, tests/golden/stsae_v25.npz); V = 25 spherical-VAE step
+7.0 -> 5.5 ms.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+Tensor = torch.Tensor
+
+# which decoders take the folded first layer: 'wide' = only where the layer would run the composed wide path (64 input channels on
+# the 25-joint layout), 'always', 'never' (tests flip it)
+MODE = 'wide'
+
+
+class LowRankFirstLayer:
+    def __init__(self, rev: nn.Linear, layer, gviews: dict, rev_prefix: str = "rev_btlnk.", layer_prefix: str = "decoder.model.0.") -> None:
+        self.rev, self.layer, self.gv = rev, layer, gviews
+        self.rev_prefix, self.layer_prefix = rev_prefix, layer_prefix
+        self._saved = None
+
+    @staticmethod
+    def supports(rev, layer) -> bool:
+        if not isinstance(rev, nn.Linear) or rev.bias is None or float(getattr(layer, "dropout", 0.0)) > 0:
+            return False
+        n_out = layer.out_channels * layer.time_dim * layer.joints_dim
+        if rev.out_features != layer.in_channels * layer.time_dim * layer.joints_dim:
+            return False
+        return ops.rev_btlnk_ok(n_out, rev.in_features)
+
+    # ---- the K folded images as a differentiable function of the parameters and of G ------------------------------------------------
+    def _fold(self, G: Tensor, n_pos: float, update_running: bool):
+        rev, lay = self.rev, self.layer
+        Lz = rev.in_features
+        K = Lz + 1
+        Ci, Co, T, V = lay.in_channels, lay.out_channels, lay.time_dim, lay.joints_dim
+        TV = T * V
+        Hb = torch.cat([rev.weight.t(), rev.bias[None]], 0).view(K, Ci, T, V)
+        Y = torch.einsum('kctv,vtq->kcqv', Hb, lay.gcn.T)                 # stsgcn.py:154
+        Zb = torch.einsum('kctv,tvw->kctw', Y, lay.gcn.A)                 # stsgcn.py:155
+        last = torch.zeros(K, 1, 1, device=G.device, dtype=torch.float32)
+        last[K - 1] = 1.0                                                 # conv biases and BatchNorm shifts live on the constant image
+
+        def conv(w, b, X):
+            out = torch.matmul(w.view(Co, Ci), X.reshape(K, Ci, TV))
+            return out if b is None else out + last * b.view(1, Co, 1)
+
+        def fold(bn, X):
+            """-> (scale a [Co] fp32, shift [Co] fp32) of this BatchNorm on the rank-K tensor X, batch statistics from G (fp64)"""
+            Xd = X.double()
+            mean = torch.einsum('l,lc->c', G[:, K - 1], Xd.sum(-1)) / n_pos
+            e2 = (torch.einsum('lcp,mcp->clm', Xd, Xd) * G[None]).sum((1, 2)) / n_pos
+            var = (e2 - mean * mean).clamp_min(0.0)
+            if update_running and bn.running_mean is not None:
+                with torch.no_grad():                                      # nn.BatchNorm2d: momentum average, unbiased variance
+                    mom = ops.bn_momentum(bn)
+                    unb = n_pos / (n_pos - 1.0) if n_pos > 1 else 1.0
+                    bn.running_mean.mul_(1 - mom).add_(mom * mean.float())
+                    bn.running_var.mul_(1 - mom).add_(mom * (var * unb).float())
+                    bn.num_batches_tracked.add_(1)
+            a = bn.weight.double() / torch.sqrt(var + bn.eps)
+            return a.float(), (bn.bias.double() - a * mean).float()
+
+        tc, tb = lay.tcn[0], lay.tcn[1]
+        P = conv(tc.weight, tc.bias, Zb)
+        a_t, shift = fold(tb, P)
+        M = a_t.view(1, Co, 1) * P
+        if isinstance(lay.residual, nn.Identity):
+            M = M + Hb.reshape(K, Ci, TV)
+        else:
+            rc, rb = lay.residual[0], lay.residual[1]
+            Q = conv(rc.weight, rc.bias, Hb)
+            a_r, shift_r = fold(rb, Q)
+            M = M + a_r.view(1, Co, 1) * Q
+            shift = shift + shift_r
+        M = M + last * shift.view(1, Co, 1)
+        Mw = M[:K - 1].reshape(K - 1, Co * TV).t().contiguous()            # the streaming kernels' weight layout [features, Lz]
+        Mb = M[K - 1].reshape(-1).contiguous()
+        return Mw, Mb
+
+    def forward(self, z: Tensor) -> Tensor:
+        """z [B, Lz] (no autograd) -> U1 [B, C_out, T, V]: the first decoder layer's PRE-activation (apply its PReLU on load)"""
+        lay = self.layer
+        B, Lz = z.shape
+        zt = torch.cat([z, torch.ones(B, 1, device=z.device, dtype=z.dtype)], 1).double()
+        G = (zt.t() @ zt).requires_grad_(True)
+        with torch.enable_grad():
+            Mw, Mb = self._fold(G, float(B * lay.time_dim * lay.joints_dim), update_running=True)
+        Mwd, Mbd = Mw.detach(), Mb.detach()
+        U1 = ops.rev_btlnk_fwd(z, Mwd, Mbd)
+        self._saved = (z, zt, G, Mw, Mb, Mwd)
+        return U1.view(B, lay.out_channels, lay.time_dim, lay.joints_dim)
+
+    def _params(self):
+        lay, rp, lp = self.layer, self.rev_prefix, self.layer_prefix
+        named = [(rp + "weight", self.rev.weight), (rp + "bias", self.rev.bias), (lp + "gcn.A", lay.gcn.A), (lp + "gcn.T", lay.gcn.T),
+                 (lp + "tcn.0.weight", lay.tcn[0].weight), (lp + "tcn.1.weight", lay.tcn[1].weight), (lp + "tcn.1.bias", lay.tcn[1].bias)]
+        if not isinstance(lay.residual, nn.Identity):
+            named += [(lp + "residual.0.weight", lay.residual[0].weight), (lp + "residual.1.weight", lay.residual[1].weight),
+                      (lp + "residual.1.bias", lay.residual[1].bias)]
+        # (conv biases in front of a train-mode BatchNorm: gradient exactly 0, never written -- as everywhere on the flat path)
+        return named
+
+    def backward(self, dU1: Tensor, dz: Optional[Tensor] = None) -> Tensor:
+        """dU1: gradient w.r.t. U1 (the next layer's backward has already applied this layer's PReLU'); fills the flat gradient views
+        of rev_btlnk and of the layer, returns dz [B, Lz] (added to `dz` when one is given)."""
+        z, zt, G, Mw, Mb, Mwd = self._saved
+        self._saved = None
+        B = z.shape[0]
+        dMw, dMb = torch.empty_like(Mwd), torch.empty(Mwd.shape[0], device=z.device, dtype=torch.float32)
+        dz = ops.rev_btlnk_bwd(dU1.reshape(B, -1), z, Mwd, dMw, dMb, dz=dz)
+        named = self._params()
+        grads = torch.autograd.grad([Mw, Mb], [p for _, p in named] + [G], [dMw, dMb], allow_unused=True)
+        for (n, _), g in zip(named, grads[:-1]):
+            if g is None:
+                self.gv[n].zero_()
+            else:
+                self.gv[n].copy_(g.view_as(self.gv[n]))
+        dG = grads[-1]
+        if dG is not None:                                                 # the statistics' dependence on the latents: G = sum zt zt^T
+            dz.add_((zt @ (dG + dG.t()))[:, :z.shape[1]].float())
+        return dz

@@ -283,26 +283,28 @@ class _FlatStack:
     HIP path (stsgcn.wide_forward / wide_backward: explicit forward and backward, no autograd), gradients written to the flat
     buffer's views."""
 
-    def __init__(self, modules, fp: "FlatParams", prefix: str) -> None:
+    def __init__(self, modules, fp: "FlatParams", prefix: str, first: int = 0) -> None:
+        """modules: the layers first, first + 1, .. of the nn.Sequential whose parameters are named `{prefix}{index}.`"""
         self.segs = []                 # ('tile', [LayerTensors], [grad dicts]) | ('wide', module, names)
         i, n = 0, len(modules)
         while i < n:
             if modules[i].is_wide:
-                self.segs.append(('wide', modules[i], f"{prefix}{i}."))
+                self.segs.append(('wide', modules[i], f"{prefix}{first + i}."))
                 i += 1
             else:
                 j = i
                 while j < n and not modules[j].is_wide:
                     j += 1
                 self.segs.append(('tile', [layer_tensors(m) for m in modules[i:j]],
-                                  [_layer_grad_views(fp, f"{prefix}{k}.") for k in range(i, j)]))
+                                  [_layer_grad_views(fp, f"{prefix}{first + k}.") for k in range(i, j)]))
                 i = j
         self.fp = fp
-        self.last_slope_grad = fp.gviews[f"{prefix}{n - 1}.prelu.weight"] if self.segs[-1][0] == 'tile' else None
+        self.last_slope_grad = fp.gviews[f"{prefix}{first + n - 1}.prelu.weight"] if self.segs[-1][0] == 'tile' else None
 
-    def forward(self, x: Tensor, ws: engine.Workspace):
-        """x: raw (activated) input -> (h, slope, saved): apply PReLU(slope) to h for the stack's output (slope None: done)."""
-        h, slope, saved = x, None, []
+    def forward(self, x: Tensor, ws: engine.Workspace, in_slope: Optional[Tensor] = None):
+        """x: the stack's input, activated (in_slope None) or a pre-activation whose PReLU weight is `in_slope`
+        -> (h, slope, saved): apply PReLU(slope) to h for the stack's output (slope None: done)."""
+        h, slope, saved = x, in_slope, []
         for seg in self.segs:
             if seg[0] == 'tile':
                 u, ctx = engine.chain_forward(h, seg[1], True, ws, in_slope=slope, want_ctx=True)
@@ -321,17 +323,20 @@ class _FlatStack:
         """(ChainCtx, layers) of the last segment when it is a tile run (engine.btlnk_backward), else (None, None)"""
         return (saved[-1], self.segs[-1][1]) if self.segs[-1][0] == 'tile' else (None, None)
 
-    def backward(self, saved, d_last: Tensor, ws: engine.Workspace, need_dx: bool, top_stats=None) -> Optional[Tensor]:
+    def backward(self, saved, d_last: Tensor, ws: engine.Workspace, need_dx: bool, top_stats=None,
+                 in_slope_grad: Optional[Tensor] = None) -> Optional[Tensor]:
         """d_last: gradient w.r.t. the last segment's output (pre-activation U of a tile run -- the caller owns its slope
         gradient -- or the activated output of a wide layer); top_stats: the last tile run's top-layer batch reductions when
-        the producer of d_last formed them (engine.btlnk_backward)."""
+        the producer of d_last formed them (engine.btlnk_backward); in_slope_grad: where the gradient of forward's `in_slope`
+        goes (the returned gradient is then w.r.t. the PRE-activation input)."""
         d = d_last
         for k in range(len(self.segs) - 1, -1, -1):
             seg, sv = self.segs[k], saved[k]
             first = k == 0
             if seg[0] == 'tile':
                 d = engine.chain_backward(sv, seg[1], d, ws, seg[2], need_dx=need_dx or not first,
-                                          stats_in=top_stats if k == len(self.segs) - 1 else None)
+                                          stats_in=top_stats if k == len(self.segs) - 1 else None,
+                                          in_slope_grad=in_slope_grad if first else None)
             else:
                 from .models.graph_layers.stsgcn import wide_backward
                 wsaved, wmeta, pre_u, pre_slope = sv
@@ -349,8 +354,8 @@ class _FlatStack:
                 d = res[0] if want_x else None
                 if d is not None and pre_u is not None:
                     # the wide layer consumed PReLU(pre_u): back through it, into the producing tile run's last slope
-                    prev = self.segs[k - 1]
-                    d = ops.prelu_bwd(pre_u, d.contiguous(), pre_slope, prev[2][-1]["slope"])
+                    dslope = self.segs[k - 1][2][-1]["slope"] if k > 0 else in_slope_grad
+                    d = ops.prelu_bwd(pre_u, d.contiguous(), pre_slope, dslope)
         return d
 
 
@@ -391,7 +396,17 @@ class STSAETrainStep:
         self.use_graph = False
         self.ws = engine.Workspace()
         self.enc = _FlatStack(list(model.encoder.model), self.fp, "encoder.model.")
-        self.dec = _FlatStack(list(model.decoder.model), self.fp, "decoder.model.")
+        # the decoder's first layer sees a rank-(latent + 1) input (rev_btlnk of the latent): folded into one streaming pass where that
+        # layer would otherwise take the composed wide path (coskad_amd/lowrank.py)
+        from . import lowrank
+        dec_layers = list(model.decoder.model)
+        self.lowrank = None
+        if (len(dec_layers) > 1 and lowrank.LowRankFirstLayer.supports(model.rev_btlnk, dec_layers[0])
+                and (lowrank.MODE == 'always' or (lowrank.MODE == 'wide' and dec_layers[0].is_wide))):
+            self.lowrank = lowrank.LowRankFirstLayer(model.rev_btlnk, dec_layers[0], self.fp.gviews)
+            self.dec = _FlatStack(dec_layers[1:], self.fp, "decoder.model.", first=1)
+        else:
+            self.dec = _FlatStack(dec_layers, self.fp, "decoder.model.")
         self.center_acc = torch.zeros(ops.HEAD_SLOTS, device=dev, dtype=torch.float32)
         self.reg_scale = 0.5 / self.fp.n_reg_tensors
         self.reg_coef = self.alpha * 2.0 * self.reg_scale
@@ -490,20 +505,29 @@ class STSAETrainStep:
         out['z'] = z_dec
         # rev_btlnk (ae.py:223-227): H = z Wr^T + br on the strided MFMA GEMM, straight into the decoder's [B, hid, T, V] view
         Wr, br = m.rev_btlnk.weight, m.rev_btlnk.bias
-        H = ops.rev_btlnk_fwd(z_dec, Wr, br)
-        Ud, dslope_d, dec_saved = self.dec.forward(H.view(B, hid, T, V), self.ws)
+        if self.lowrank is not None:
+            l0 = m.decoder.model[0]
+            Ud, dslope_d, dec_saved = self.dec.forward(self.lowrank.forward(z_dec), self.ws, in_slope=l0.prelu.weight)
+        else:
+            H = ops.rev_btlnk_fwd(z_dec, Wr, br)
+            Ud, dslope_d, dec_saved = self.dec.forward(H.view(B, hid, T, V), self.ws)
         w_rec = self.lambda_ if self.mode == 'ae' else self.phi
         if dslope_d is None:
             raise NotImplementedError("STSAETrainStep: a decoder ending in a wide layer")
         loss_rec, dUd, _ = ops.rec_head(Ud, x, dslope_d, dslope=self.dec.last_slope_grad, upstream=w_rec)
         out['rec'] = loss_rec
         # ---- backward ----------------------------------------------------------------------------------------------------
-        dH = self.dec.backward(dec_saved, dUd, self.ws, need_dx=True).reshape(B, -1)
-        # rev_btlnk: dWr = dH^T z, dbr = sum dH, dz (+)= dH Wr: streaming kernels over dH (csrc/rev_btlnk.hip)
-        if self.mode == 'ae':
-            dHd = ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"], dz=dz)   # dz = d MSE(z, c) + dH Wr
+        if self.lowrank is not None:
+            dU1 = self.dec.backward(dec_saved, dUd, self.ws, need_dx=True, in_slope_grad=gv["decoder.model.0.prelu.weight"])
+            rev_bwd = lambda dz_: self.lowrank.backward(dU1, dz=dz_)
         else:
-            dz_dec = ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"])
+            dH = self.dec.backward(dec_saved, dUd, self.ws, need_dx=True).reshape(B, -1)
+            # rev_btlnk: dWr = dH^T z, dbr = sum dH, dz (+)= dH Wr: streaming kernels over dH (csrc/rev_btlnk.hip)
+            rev_bwd = lambda dz_: ops.rev_btlnk_bwd(dH, z_dec, Wr, gv["rev_btlnk.weight"], gv["rev_btlnk.bias"], dz=dz_)
+        if self.mode == 'ae':
+            dHd = rev_bwd(dz)                                                     # dz = d MSE(z, c) + dH Wr
+        else:
+            dz_dec = rev_bwd(None)
             L = m.latent_dim
             if graph[0] == 'ps':
                 _, Hd, H2, Wc, ps_saved, mlp_saved = graph

@@ -232,3 +232,39 @@ def test_power_spherical_head_kernels_vs_torch_autograd(L):
     ok = np.isfinite(ref).all(axis=1)                     # (mu = e1 exactly: torch's own gradient is 0 / 0 there)
     assert ok.sum() >= B - 2
     np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-3, atol=2e-6 + 2e-4 * np.abs(ref[ok]).max())
+
+
+@pytest.mark.parametrize("name", ["stsae_small.npz", "stsae_v25.npz"])
+def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name, monkeypatch):
+    """coskad_amd/lowrank.py (rev_btlnk + the decoder's first layer as ONE streaming pass over a rank-(latent + 1) input) against
+    the layer-by-layer flat step on the same model: loss, latents, every gradient, the running statistics -- at 17 joints (where
+    the layer would run on the tile kernels) and at 25 (where it would take the composed wide path; the mode the flat step picks
+    by itself there: the reference-gradient test above runs through it)."""
+    from coskad_amd import lowrank
+    from coskad_amd.models.sts.ae import STSAE
+    from coskad_amd.trainer import STSAETrainStep
+    g = golden(name)
+    res = {}
+    for mode in ("never", "always"):
+        monkeypatch.setattr(lowrank, "MODE", mode)
+        m, st = _build(g, STSAE)
+        m.load_state_dict(st, strict=True)
+        m.c.copy_(torch.from_numpy(g["c"]))
+        m.cuda().train()
+        eng = STSAETrainStep(m, mode='ae', lr=0.0, alpha=0.0, lambda_=0.7)
+        assert (eng.lowrank is not None) == (mode == "always")
+        out = eng.step(torch.from_numpy(g["x"]).cuda())
+        torch.cuda.synchronize()
+        res[mode] = (float(out['rec']), float(out['head']), {n: v.cpu().numpy().copy() for n, v in eng.fp.gviews.items()},
+                     {k: v.cpu().numpy().copy() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+    monkeypatch.setattr(lowrank, "MODE", "wide")
+    m, st = _build(g, STSAE)
+    assert (STSAETrainStep(m.cuda().train(), mode='ae').lowrank is not None) == (name == "stsae_v25.npz")
+    a, b = res["never"], res["always"]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-5)
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-5)
+    gmax = max(np.abs(v).max() for v in a[2].values())
+    for n, ref in a[2].items():
+        np.testing.assert_allclose(b[2][n], ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max() + 2e-5 * gmax, err_msg=n)
+    for k, ref in a[3].items():
+        np.testing.assert_allclose(b[3][k], ref, rtol=1e-4, atol=1e-6, err_msg=k)
