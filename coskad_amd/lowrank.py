@@ -105,8 +105,10 @@ class LowRankFirstLayer:
         """z [B, Lz] (no autograd) -> U1 [B, C_out, T, V]: the first decoder layer's PRE-activation (apply its PReLU on load)"""
         lay = self.layer
         B, Lz = z.shape
-        zt = torch.cat([z, torch.ones(B, 1, device=z.device, dtype=z.dtype)], 1).double()
-        G = (zt.t() @ zt).requires_grad_(True)
+        zt = torch.cat([z, torch.ones(B, 1, device=z.device, dtype=z.dtype)], 1)
+        # G = sum_n zt zt^T: 256-row pieces on the fp32 MFMA GEMM, pieces summed in fp64 in a fixed order (ONE [K, B] x [B, K] fp64
+        # library product is a single-workgroup kernel: 224 us at B = 4096)
+        G = ops.gemm_rows_outer(zt, zt, torch.empty(Lz + 1, Lz + 1, device=z.device, dtype=torch.float32)).double().requires_grad_(True)
         with torch.enable_grad():
             Mw, Mb = self._fold(G, float(B * lay.time_dim * lay.joints_dim), update_running=True)
         Mwd, Mbd = Mw.detach(), Mb.detach()
@@ -141,5 +143,5 @@ class LowRankFirstLayer:
                 self.gv[n].copy_(g.view_as(self.gv[n]))
         dG = grads[-1]
         if dG is not None:                                                 # the statistics' dependence on the latents: G = sum zt zt^T
-            dz.add_((zt @ (dG + dG.t()))[:, :z.shape[1]].float())
+            dz.add_((zt @ (dG + dG.t()).float())[:, :z.shape[1]])
         return dz
