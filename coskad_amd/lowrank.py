@@ -34,6 +34,12 @@ Tensor = torch.Tensor
 # which decoders take the folded first layer: 'wide' = only where the layer would run the composed wide path (64 input channels on
 # the 25-joint layout), 'always', 'never' (tests flip it)
 MODE = 'wide'
+# True: the fold's ~60 small torch launches and the ~170 of its autograd backward are replayed as two hipGraphs per position count
+# (their shapes do not depend on the batch).  Measured on the V = 25 VAE step (B = 4096): host enqueue time 4.4 -> 2.0 ms per step, but
+# the step itself 5.53 -> 6.0 ms -- a graph node costs more device time than an eager back-to-back launch on this stack -- so the
+# default is eager; a host that cannot keep 4.4 ms of launches ahead of 5.5 ms of kernels would flip it.  (A BatchNorm with
+# momentum=None -- its averaging factor changes per step -- and a failed capture are always eager.)
+GRAPH_FOLD = False
 
 
 class LowRankFirstLayer:
@@ -101,6 +107,29 @@ class LowRankFirstLayer:
         Mb = M[K - 1].reshape(-1).contiguous()
         return Mw, Mb
 
+    def _bns(self):
+        lay = self.layer
+        return [lay.tcn[1]] + ([] if isinstance(lay.residual, nn.Identity) else [lay.residual[1]])
+
+    def _graph(self, n_pos: float, device):
+        """the fold's forward / backward captured for this position count, or None (eager)"""
+        if not GRAPH_FOLD or any(bn.momentum is None for bn in self._bns()):
+            return None
+        graphs = self.__dict__.setdefault("_graphs", {})
+        if n_pos in graphs:
+            return graphs[n_pos]
+        bufs = [b for bn in self._bns() for b in (bn.running_mean, bn.running_var, bn.num_batches_tracked) if b is not None]
+        keep = [b.clone() for b in bufs]                    # warm-up really runs the running-statistics update
+        fg = None
+        try:
+            fg = _FoldGraph(self, n_pos, device)
+        except Exception:                                   # capture not possible on this stack: eager from now on
+            fg = None
+        for b, k in zip(bufs, keep):
+            b.copy_(k)
+        graphs[n_pos] = fg
+        return fg
+
     def forward(self, z: Tensor) -> Tensor:
         """z [B, Lz] (no autograd) -> U1 [B, C_out, T, V]: the first decoder layer's PRE-activation (apply its PReLU on load)"""
         lay = self.layer
@@ -108,12 +137,21 @@ class LowRankFirstLayer:
         zt = torch.cat([z, torch.ones(B, 1, device=z.device, dtype=z.dtype)], 1)
         # G = sum_n zt zt^T: 256-row pieces on the fp32 MFMA GEMM, pieces summed in fp64 in a fixed order (ONE [K, B] x [B, K] fp64
         # library product is a single-workgroup kernel: 224 us at B = 4096)
-        G = ops.gemm_rows_outer(zt, zt, torch.empty(Lz + 1, Lz + 1, device=z.device, dtype=torch.float32)).double().requires_grad_(True)
-        with torch.enable_grad():
-            Mw, Mb = self._fold(G, float(B * lay.time_dim * lay.joints_dim), update_running=True)
+        G32 = ops.gemm_rows_outer(zt, zt, torch.empty(Lz + 1, Lz + 1, device=z.device, dtype=torch.float32))
+        n_pos = float(B * lay.time_dim * lay.joints_dim)
+        fg = self._graph(n_pos, z.device)
+        if fg is not None:
+            with torch.no_grad():
+                fg.G.copy_(G32)
+            fg.fwd.replay()
+            G, Mw, Mb = fg.G, fg.Mw, fg.Mb
+        else:
+            G = G32.double().requires_grad_(True)
+            with torch.enable_grad():
+                Mw, Mb = self._fold(G, n_pos, update_running=True)
         Mwd, Mbd = Mw.detach(), Mb.detach()
         U1 = ops.rev_btlnk_fwd(z, Mwd, Mbd)
-        self._saved = (z, zt, G, Mw, Mb, Mwd)
+        self._saved = (z, zt, G, Mw, Mb, Mwd, fg)
         return U1.view(B, lay.out_channels, lay.time_dim, lay.joints_dim)
 
     def _params(self):
@@ -129,13 +167,20 @@ class LowRankFirstLayer:
     def backward(self, dU1: Tensor, dz: Optional[Tensor] = None) -> Tensor:
         """dU1: gradient w.r.t. U1 (the next layer's backward has already applied this layer's PReLU'); fills the flat gradient views
         of rev_btlnk and of the layer, returns dz [B, Lz] (added to `dz` when one is given)."""
-        z, zt, G, Mw, Mb, Mwd = self._saved
+        z, zt, G, Mw, Mb, Mwd, fg = self._saved
         self._saved = None
         B = z.shape[0]
-        dMw, dMb = torch.empty_like(Mwd), torch.empty(Mwd.shape[0], device=z.device, dtype=torch.float32)
-        dz = ops.rev_btlnk_bwd(dU1.reshape(B, -1), z, Mwd, dMw, dMb, dz=dz)
         named = self._params()
-        grads = torch.autograd.grad([Mw, Mb], [p for _, p in named] + [G], [dMw, dMb], allow_unused=True)
+        if fg is not None:
+            dMw, dMb = fg.dMw, fg.dMb
+        else:
+            dMw, dMb = torch.empty_like(Mwd), torch.empty(Mwd.shape[0], device=z.device, dtype=torch.float32)
+        dz = ops.rev_btlnk_bwd(dU1.reshape(B, -1), z, Mwd, dMw, dMb, dz=dz)
+        if fg is not None:
+            fg.bwd.replay()
+            grads = fg.grads
+        else:
+            grads = torch.autograd.grad([Mw, Mb], [p for _, p in named] + [G], [dMw, dMb], allow_unused=True)
         for (n, _), g in zip(named, grads[:-1]):
             if g is None:
                 self.gv[n].zero_()
@@ -145,3 +190,29 @@ class LowRankFirstLayer:
         if dG is not None:                                                 # the statistics' dependence on the latents: G = sum zt zt^T
             dz.add_((zt @ (dG + dG.t()).float())[:, :z.shape[1]])
         return dz
+
+
+class _FoldGraph:
+    """LowRankFirstLayer._fold and its autograd backward for ONE position count as two hipGraphs over static buffers: G in, the
+    folded images out; their gradients in, the parameters' and G's gradients out."""
+
+    def __init__(self, owner: LowRankFirstLayer, n_pos: float, device) -> None:
+        K = owner.rev.in_features + 1
+        params = [p for _, p in owner._params()]
+        self.G = torch.eye(K, device=device, dtype=torch.float64).mul_(n_pos).requires_grad_(True)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up outside capture: allocator, library GEMM handles
+            for _ in range(2):
+                with torch.enable_grad():
+                    Mw, Mb = owner._fold(self.G, n_pos, True)
+                torch.autograd.grad([Mw, Mb], params + [self.G], [torch.zeros_like(Mw), torch.zeros_like(Mb)], allow_unused=True)
+        torch.cuda.current_stream().wait_stream(side)
+        self.fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd):
+            with torch.enable_grad():
+                self.Mw, self.Mb = owner._fold(self.G, n_pos, True)
+        self.dMw, self.dMb = torch.zeros_like(self.Mw), torch.zeros_like(self.Mb)
+        self.bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd, pool=self.fwd.pool()):
+            self.grads = torch.autograd.grad([self.Mw, self.Mb], params + [self.G], [self.dMw, self.dMb], allow_unused=True)

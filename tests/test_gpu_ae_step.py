@@ -234,8 +234,9 @@ def test_power_spherical_head_kernels_vs_torch_autograd(L):
     np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-3, atol=2e-6 + 2e-4 * np.abs(ref[ok]).max())
 
 
+@pytest.mark.parametrize("graph", [True, False])
 @pytest.mark.parametrize("name", ["stsae_small.npz", "stsae_v25.npz"])
-def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name, monkeypatch):
+def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name, graph, monkeypatch):
     """coskad_amd/lowrank.py (rev_btlnk + the decoder's first layer as ONE streaming pass over a rank-(latent + 1) input) against
     the layer-by-layer flat step on the same model: loss, latents, every gradient, the running statistics -- at 17 joints (where
     the layer would run on the tile kernels) and at 25 (where it would take the composed wide path; the mode the flat step picks
@@ -245,6 +246,7 @@ def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name,
     from coskad_amd.trainer import STSAETrainStep
     g = golden(name)
     res = {}
+    monkeypatch.setattr(lowrank, "GRAPH_FOLD", graph)      # the fold replayed as two hipGraphs / launched eagerly
     for mode in ("never", "always"):
         monkeypatch.setattr(lowrank, "MODE", mode)
         m, st = _build(g, STSAE)
@@ -254,6 +256,9 @@ def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name,
         eng = STSAETrainStep(m, mode='ae', lr=0.0, alpha=0.0, lambda_=0.7)
         assert (eng.lowrank is not None) == (mode == "always")
         out = eng.step(torch.from_numpy(g["x"]).cuda())
+        if mode == "always":
+            assert (getattr(eng.lowrank, "_graphs", {}).get(float(g["x"].shape[0] * 12 * m.n_joints)) is not None) == graph
+        out = eng.step(torch.from_numpy(g["x"]).cuda())       # lr = 0: the second step (a graph REPLAY) repeats the first
         torch.cuda.synchronize()
         res[mode] = (float(out['rec']), float(out['head']), {n: v.cpu().numpy().copy() for n, v in eng.fp.gviews.items()},
                      {k: v.cpu().numpy().copy() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
