@@ -74,34 +74,48 @@ class LowRankFirstLayer:
             out = torch.matmul(w.view(Co, Ci), X.reshape(K, Ci, TV))
             return out if b is None else out + last * b.view(1, Co, 1)
 
-        def fold(bn, X):
-            """-> (scale a [Co] fp32, shift [Co] fp32) of this BatchNorm on the rank-K tensor X, batch statistics from G (fp64)"""
+        def fold(bns, X):
+            """X [R, K, Co, TV]: the rank-K tensors of R BatchNorm branches -> (scale a [R, Co] fp32, shift [R, Co] fp32), batch
+            statistics from G in fp64 (both branches in one set of launches)"""
             Xd = X.double()
-            mean = torch.einsum('l,lc->c', G[:, K - 1], Xd.sum(-1)) / n_pos
-            e2 = (torch.einsum('lcp,mcp->clm', Xd, Xd) * G[None]).sum((1, 2)) / n_pos
+            mean = torch.einsum('l,rlc->rc', G[:, K - 1], Xd.sum(-1)) / n_pos
+            e2 = (torch.matmul(Xd.permute(0, 2, 1, 3), Xd.permute(0, 2, 3, 1)) * G).sum((2, 3)) / n_pos       # [R, Co, K, K] . G
             var = (e2 - mean * mean).clamp_min(0.0)
-            if update_running and bn.running_mean is not None:
+            if update_running:
                 with torch.no_grad():                                      # nn.BatchNorm2d: momentum average, unbiased variance
-                    mom = ops.bn_momentum(bn)
                     unb = n_pos / (n_pos - 1.0) if n_pos > 1 else 1.0
-                    bn.running_mean.mul_(1 - mom).add_(mom * mean.float())
-                    bn.running_var.mul_(1 - mom).add_(mom * (var * unb).float())
-                    bn.num_batches_tracked.add_(1)
-            a = bn.weight.double() / torch.sqrt(var + bn.eps)
-            return a.float(), (bn.bias.double() - a * mean).float()
+                    mf, vf = mean.float(), (var * unb).float()
+                    for r, bn in enumerate(bns):
+                        if bn.running_mean is not None:
+                            mom = ops.bn_momentum(bn)
+                            bn.running_mean.mul_(1 - mom).add_(mf[r], alpha=mom)
+                            bn.running_var.mul_(1 - mom).add_(vf[r], alpha=mom)
+                            bn.num_batches_tracked.add_(1)
+            gamma = torch.stack([bn.weight for bn in bns]).double()
+            beta = torch.stack([bn.bias for bn in bns]).double()
+            if all(bn.eps == bns[0].eps for bn in bns):
+                eps = bns[0].eps
+            else:                                                          # (built once: no host-to-device copy per step / under capture)
+                key = tuple(bn.eps for bn in bns)
+                cache = self.__dict__.setdefault("_eps", {})
+                if key not in cache:
+                    cache[key] = torch.tensor(key, device=G.device, dtype=torch.float64).view(-1, 1)
+                eps = cache[key]
+            a = gamma / torch.sqrt(var + eps)
+            return a.float(), (beta - a * mean).float()
 
         tc, tb = lay.tcn[0], lay.tcn[1]
         P = conv(tc.weight, tc.bias, Zb)
-        a_t, shift = fold(tb, P)
-        M = a_t.view(1, Co, 1) * P
         if isinstance(lay.residual, nn.Identity):
-            M = M + Hb.reshape(K, Ci, TV)
+            a, shift = fold([tb], P[None])
+            M = a[0].view(1, Co, 1) * P + Hb.reshape(K, Ci, TV)
+            shift = shift[0]
         else:
             rc, rb = lay.residual[0], lay.residual[1]
-            Q = conv(rc.weight, rc.bias, Hb)
-            a_r, shift_r = fold(rb, Q)
-            M = M + a_r.view(1, Co, 1) * Q
-            shift = shift + shift_r
+            X = torch.stack([P, conv(rc.weight, rc.bias, Hb)])
+            a, shift = fold([tb, rb], X)
+            M = (a.view(2, 1, Co, 1) * X).sum(0)
+            shift = shift.sum(0)
         M = M + last * shift.view(1, Co, 1)
         Mw = M[:K - 1].reshape(K - 1, Co * TV).t().contiguous()            # the streaming kernels' weight layout [features, Lz]
         Mb = M[K - 1].reshape(-1).contiguous()
