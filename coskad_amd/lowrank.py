@@ -206,6 +206,41 @@ class LowRankFirstLayer:
         return dz
 
 
+def fold_eval(rev: nn.Linear, layer):
+    """Eval mode (BatchNorm from the running statistics): the K folded images of rev_btlnk + `layer` as the rev_btlnk kernel's
+    (weight [C_out T V, Lz], bias [C_out T V]) -- no statistics, no autograd; ~30 small launches on [K, C, T V] tensors."""
+    with torch.no_grad():
+        Lz = rev.in_features
+        K = Lz + 1
+        Ci, Co, T, V = layer.in_channels, layer.out_channels, layer.time_dim, layer.joints_dim
+        TV = T * V
+        Hb = torch.cat([rev.weight.t(), rev.bias[None]], 0).view(K, Ci, T, V)
+        Zb = torch.einsum('kctv,tvw->kctw', torch.einsum('kctv,vtq->kcqv', Hb, layer.gcn.T), layer.gcn.A)
+
+        def branch(conv, bn, X):
+            a = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            out = a.view(1, Co, 1) * torch.matmul(conv.weight.view(Co, Ci), X.reshape(K, Ci, TV))
+            shift = bn.bias - a * bn.running_mean + (a * conv.bias if conv.bias is not None else 0.0)
+            return out, shift
+
+        M, shift = branch(layer.tcn[0], layer.tcn[1], Zb)
+        if isinstance(layer.residual, nn.Identity):
+            M = M + Hb.reshape(K, Ci, TV)
+        else:
+            Mr, shift_r = branch(layer.residual[0], layer.residual[1], Hb)
+            M, shift = M + Mr, shift + shift_r
+        Mb = (M[K - 1] + shift.view(Co, 1)).reshape(-1).contiguous()
+        Mw = M[:K - 1].reshape(K - 1, Co * TV).t().contiguous()
+    return Mw, Mb
+
+
+def eval_supported(rev, layer) -> bool:
+    if MODE == 'never' or not LowRankFirstLayer.supports(rev, layer) or not (MODE == 'always' or layer.is_wide):
+        return False
+    bns = [layer.tcn[1]] + ([] if isinstance(layer.residual, nn.Identity) else [layer.residual[1]])
+    return all(bn.running_mean is not None and bn.running_var is not None for bn in bns)
+
+
 class _FoldGraph:
     """LowRankFirstLayer._fold and its autograd backward for ONE position count as two hipGraphs over static buffers: G in, the
     folded images out; their gradients in, the parameters' and G's gradients out."""

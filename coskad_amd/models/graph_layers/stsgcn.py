@@ -351,10 +351,12 @@ class ST_GCNN_layer(nn.Module):
         return _PReLUFn.apply(u, slope)
 
 
-def run_stack(x: Tensor, layer_modules: List["ST_GCNN_layer"], ws: engine.Workspace) -> Tuple[Tensor, Optional[Tensor]]:
-    """A stack that may mix fused (<= 64 channels) and wide layers.  -> (h, slope): apply PReLU(slope) to h to get the
-    stack's output (slope None: h is already activated)."""
-    h, slope = x, None
+def run_stack(x: Tensor, layer_modules: List["ST_GCNN_layer"], ws: engine.Workspace,
+              in_slope: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """A stack that may mix fused (<= 64 channels) and wide layers.  x: activated input, or (in_slope given) a pre-activation
+    whose PReLU weight is in_slope (no gradient flows to it: eval-mode hand-over of coskad_amd/lowrank.py).  -> (h, slope): apply
+    PReLU(slope) to h to get the stack's output (slope None: h is already activated)."""
+    h, slope = x, in_slope
     i, n = 0, len(layer_modules)
     while i < n:
         if layer_modules[i].is_wide:

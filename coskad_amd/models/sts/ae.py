@@ -208,12 +208,30 @@ class STSAE(STSE):
 
     def decode(self, Z: Tensor, input_shape: Tuple[int]) -> Tensor:
         B, C, T, V, M = input_shape
+        folded = self._decode_folded(Z, B * M, T, V)
+        if folded is not None:
+            return folded
         if Z.is_cuda and Z.dtype == torch.float32 and ops.rev_btlnk_ok(self.rev_btlnk.out_features, self.latent_dim):
             H = _RevBtlnkFn.apply(Z, self.rev_btlnk.weight, self.rev_btlnk.bias)   # streaming kernels of csrc/rev_btlnk.hip
         else:
             H = self.rev_btlnk(Z)        # other latent sizes: torch
         H = H.view(B * M, C, T, V)
         return self.decoder(H)
+
+    def _decode_folded(self, Z: Tensor, N: int, T: int, V: int) -> Optional[Tensor]:
+        """Eval-mode fast path (no gradient): rev_btlnk + the decoder's first layer as ONE streaming pass where that layer would
+        take the composed wide path (coskad_amd/lowrank.py: the latent makes its input rank latent + 1), the remaining layers
+        as usual.  None: not applicable."""
+        from ... import lowrank
+        from ..graph_layers.stsgcn import run_stack
+        mods = list(self.decoder.model) if isinstance(self.decoder, Decoder) else []
+        if (self.training or torch.is_grad_enabled() or not Z.is_cuda or Z.dtype != torch.float32 or len(mods) < 2
+                or not lowrank.eval_supported(self.rev_btlnk, mods[0])):
+            return None
+        Mw, Mb = lowrank.fold_eval(self.rev_btlnk, mods[0])
+        U1 = ops.rev_btlnk_fwd(Z.contiguous(), Mw, Mb).view(N, mods[0].out_channels, T, V)
+        u, slope = run_stack(U1, mods[1:], self.decoder._ws, in_slope=mods[0].prelu.weight)
+        return u if slope is None else _PReLUFn.apply(u, slope)
 
     def forward(self, X: Tensor) -> Tuple[Tensor]:
         Z, X_shape = self.encode(X, return_shape=True)

@@ -273,3 +273,35 @@ def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name,
         np.testing.assert_allclose(b[2][n], ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max() + 2e-5 * gmax, err_msg=n)
     for k, ref in a[3].items():
         np.testing.assert_allclose(b[3][k], ref, rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("name,mode", [("stsae_v25.npz", "wide"), ("stsae_small.npz", "always")])
+def test_eval_decode_through_the_folded_first_layer(golden, name, mode, monkeypatch):
+    """Eval mode: STSAE.decode with rev_btlnk + the first decoder layer as one streaming pass (lowrank.fold_eval, BatchNorm from the
+    running statistics) reconstructs what the layer-by-layer decode does -- and what the reference does (golden eval outputs)."""
+    from coskad_amd import lowrank
+    from coskad_amd.models.sts.ae import STSAE
+    g = golden(name)
+    m, st = _build(g, STSAE)
+    m.load_state_dict(st, strict=True)
+    m.cuda().eval()
+    for bn in [b for b in m.decoder.modules() if isinstance(b, torch.nn.BatchNorm2d)]:     # non-trivial running statistics
+        bn.running_mean.uniform_(-0.3, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    x = torch.from_numpy(g["x"]).cuda()
+    with torch.no_grad():
+        monkeypatch.setattr(lowrank, "MODE", "never")
+        z0, r0 = m(x)
+        monkeypatch.setattr(lowrank, "MODE", mode)
+        assert lowrank.eval_supported(m.rev_btlnk, m.decoder.model[0])
+        z1, r1 = m(x)
+    assert torch.equal(z0, z1)
+    scale = float(r0.abs().max())
+    np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    # and with the reference's own weights and statistics: its eval-mode reconstruction
+    m.load_state_dict(st, strict=True)
+    with torch.no_grad():
+        _, r2 = m(x)
+    key = "eval.xrec" if "eval.xrec" in g else None
+    if key:
+        np.testing.assert_allclose(r2.cpu().numpy(), g[key], rtol=1e-4, atol=1e-4)
