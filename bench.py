@@ -203,7 +203,13 @@ def run_legs(B, rank, world, sync, steps, warmup, only=None):
         fd = sum(4 * T * 25 * (ci + co) for ci, co in zip(dchans[:-1], dchans[1:]))
         bd = sum(4 * T * 25 * (co + 2 * ci) for ci, co in zip(dchans[:-1], dchans[1:]))
         total = fb + bb + fd + bd
-        return {"workload": f"spherical_vae train step (BASELINE config 4's model: STSVAE, projector 'mlp', PowerSpherical latent 8, decoder; phi MSE + "
+        m.eval()
+        with torch.no_grad():                                  # scoring forward: encoder, heads, sample, decoder (spherical_vae.py:76-78)
+            dtf = timed(lambda: m(x), k=max(5, steps), w=3)
+        m.train()
+        fwd_only = {"ms": round(dtf * 1e3, 4), "clips_per_s": round(B / dtf, 1), "layerwise_equiv_hbm_frac": hbm(B / dtf, fb + fd),
+                    "what": "eval-mode forward of the whole VAE (latent sampled as in the reference's scoring)"}
+        return {"forward_only": fwd_only, "workload": f"spherical_vae train step (BASELINE config 4's model: STSVAE, projector 'mlp', PowerSpherical latent 8, decoder; phi MSE + "
                             f"beta KL + gamma mean(1/kappa) + alpha reg), B={B}/GPU T={T} V=25, default widths", "engine": "STSAETrainStep",
                 "ms_per_step": round(dt * 1e3, 4), "clips_per_s": round(world * B / dt, 1),
                 "roofline": {"bound": "hbm", "frac": hbm(B / dt, total), "algorithmic_bytes_per_clip": total, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}

@@ -302,6 +302,11 @@ class ST_GCNN_layer(nn.Module):
             self.residual = nn.Identity()
         self.prelu = nn.PReLU()
 
+    def train(self, mode: bool = True):
+        if mode:
+            self.__dict__.pop("_lowrank_eval", None)     # eval-mode folded images (models/sts/ae.py): training is about to change what they fold
+        return super().train(mode)
+
     @property
     def is_wide(self) -> bool:
         """Beyond the LDS-resident tile kernels: more than 64 channels on either side, or a clip whose images do not fit

@@ -228,7 +228,19 @@ class STSAE(STSE):
         if (self.training or torch.is_grad_enabled() or not Z.is_cuda or Z.dtype != torch.float32 or len(mods) < 2
                 or not lowrank.eval_supported(self.rev_btlnk, mods[0])):
             return None
-        Mw, Mb = lowrank.fold_eval(self.rev_btlnk, mods[0])
+        # the folded images depend on parameters and running statistics only: kept until one of them changes (torch-side writes
+        # move the version counters; this library's training kernels write through raw pointers, but training needs .train() first,
+        # which drops the cache: ST_GCNN_layer.train)
+        l0, rev = mods[0], self.rev_btlnk
+        ts = [rev.weight, rev.bias, l0.gcn.A, l0.gcn.T] + [t for seq in (l0.tcn, l0.residual) if not isinstance(seq, nn.Identity)
+                                                          for t in (seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias,
+                                                                    seq[1].running_mean, seq[1].running_var) if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        cached = l0.__dict__.get("_lowrank_eval")
+        if cached is None or cached[0] != key:
+            cached = (key, lowrank.fold_eval(rev, l0))
+            l0.__dict__["_lowrank_eval"] = cached
+        Mw, Mb = cached[1]
         U1 = ops.rev_btlnk_fwd(Z.contiguous(), Mw, Mb).view(N, mods[0].out_channels, T, V)
         u, slope = run_stack(U1, mods[1:], self.decoder._ws, in_slope=mods[0].prelu.weight)
         return u if slope is None else _PReLUFn.apply(u, slope)

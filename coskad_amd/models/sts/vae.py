@@ -101,13 +101,17 @@ class STSVAE(STSAE):
 
     def encode(self, X: Tensor, return_shape: bool = False):
         assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
+        X_shape = (X.shape[0], self.hidden_dimension, self.n_frames, self.n_joints, 1)
+        Z_mean, var_raw = self._raw_heads(X)
+        return self._finish_heads(Z_mean, var_raw, X_shape, return_shape)
+
+    def _raw_heads(self, X: Tensor):
+        """-> (fc_mean's output before the normalisation, fc_var's output before softplus + 1)  (vae.py:79-85)"""
         B = X.shape[0]
-        X_shape = (B, self.hidden_dimension, self.n_frames, self.n_joints, 1)
         n_var = self.fc_var.out_features
         heads = self._heads_fused(X)
         if heads is not None:
-            Z_mean, var_raw = heads
-            return self._finish_heads(Z_mean, var_raw, X_shape, return_shape)
+            return heads
         U, slope = self.encoder.forward_preact(X)
         if isinstance(self.btlnk, nn.Identity) and self.latent_dim + n_var <= 16:
             # `linear` projector (vae.py:147-150): both heads read the flattened encoder output -- ONE pass of the
@@ -124,7 +128,7 @@ class STSVAE(STSAE):
             else:
                 Z = self.btlnk((U if slope is None else _PReLUFn.apply(U, slope)).reshape(B, -1))
             Z_mean, var_raw = self.fc_mean(Z), self.fc_var(Z)
-        return self._finish_heads(Z_mean, var_raw, X_shape, return_shape)
+        return Z_mean, var_raw
 
     def _finish_heads(self, Z_mean: Tensor, var_raw: Tensor, X_shape, return_shape: bool):
         if self.distribution == 'ps':
@@ -164,6 +168,17 @@ class STSVAE(STSAE):
         return q_Z, p_Z
 
     def forward(self, X: Tensor):
+        if (not self.training and not torch.is_grad_enabled() and X.is_cuda and self.distribution == 'ps' and 2 <= self.latent_dim <= 16):
+            # scoring forward (spherical_vae.py:76-78): normalise, softplus + 1 and the PowerSpherical sample on csrc/vae_head.hip
+            # (two launches around torch's Beta draw and Gaussian direction: the module path's noise streams) instead of ~40
+            # element-wise launches
+            assert len(X.shape) == 4, f'Input tensor must have shape [batch_size, input_dim, n_frames, n_joints]. Got {X.shape}'
+            input_shape = (X.shape[0], self.hidden_dimension, self.n_frames, self.n_joints, 1)
+            m_raw, v_raw = self._raw_heads(X)
+            Z, _, _, saved = ops.ps_head_forward(m_raw, v_raw)
+            Z_var = saved[3].unsqueeze(-1)
+            q_Z, p_Z = self.reparameterize(saved[2], Z_var)
+            return Z, self.decode(Z, input_shape=input_shape), (q_Z, p_Z, Z_var)
         Z_mean, Z_var, input_shape = self.encode(X, return_shape=True)
         q_Z, p_Z = self.reparameterize(Z_mean, Z_var)
         Z = q_Z.rsample()

@@ -305,3 +305,59 @@ def test_eval_decode_through_the_folded_first_layer(golden, name, mode, monkeypa
     key = "eval.xrec" if "eval.xrec" in g else None
     if key:
         np.testing.assert_allclose(r2.cpu().numpy(), g[key], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("V,projector", [(17, 'linear'), (25, 'mlp')])
+def test_vae_eval_forward_head_on_hip_equals_the_torch_head(V, projector):
+    """STSVAE.forward in eval mode without autograd (the scoring forward, spherical_vae.py:76-78) takes csrc/vae_head.hip for the
+    normalisation, softplus + 1 and the PowerSpherical sample; with autograd enabled the same call runs the torch restatement: same
+    seed -> same sample, reconstruction and concentration."""
+    from coskad_amd.models.sts.vae import STSVAE
+    from oracle import ref_cpu as R
+    torch.manual_seed(7)
+    m = STSVAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', projector, 'euclidean', 0.0, distribution='ps').cuda().eval()
+    x = R.synthetic_clips(40, 2, 12, V, seed=9).cuda()
+    torch.manual_seed(21)
+    with torch.no_grad():
+        z1, r1, (q1, _, k1) = m(x)
+    torch.manual_seed(21)
+    z2, r2, (q2, _, k2) = m(x)
+    np.testing.assert_allclose(k1.cpu().numpy(), k2.detach().cpu().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(q1.loc.cpu().numpy(), q2.loc.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(z1.cpu().numpy(), z2.detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(r1.cpu().numpy(), r2.detach().cpu().numpy(), rtol=2e-4, atol=2e-5 * float(r2.abs().max()) + 1e-5)
+
+
+def test_eval_decode_cache_follows_training(golden):
+    """the cached folded images of the eval decode are rebuilt after a flat training step (whose kernels write parameters and
+    running statistics through raw pointers: no torch version counter moves) and after a torch-side parameter write"""
+    from coskad_amd.models.sts.ae import STSAE
+    from coskad_amd.trainer import STSAETrainStep
+    g = golden("stsae_v25.npz")
+    m, st = _build(g, STSAE)
+    m.load_state_dict(st, strict=True)
+    m.cuda()
+    x = torch.from_numpy(g["x"]).cuda()
+    eng = STSAETrainStep(m.train(), mode='ae', lr=1e-2, alpha=0.0, lambda_=1.0)
+
+    def recon():
+        m.eval()
+        with torch.no_grad():
+            return m(x)[1].clone()
+    r0 = recon()
+    assert torch.equal(recon(), r0) and "_lowrank_eval" in m.decoder.model[0].__dict__
+    m.train()
+    eng.step(x)
+    r1 = recon()
+    assert float((r1 - r0).abs().max()) > 1e-4                # the step moved the decoder
+    from coskad_amd import lowrank
+    keep = lowrank.MODE
+    try:
+        lowrank.MODE = "never"
+        ref = recon()
+    finally:
+        lowrank.MODE = keep
+    np.testing.assert_allclose(r1.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+    with torch.no_grad():
+        m.rev_btlnk.bias.add_(0.05)                           # torch-side write: the version counter moves
+    assert float((recon() - r1).abs().max()) > 1e-5
