@@ -901,6 +901,37 @@ def poincare_logmap0(y):
     return out
 
 
+def narrow_conv_ok(Ci: int, J: int, TV: int) -> bool:
+    return Ci in (16, 32, 64) and J in (2, 4, 6, 8) and TV % 4 == 0
+
+
+def narrow_conv_fwd(U: Tensor, in_slope: Optional[Tensor], W: Tensor) -> Tensor:
+    """[Y; R] = W . PReLU(U): U [B, Ci, T, V] (pre-activation when in_slope is given), W [J, Ci] -> [B, J, T, V] (csrc/last_layer.hip)"""
+    B, Ci, T, V = U.shape
+    J = W.shape[0]
+    _chk(U, "U"); _chk(W, "W", (J, Ci)); _chk(in_slope, "in_slope", (1,), optional=True)
+    out = torch.empty(B, J, T, V, device=U.device, dtype=torch.float32)
+    call("coskad_narrow_conv_fwd_f32", ptr(U), ptr(in_slope), ptr(W), ptr(out), i32(B), i32(Ci), i32(J), i32(T * V), _stream())
+    return out
+
+
+def narrow_conv_bwd(U: Tensor, in_slope: Optional[Tensor], W: Tensor, dOut: Tensor):
+    """-> (dU [B, Ci, T, V], sums [J Ci + 1]): dU = (W^T dOut) PReLU'(U); sums[:J Ci] = dW (row-major [J, Ci]), sums[-1] = the producer's
+    slope gradient (0 without in_slope)."""
+    B, Ci, T, V = U.shape
+    J = W.shape[0]
+    _chk(U, "U"); _chk(W, "W", (J, Ci)); _chk(dOut, "dOut", (B, J, T, V)); _chk(in_slope, "in_slope", (1,), optional=True)
+    rows = _lib.lib().coskad_narrow_conv_rows(i32(B), i32(T * V))
+    E = J * Ci + 1
+    part = torch.empty(rows, E, device=U.device, dtype=torch.float32)
+    dU = torch.empty_like(U)
+    call("coskad_narrow_conv_bwd_f32", ptr(U), ptr(in_slope), ptr(W), ptr(dOut), ptr(dU), ptr(part), ctypes.c_size_t(part.numel()),
+         i32(B), i32(Ci), i32(J), i32(T * V), _stream())
+    sums = torch.empty(E, device=U.device, dtype=torch.float32)
+    call("coskad_gemm_sum_f32", ptr(part), i32(rows), ctypes.c_size_t(E), ptr(sums), i32(0), _stream())
+    return dU, sums
+
+
 def _rows(t: Tensor, name: str, cols: int):
     """a [B, cols] fp32 device view with unit column stride (a column block of a wider row-major tensor is fine) -> its row stride"""
     _cuda_f32(t, name)

@@ -276,6 +276,47 @@ def _layer_grad_views(fp: "FlatParams", prefix: str) -> Dict[str, Tensor]:
     return {k: fp.gviews[prefix + n] for k, n in g.items() if prefix + n in fp.gviews}
 
 
+# layers with <= 4 output channels behind 16 / 32 / 64 input channels (the decoder's last layer) run by commutation: both 1x1
+# convolutions first, as one streaming pass over the wide input, then mixing / BatchNorm / PReLU on 2 C_out-channel tensors
+# (csrc/last_layer.hip).  Tests flip it to hold the two paths against each other.
+NARROW_OUT = True
+
+
+def _is_narrow(m) -> bool:
+    return (NARROW_OUT and m.out_channels <= 4 and not m.is_wide and not isinstance(m.residual, torch.nn.Identity)
+            and ops.narrow_conv_ok(m.in_channels, 2 * m.out_channels, m.time_dim * m.joints_dim))
+
+
+def _virtual_narrow_layer(mod, fp: "FlatParams", prefix: str):
+    """The (2 C_out -> C_out) layer that remains behind the commuted convolutions: input [Y; R] = [Wt X; Wr X], `tcn` convolution =
+    selector of the Y channels (+ the real bias), `residual` convolution = selector of the R channels (+ the real bias); mixing
+    parameters, BatchNorms and PReLU are the real layer's.  -> (LayerTensors, gradient views: the selectors' go to scratch)."""
+    from .models.graph_layers.stsgcn import check_bn
+    Co = mod.out_channels
+    J = 2 * Co
+    tc, tb, rc, rb = mod.tcn[0], mod.tcn[1], mod.residual[0], mod.residual[1]
+    check_bn(tb, rb)
+    dev = mod.gcn.A.device
+    sel_t = torch.zeros(Co, J, 1, 1, device=dev)
+    sel_r = torch.zeros(Co, J, 1, 1, device=dev)
+    for o in range(Co):
+        sel_t[o, o] = 1.0
+        sel_r[o, Co + o] = 1.0
+    lt = engine.LayerTensors(A=mod.gcn.A, T=mod.gcn.T, Wt=sel_t, bt=tc.bias, gt=tb.weight, bet=tb.bias, rm_t=tb.running_mean,
+                             rv_t=tb.running_var, nbt_t=tb.num_batches_tracked, Wr=sel_r, br=rc.bias, gr=rb.weight, ber=rb.bias,
+                             rm_r=rb.running_mean, rv_r=rb.running_var, nbt_r=rb.num_batches_tracked, slope=mod.prelu.weight,
+                             momentum=tb.momentum if tb.momentum is not None else 0.1, bn=tb if tb.momentum is None else None, cache={})
+    gv = fp.gviews
+    g = {"A": gv[prefix + "gcn.A"], "T": gv[prefix + "gcn.T"], "Wt": torch.empty_like(sel_t), "gt": gv[prefix + "tcn.1.weight"],
+         "bet": gv[prefix + "tcn.1.bias"], "Wr": torch.empty_like(sel_r), "gr": gv[prefix + "residual.1.weight"],
+         "ber": gv[prefix + "residual.1.bias"], "slope": gv[prefix + "prelu.weight"]}
+    if tc.bias is not None:
+        g["bt"] = gv[prefix + "tcn.0.bias"]
+    if rc.bias is not None:
+        g["br"] = gv[prefix + "residual.0.bias"]
+    return lt, g
+
+
 class _FlatStack:
     """A stack of ST_GCNN layers (Encoder / Decoder `model`, components.py:70-105,143-179) on flat parameter / gradient
     buffers: runs of layers the LDS tile kernels take go through engine.chain_forward / chain_backward (no autograd);
@@ -291,15 +332,19 @@ class _FlatStack:
             if modules[i].is_wide:
                 self.segs.append(('wide', modules[i], f"{prefix}{first + i}."))
                 i += 1
+            elif _is_narrow(modules[i]):
+                pre = f"{prefix}{first + i}."
+                self.segs.append(('narrow', modules[i], pre) + _virtual_narrow_layer(modules[i], fp, pre))
+                i += 1
             else:
                 j = i
-                while j < n and not modules[j].is_wide:
+                while j < n and not modules[j].is_wide and not _is_narrow(modules[j]):
                     j += 1
                 self.segs.append(('tile', [layer_tensors(m) for m in modules[i:j]],
                                   [_layer_grad_views(fp, f"{prefix}{first + k}.") for k in range(i, j)]))
                 i = j
         self.fp = fp
-        self.last_slope_grad = fp.gviews[f"{prefix}{first + n - 1}.prelu.weight"] if self.segs[-1][0] == 'tile' else None
+        self.last_slope_grad = fp.gviews[f"{prefix}{first + n - 1}.prelu.weight"] if self.segs[-1][0] in ('tile', 'narrow') else None
 
     def forward(self, x: Tensor, ws: engine.Workspace, in_slope: Optional[Tensor] = None):
         """x: the stack's input, activated (in_slope None) or a pre-activation whose PReLU weight is `in_slope`
@@ -310,6 +355,14 @@ class _FlatStack:
                 u, ctx = engine.chain_forward(h, seg[1], True, ws, in_slope=slope, want_ctx=True)
                 saved.append(ctx)
                 h, slope = u, seg[1][-1].slope
+            elif seg[0] == 'narrow':
+                mod, virt = seg[1], seg[3]
+                Co, Ci = mod.out_channels, mod.in_channels
+                W4 = torch.cat([mod.tcn[0].weight.view(Co, Ci), mod.residual[0].weight.view(Co, Ci)], 0)
+                YR = ops.narrow_conv_fwd(h, slope, W4)                     # [Wt X; Wr X] with X = PReLU(h)
+                u, ctx = engine.chain_forward(YR, [virt], True, ws, want_ctx=True)
+                saved.append((ctx, h, slope, W4))
+                h, slope = u, virt.slope
             else:
                 from .models.graph_layers.stsgcn import wide_forward
                 pre_u, pre_slope = (h, slope) if slope is not None else (None, None)
@@ -337,6 +390,22 @@ class _FlatStack:
                 d = engine.chain_backward(sv, seg[1], d, ws, seg[2], need_dx=need_dx or not first,
                                           stats_in=top_stats if k == len(self.segs) - 1 else None,
                                           in_slope_grad=in_slope_grad if first else None)
+            elif seg[0] == 'narrow':
+                mod, prefix, virt, vg = seg[1], seg[2], seg[3], seg[4]
+                ctx, pre_u, pre_slope, W4 = sv
+                Co, Ci = mod.out_channels, mod.in_channels
+                dYR = engine.chain_backward(ctx, [virt], d, ws, [vg], need_dx=True)
+                d, sums = ops.narrow_conv_bwd(pre_u, pre_slope, W4, dYR)
+                gv = self.fp.gviews
+                gv[prefix + "tcn.0.weight"].copy_(sums[:Co * Ci].view(Co, Ci, 1, 1))
+                gv[prefix + "residual.0.weight"].copy_(sums[Co * Ci:2 * Co * Ci].view(Co, Ci, 1, 1))
+                if pre_slope is not None:
+                    dslope = (self.segs[k - 1][2][-1]["slope"] if self.segs[k - 1][0] == 'tile' else self.segs[k - 1][4]["slope"]) \
+                        if k > 0 else in_slope_grad
+                    if dslope is not None:
+                        dslope.copy_(sums[2 * Co * Ci:])
+                if not (need_dx or not first):
+                    d = None
             else:
                 from .models.graph_layers.stsgcn import wide_backward
                 wsaved, wmeta, pre_u, pre_slope = sv

@@ -406,6 +406,19 @@ int coskad_poincare_dist_f32(const float* zh, const float* c, float* score, int 
  * never call it, so it stands alone (no gradient entry). */
 int coskad_poincare_logmap0_f32(const float* y, float* out, int B, int L, hipStream_t stream);
 
+/* Narrow-output layers (C_out <= 4 behind 16 / 32 / 64 input channels: the decoder's last layer, models/common/components.py:143-179 ->
+ * models/graph_layers/stsgcn.py:94-116) by commutation -- the mixing acts per channel, a 1x1 convolution per position, so
+ * Wt gcn(X) = gcn(Wt X): both convolutions of the layer run first, as one streaming pass over the wide input, and mixing / BatchNorm /
+ * PReLU see 2 C_out-channel tensors (csrc/last_layer.hip).
+ *   fwd : out [B, J, TV] = W [J, Ci] . PReLU(U [B, Ci, TV])   (in_slope NULL: U is activated already); J = 2 C_out in {2, 4, 6, 8}
+ *   bwd : dU [B, Ci, TV] = (W^T dOut) * PReLU'(U); partials [coskad_narrow_conv_rows(B, TV)][J Ci + 1]: per-workgroup sums of
+ *         dW[j][c] = sum dOut_j PReLU(U)_c and, last column, of the producer's slope gradient -- add the rows with coskad_gemm_sum_f32 */
+int coskad_narrow_conv_rows(int B, int TV);
+int coskad_narrow_conv_fwd_f32(const float* U, const float* in_slope, const float* W, float* out, int B, int Ci, int J, int TV,
+                               hipStream_t stream);
+int coskad_narrow_conv_bwd_f32(const float* U, const float* in_slope, const float* W, const float* dOut, float* dU, float* partials,
+                               size_t partials_floats, int B, int Ci, int J, int TV, hipStream_t stream);
+
 /* The spherical VAE's latent head between the raw outputs of fc_mean / fc_var and the decoder's input (models/sts/vae.py:79-91,
  * 104-118; loss terms of models/spherical_vae.py:86-94; PowerSpherical of the un-vendored `power_spherical` package, restated in
  * coskad_amd/models/sts/vae.py).  Rows are clips; mean_raw [B, L] and var_raw [B] are addressed with row strides ld_* (floats), so both

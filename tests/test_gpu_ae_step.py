@@ -361,3 +361,37 @@ def test_eval_decode_cache_follows_training(golden):
     with torch.no_grad():
         m.rev_btlnk.bias.add_(0.05)                           # torch-side write: the version counter moves
     assert float((recon() - r1).abs().max()) > 1e-5
+
+
+@pytest.mark.parametrize("V", [17, 25])
+def test_narrow_output_layer_by_commutation_equals_the_layer_kernels(V, monkeypatch):
+    """The decoder's last layer (32 -> 2) with its convolutions commuted in front of the mixing (csrc/last_layer.hip + the few-channel
+    kernels on a virtual 4 -> 2 layer: trainer._FlatStack `narrow` segments) against the same layer on the tile kernels: losses,
+    every gradient (incl. the producing layer's PReLU slope), the running statistics; default widths, ragged batch."""
+    from coskad_amd import trainer
+    from coskad_amd.models.sts.ae import STSAE
+    from oracle import ref_cpu as R
+    torch.manual_seed(5)
+    proto = STSAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    st = {k: v.detach().clone() for k, v in proto.state_dict().items()}
+    x = R.synthetic_clips(37, 2, 12, V, seed=6).cuda()
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(trainer, "NARROW_OUT", on)
+        m = STSAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', 'linear', 'euclidean', 0.0)
+        m.load_state_dict(st)
+        m.cuda().train()
+        eng = trainer.STSAETrainStep(m, mode='ae', lr=0.0, alpha=0.0, lambda_=0.8)
+        assert any(s[0] == 'narrow' for s in eng.dec.segs) == on
+        out = eng.step(x)
+        torch.cuda.synchronize()
+        res[on] = (float(out['rec']), float(out['head']), {n: v.cpu().numpy().copy() for n, v in eng.fp.gviews.items()},
+                   {k: v.cpu().numpy().copy() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+    a, b = res[False], res[True]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-5)
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-5)
+    gmax = max(np.abs(v).max() for v in a[2].values())
+    for n, ref in a[2].items():
+        np.testing.assert_allclose(b[2][n], ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max() + 2e-5 * gmax, err_msg=n)
+    for k, ref in a[3].items():
+        np.testing.assert_allclose(b[3][k], ref, rtol=1e-4, atol=1e-6, err_msg=k)
