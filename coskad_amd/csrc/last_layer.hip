@@ -20,6 +20,22 @@ constexpr int JMAX = 8, CMAX = 64, kThreads = 256;
 
 __device__ __forceinline__ float prelu1(float v, float a) { return v > 0.f ? v : a * v; }
 
+// sum over the 64 lanes as six DPP adds (quad swaps, half-row / row mirrors, row broadcasts) + a readlane -- the shuffle butterfly of
+// wave_sum (six ds_bpermute + adds) costs three times as much, and this kernel does J C_in of them per 256 positions
+__device__ __forceinline__ float wave_total(float v) {
+  int x = __float_as_int(v);
+#define DPP_ADD(ctrl, rmask)                                                                                         \
+  x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, true)))
+  DPP_ADD(0xB1, 0xf);    // quad_perm [1, 0, 3, 2]
+  DPP_ADD(0x4E, 0xf);    // quad_perm [2, 3, 0, 1]
+  DPP_ADD(0x141, 0xf);   // row_half_mirror
+  DPP_ADD(0x140, 0xf);   // row_mirror: every lane of a 16-lane row holds the row's sum
+  DPP_ADD(0x142, 0xa);   // row_bcast15 into rows 1 and 3
+  DPP_ADD(0x143, 0xc);   // row_bcast31 into rows 2 and 3: row 3 holds the total
+#undef DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
 // thread <-> (clip, float4 of positions); channels in the loop: a wave's loads are 1 KB contiguous per channel
 template <int J>
 __global__ __launch_bounds__(kThreads) void k_narrow_fwd(const float* __restrict__ U, const float* __restrict__ in_slope,
@@ -96,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void k_narrow_bwd(const float* __restrict
         d.x = fmaf(w, g[j].x, d.x); d.y = fmaf(w, g[j].y, d.y); d.z = fmaf(w, g[j].z, d.z); d.w = fmaf(w, g[j].w, d.w);
         // d W[j][c] += <dOut_j, X_c> over this wave's 64 position quads
         float s = fmaf(g[j].x, x.x, fmaf(g[j].y, x.y, fmaf(g[j].z, x.z, g[j].w * x.w)));
-        s = wave_sum(s);
+        s = wave_total(s);
         if (lane == 0) red[wave][j * Ci + c] += s;
       }
       if (pre) {
