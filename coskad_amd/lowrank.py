@@ -148,6 +148,8 @@ class LowRankFirstLayer:
         """z [B, Lz] (no autograd) -> U1 [B, C_out, T, V]: the first decoder layer's PRE-activation (apply its PReLU on load)"""
         lay = self.layer
         B, Lz = z.shape
+        lay.__dict__.pop("_lowrank_eval", None)               # eval-mode folds of this layer go stale with this step
+        lay.__dict__.get("_fold_cache", {}).clear()
         zt = torch.cat([z, torch.ones(B, 1, device=z.device, dtype=z.dtype)], 1)
         # G = sum_n zt zt^T: 256-row pieces on the fp32 MFMA GEMM, pieces summed in fp64 in a fixed order (ONE [K, B] x [B, K] fp64
         # library product is a single-workgroup kernel: 224 us at B = 4096)

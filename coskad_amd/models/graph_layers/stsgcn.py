@@ -304,7 +304,11 @@ class ST_GCNN_layer(nn.Module):
 
     def train(self, mode: bool = True):
         if mode:
-            self.__dict__.pop("_lowrank_eval", None)     # eval-mode folded images (models/sts/ae.py): training is about to change what they fold
+            # eval-mode folds (the BatchNorm-folded weights of engine.chain_forward, the folded images of models/sts/ae.py): training is
+            # about to change what they fold, through raw-pointer kernels that move no torch version counter -- and not every training
+            # path runs through this layer's own LayerTensors (trainer._FlatStack `narrow` segments, coskad_amd/lowrank.py)
+            self.__dict__.pop("_lowrank_eval", None)
+            self.__dict__.get("_fold_cache", {}).clear()
         return super().train(mode)
 
     @property

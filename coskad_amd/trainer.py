@@ -359,6 +359,7 @@ class _FlatStack:
                 mod, virt = seg[1], seg[3]
                 Co, Ci = mod.out_channels, mod.in_channels
                 W4 = torch.cat([mod.tcn[0].weight.view(Co, Ci), mod.residual[0].weight.view(Co, Ci)], 0)
+                mod.__dict__.get("_fold_cache", {}).clear()                # (the real layer's eval-mode fold goes stale with this step)
                 YR = ops.narrow_conv_fwd(h, slope, W4)                     # [Wt X; Wr X] with X = PReLU(h)
                 u, ctx = engine.chain_forward(YR, [virt], True, ws, want_ctx=True)
                 saved.append((ctx, h, slope, W4))

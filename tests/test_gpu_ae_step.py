@@ -395,3 +395,38 @@ def test_narrow_output_layer_by_commutation_equals_the_layer_kernels(V, monkeypa
         np.testing.assert_allclose(b[2][n], ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max() + 2e-5 * gmax, err_msg=n)
     for k, ref in a[3].items():
         np.testing.assert_allclose(b[3][k], ref, rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_eval_after_training_through_the_narrow_and_folded_paths_sees_the_new_weights():
+    """eval -> train steps -> eval on one model: the second evaluation must use the trained weights although the narrow / folded
+    training paths never touch the real layers' eval-mode fold caches (regression: stale BatchNorm-folded weights of the decoder's
+    last layer after the first validation)."""
+    from coskad_amd import lowrank
+    from coskad_amd.models.sts.ae import STSAE
+    from coskad_amd.trainer import STSAETrainStep
+    from oracle import ref_cpu as R
+    torch.manual_seed(2)
+    keep = lowrank.MODE
+    lowrank.MODE = 'always'
+    try:
+        m = STSAE(2, [16, 8, 16], 16, 8, 12, 17, 'sts_gcn', 'linear', 'euclidean', 0.0).cuda()
+        eng = STSAETrainStep(m.train(), mode='ae', lr=5e-3, alpha=0.0, lambda_=1.0)
+        assert eng.lowrank is not None and any(s[0] == 'narrow' for s in eng.dec.segs)
+        x = R.synthetic_clips(64, 2, 12, 17, seed=3).cuda()
+
+        def recon():
+            m.eval()
+            with torch.no_grad():
+                return m(x)[1].cpu()
+        r0 = recon()
+        m.train()
+        for _ in range(5):
+            eng.step(x)
+        r1 = recon()
+        st = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            ref = R.stsae_decode(R.stse_encode(x.cpu(), st, training=False), st, 16, 12, 17, training=False)
+        assert float((r1 - r0).abs().max()) > 1e-3
+        np.testing.assert_allclose(r1.numpy(), ref.numpy(), rtol=2e-4, atol=2e-5)
+    finally:
+        lowrank.MODE = keep
