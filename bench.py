@@ -143,11 +143,14 @@ def run_legs(B, rank, world, sync, steps, warmup, only=None):
         for _ in range(w):
             fn()
         sync()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            fn()
-        sync()
-        return (time.perf_counter() - t0) / k
+        reps = []                                     # median of three blocks of k calls: one host hiccup does not decide a leg's figure
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            sync()
+            reps.append((time.perf_counter() - t0) / k)
+        return sorted(reps)[1]
 
     legs = {}
 
