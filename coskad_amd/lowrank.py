@@ -17,8 +17,8 @@ instead of rev_btlnk, the mixing, two convolutions and a BatchNorm / add pass ov
 25-joint layout: 64 input channels do not fit the LDS tile kernels).  Backward: the rev_btlnk backward kernel with M as its weight
 returns dM_l = sum_n zt_l[n] dU1[n] and the direct part of dz; how M depends on the layer's parameters, on Wrev / brev (K images: tiny
 tensors) and on G is differentiated by torch autograd on [K, C, T V] tensors; dz += zt (dG + dG^T).  Same function, same gradients
-(tests/test_gpu_ae_step.py holds it against the REFERENCE's gradients, tests/golden/stsae_v25.npz); V = 25 spherical-VAE step
-7.0 -> 5.5 ms.
+(tests/test_gpu_ae_step.py holds it against the REFERENCE's gradients, tests/golden/stsae_*.npz); V = 25 spherical-VAE step
+7.0 -> 5.4 ms, default-width autoencoder step at 17 joints 3.83 -> 3.08 ms.
 """
 from __future__ import annotations
 
@@ -31,9 +31,11 @@ from . import ops
 
 Tensor = torch.Tensor
 
-# which decoders take the folded first layer: 'wide' = only where the layer would run the composed wide path (64 input channels on
-# the 25-joint layout), 'always', 'never' (tests flip it)
-MODE = 'wide'
+# which decoders take the folded first layer: 'always' (wherever rev_btlnk's latent size is one the streaming kernels take), 'wide' =
+# only where the layer would run the composed wide path (64 input channels on the 25-joint layout), 'never'.  Measured at B = 4096,
+# default-width autoencoder step (tools/bench_ae.py): 17 joints 3.83 -> 3.08 ms (64 input channels are beyond the fused 17-joint
+# kernels too: that layer ran on the round-1 tile kernels), 25 joints 6.41 -> 4.87 ms.  Tests flip it.
+MODE = 'always'
 # True: the fold's ~60 small torch launches and the ~170 of its autograd backward are replayed as two hipGraphs per position count
 # (their shapes do not depend on the batch).  Measured on the V = 25 VAE step (B = 4096): host enqueue time 4.4 -> 2.0 ms per step, but
 # the step itself 5.53 -> 6.0 ms -- a graph node costs more device time than an eager back-to-back launch on this stack -- so the
