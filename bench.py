@@ -194,17 +194,17 @@ def run_legs(B, rank, world, sync, steps, warmup, only=None):
     leg("v25_encoder", enc_leg(25, 'euclidean', 'linear', f"euclidean encoder train step on the 25-joint layout, B={B}/GPU T={T} V=25, default "
                                f"stack, latent {LATENT}"))
 
-    def vae_leg():
+    def vae_leg(v=25):
         torch.manual_seed(0)
-        m = STSVAE(C_IN, CHANNELS, HID, 8, T, 25, 'sts_gcn', 'mlp', 'euclidean', 0.0, distribution='ps')   # projector: spherical_vae.yaml:37
+        m = STSVAE(C_IN, CHANNELS, HID, 8, T, v, 'sts_gcn', 'mlp', 'euclidean', 0.0, distribution='ps')   # projector: spherical_vae.yaml:37
         eng = STSAETrainStep(m.cuda().train(), mode='vae', lr=1e-4, alpha=1e-6, phi=1.0, beta=1.0, gamma=1.0)
-        x = synthetic_clips(B, C_IN, T, 25, seed=400 + rank).cuda()
+        x = synthetic_clips(B, C_IN, T, v, seed=400 + rank).cuda()
         dt = timed(lambda: eng.step(x))
         chans = [C_IN] + CHANNELS + [HID]
-        fb, bb = algorithmic_bytes_per_clip(tv=T * 25, latent=9)
+        fb, bb = algorithmic_bytes_per_clip(tv=T * v, latent=9)
         dchans = chans[::-1]
-        fd = sum(4 * T * 25 * (ci + co) for ci, co in zip(dchans[:-1], dchans[1:]))
-        bd = sum(4 * T * 25 * (co + 2 * ci) for ci, co in zip(dchans[:-1], dchans[1:]))
+        fd = sum(4 * T * v * (ci + co) for ci, co in zip(dchans[:-1], dchans[1:]))
+        bd = sum(4 * T * v * (co + 2 * ci) for ci, co in zip(dchans[:-1], dchans[1:]))
         total = fb + bb + fd + bd
         m.eval()
         with torch.no_grad():                                  # scoring forward: encoder, heads, sample, decoder (spherical_vae.py:76-78)
@@ -213,11 +213,12 @@ def run_legs(B, rank, world, sync, steps, warmup, only=None):
         fwd_only = {"ms": round(dtf * 1e3, 4), "clips_per_s": round(B / dtf, 1), "layerwise_equiv_hbm_frac": hbm(B / dtf, fb + fd),
                     "what": "eval-mode forward of the whole VAE (latent sampled as in the reference's scoring)"}
         return {"forward_only": fwd_only, "workload": f"spherical_vae train step (BASELINE config 4's model: STSVAE, projector 'mlp', PowerSpherical latent 8, decoder; phi MSE + "
-                            f"beta KL + gamma mean(1/kappa) + alpha reg), B={B}/GPU T={T} V=25, default widths", "engine": "STSAETrainStep",
+                            f"beta KL + gamma mean(1/kappa) + alpha reg), B={B}/GPU T={T} V={v}, default widths", "engine": "STSAETrainStep",
                 "ms_per_step": round(dt * 1e3, 4), "clips_per_s": round(world * B / dt, 1),
                 "roofline": {"bound": "hbm", "frac": hbm(B / dt, total), "algorithmic_bytes_per_clip": total, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
 
     leg("v25_spherical_vae", vae_leg)
+    leg("v17_spherical_vae", lambda: vae_leg(17))           # the shape of the reference's shipped config/UBnormal/spherical_vae.yaml
 
     def wide_leg():
         torch.manual_seed(0)

@@ -42,6 +42,10 @@ MODE = 'always'
 # default is eager; a host that cannot keep 4.4 ms of launches ahead of 5.5 ms of kernels would flip it.  (A BatchNorm with
 # momentum=None -- its averaging factor changes per step -- and a failed capture are always eager.)
 GRAPH_FOLD = False
+# the fold's backward written out (no autograd; the K-image mixing and its gradient on this library's gcn kernels): ~100 launches per
+# step instead of ~215, 1.3 ms less host time -- the 17-joint VAE step was host-bound on the autograd fold (4.10 ms for 3.4 ms of
+# kernels).  False: torch autograd (the form the tests hold the explicit one against); identity-residual layers always take it.
+EXPLICIT = True
 
 
 class LowRankFirstLayer:
@@ -123,6 +127,81 @@ class LowRankFirstLayer:
         Mb = M[K - 1].reshape(-1).contiguous()
         return Mw, Mb
 
+    # ---- the same fold with its backward written out (conv-residual layers) ---------------------------------------------------
+    def _fold_explicit(self, G: Tensor, n_pos: float):
+        """-> (Mw, Mb, ctx); same arithmetic as _fold (conv biases drop out of a train-mode BatchNorm's output: they only shift the
+        running means), intermediates kept for _fold_explicit_bwd"""
+        rev, lay = self.rev, self.layer
+        K = rev.in_features + 1
+        Ci, Co, T, V = lay.in_channels, lay.out_channels, lay.time_dim, lay.joints_dim
+        TV = T * V
+        tc, tb, rc, rb = lay.tcn[0], lay.tcn[1], lay.residual[0], lay.residual[1]
+        with torch.no_grad():
+            Hb = torch.cat([rev.weight.t(), rev.bias[None]], 0).view(K, Ci, T, V)
+            Zb = ops.gcn(Hb, lay.gcn.A, lay.gcn.T)
+            X = torch.empty(2, K, Co, TV, device=G.device, dtype=torch.float32)
+            torch.matmul(tc.weight.view(Co, Ci), Zb.view(K, Ci, TV), out=X[0])
+            torch.matmul(rc.weight.view(Co, Ci), Hb.view(K, Ci, TV), out=X[1])
+            Xd = X.double()
+            xbar = Xd.sum(-1)                                                # [2, K, Co]
+            s = G[:, K - 1]
+            mean = (s.view(1, K, 1) * xbar).sum(1) / n_pos                    # [2, Co] (without the conv biases)
+            XX = torch.matmul(Xd.permute(0, 2, 1, 3), Xd.permute(0, 2, 3, 1))  # [2, Co, K, K]
+            var = ((XX * G).sum((2, 3)) / n_pos - mean * mean).clamp_min(0.0)
+            unb = n_pos / (n_pos - 1.0) if n_pos > 1 else 1.0
+            mf, vf = mean.float(), (var * unb).float()
+            for r, (bn, cv) in enumerate(((tb, tc), (rb, rc))):
+                if bn.running_mean is not None:
+                    mom = ops.bn_momentum(bn)
+                    bn.running_mean.mul_(1 - mom).add_(mf[r] + cv.bias if cv.bias is not None else mf[r], alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(vf[r], alpha=mom)
+                    bn.num_batches_tracked.add_(1)
+            gamma = torch.stack([tb.weight, rb.weight]).double()
+            beta = torch.stack([tb.bias, rb.bias]).double()
+            eps = tb.eps if tb.eps == rb.eps else torch.tensor([tb.eps, rb.eps], device=G.device, dtype=torch.float64).view(2, 1)
+            istd = torch.rsqrt(var + eps)
+            a = gamma * istd
+            M = (a.float().view(2, 1, Co, 1) * X).sum(0)
+            M[K - 1] += (beta - a * mean).sum(0).float().view(Co, 1)
+            Mw = M[:K - 1].reshape(K - 1, Co * TV).t().contiguous()
+            Mb = M[K - 1].reshape(-1).contiguous()
+        return Mw, Mb, (Hb, Zb, X, xbar, XX, mean, istd, a, gamma, n_pos)
+
+    def _fold_explicit_bwd(self, G: Tensor, ctx, dMw: Tensor, dMb: Tensor):
+        """-> gradients in _params() order, then dG"""
+        Hb, Zb, X, xbar, XX, mean, istd, a, gamma, n_pos = ctx
+        rev, lay = self.rev, self.layer
+        K = rev.in_features + 1
+        Ci, Co, T, V = lay.in_channels, lay.out_channels, lay.time_dim, lay.joints_dim
+        TV = T * V
+        tc, rc = lay.tcn[0], lay.residual[0]
+        with torch.no_grad():
+            dM = torch.empty(K, Co, TV, device=G.device, dtype=torch.float32)
+            dM[:K - 1] = dMw.t().view(K - 1, Co, TV)
+            dM[K - 1] = dMb.view(Co, TV)
+            S1 = dM[K - 1].sum(-1).double()                                   # d shift: both BatchNorms' d beta
+            da = (dM[None] * X).sum((1, 3)).double() - mean * S1              # M = a X (+ shift = beta - a mean on the constant image)
+            dgamma = da * istd
+            dvar = -0.5 * (da * gamma) * istd ** 3                            # a = gamma (var + eps)^(-1/2)
+            dmean = -a * S1 - 2.0 * mean * dvar                               # var = E[x^2] - mean^2
+            s = G[:, K - 1]
+            GX = torch.matmul(G.float(), X.view(2, K, Co * TV)).view(2, K, Co, TV)
+            dX = (a.float().view(2, 1, Co, 1) * dM[None] + ((dmean / n_pos).float().view(2, 1, Co, 1) * s.float().view(1, K, 1, 1))
+                  + (2.0 * dvar / n_pos).float().view(2, 1, Co, 1) * GX)
+            dG = (dvar.view(2, Co, 1, 1) * XX).sum((0, 1)) / n_pos
+            dG[:, K - 1] += (dmean.view(2, 1, Co) * xbar).sum((0, 2)) / n_pos
+            dP, dQ = dX[0], dX[1]
+            dWt = torch.einsum('kop,kcp->oc', dP, Zb.view(K, Ci, TV))
+            dWr = torch.einsum('kop,kcp->oc', dQ, Hb.view(K, Ci, TV))
+            dZb = torch.matmul(tc.weight.view(Co, Ci).t(), dP).view(K, Ci, T, V)
+            dHr = torch.matmul(rc.weight.view(Co, Ci).t(), dQ).view(K, Ci, T, V)
+            dA, dT, dHb = ops.gcn_bwd_params_dx(Hb, dZb, lay.gcn.A, lay.gcn.T, add=dHr)
+            dHb = dHb.view(K, Ci * TV)
+            S1f = S1.float()
+            grads = [dHb[:K - 1].t(), dHb[K - 1], dA, dT, dWt.view_as(tc.weight), dgamma[0].float(), S1f,
+                     dWr.view_as(rc.weight), dgamma[1].float(), S1f]
+        return grads + [dG]
+
     def _bns(self):
         lay = self.layer
         return [lay.tcn[1]] + ([] if isinstance(lay.residual, nn.Identity) else [lay.residual[1]])
@@ -163,6 +242,10 @@ class LowRankFirstLayer:
                 fg.G.copy_(G32)
             fg.fwd.replay()
             G, Mw, Mb = fg.G, fg.Mw, fg.Mb
+        elif EXPLICIT and not isinstance(lay.residual, nn.Identity):
+            G = G32.double()
+            Mw, Mb, ectx = self._fold_explicit(G, n_pos)
+            fg = ("explicit", ectx)
         else:
             G = G32.double().requires_grad_(True)
             with torch.enable_grad():
@@ -189,12 +272,15 @@ class LowRankFirstLayer:
         self._saved = None
         B = z.shape[0]
         named = self._params()
-        if fg is not None:
+        explicit = isinstance(fg, tuple)
+        if fg is not None and not explicit:
             dMw, dMb = fg.dMw, fg.dMb
         else:
             dMw, dMb = torch.empty_like(Mwd), torch.empty(Mwd.shape[0], device=z.device, dtype=torch.float32)
         dz = ops.rev_btlnk_bwd(dU1.reshape(B, -1), z, Mwd, dMw, dMb, dz=dz)
-        if fg is not None:
+        if explicit:
+            grads = self._fold_explicit_bwd(G, fg[1], dMw, dMb)
+        elif fg is not None:
             fg.bwd.replay()
             grads = fg.grads
         else:

@@ -234,9 +234,9 @@ def test_power_spherical_head_kernels_vs_torch_autograd(L):
     np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-3, atol=2e-6 + 2e-4 * np.abs(ref[ok]).max())
 
 
-@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("variant", ["explicit", "autograd", "graph"])
 @pytest.mark.parametrize("name", ["stsae_small.npz", "stsae_v25.npz"])
-def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name, graph, monkeypatch):
+def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name, variant, monkeypatch):
     """coskad_amd/lowrank.py (rev_btlnk + the decoder's first layer as ONE streaming pass over a rank-(latent + 1) input) against
     the layer-by-layer flat step on the same model: loss, latents, every gradient, the running statistics -- at 17 joints (where
     the layer would run on the tile kernels) and at 25 (where it would take the composed wide path; the mode the flat step picks
@@ -246,7 +246,9 @@ def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name,
     from coskad_amd.trainer import STSAETrainStep
     g = golden(name)
     res = {}
-    monkeypatch.setattr(lowrank, "GRAPH_FOLD", graph)      # the fold replayed as two hipGraphs / launched eagerly
+    graph = variant == "graph"
+    monkeypatch.setattr(lowrank, "GRAPH_FOLD", graph)      # the fold replayed as two hipGraphs / launched eagerly ...
+    monkeypatch.setattr(lowrank, "EXPLICIT", variant == "explicit")   # ... its backward written out / torch autograd
     for mode in ("never", "always"):
         monkeypatch.setattr(lowrank, "MODE", mode)
         m, st = _build(g, STSAE)
