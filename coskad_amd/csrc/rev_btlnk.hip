@@ -132,7 +132,18 @@ __global__ __launch_bounds__(256) void k_rev_dz(const float* __restrict__ dH, co
   }
 }
 
-static int slices(int B) { return B < 16 ? 1 : 16; }
+// clip slices of the (column blocks) x (slices) grids: enough of them for ~1024 workgroups (a narrow output -- the folded first decoder
+// layer's 32 T V columns -- has 7..10 column blocks: at 16 slices the launch filled under half the CUs: k_rev_dw 125 us, k_rev_fwd 61 us
+// for 107 MB at B = 4096), at most one slice per 16 clips, at most 64 (the partial dW table is slices x N x (L + 1) floats)
+static int slices(int B, int N) {
+  if (B < 16) return 1;
+  const int gx = ceil_div(N / 4, 256);
+  int s = ceil_div(1024, gx);
+  if (s < 16) s = 16;
+  if (s > 64) s = 64;
+  if (s > B / 16) s = B / 16;
+  return s < 1 ? 1 : s;
+}
 
 }  // namespace rb
 }  // namespace coskad
@@ -142,14 +153,14 @@ using namespace coskad;
 extern "C" {
 
 /* floats of scratch coskad_rev_btlnk_bwd_f32 needs (partial dW / db per clip slice) */
-size_t coskad_rev_btlnk_ws_floats(int B, int N, int L) { return (size_t)rb::slices(B) * (size_t)N * (L + 1); }
+size_t coskad_rev_btlnk_ws_floats(int B, int N, int L) { return (size_t)rb::slices(B, N) * (size_t)N * (L + 1); }
 
 /* H = z W^T + bias  (ae.py:223-227): z [B, L], W [N, L], bias [N] or NULL, H [B, N]; L in {8, 16}, N % 4 == 0 */
 int coskad_rev_btlnk_fwd_f32(const float* z, const float* W, const float* bias, float* H, int B, int N, int L, hipStream_t stream) {
   if (!z || !W || !H) return fail(COSKAD_ERR_ARG, "rev_btlnk_fwd: null pointer");
   if (B <= 0 || N <= 0 || N % 4 || (L != 8 && L != 16)) return fail(COSKAD_ERR_SHAPE, "rev_btlnk_fwd: B=%d N=%d L=%d (L in {8,16}, N %% 4 == 0)", B, N, L);
   if ((size_t)H & 15) return fail(COSKAD_ERR_ARG, "rev_btlnk_fwd: H must be 16-byte aligned");
-  const int S = B < 64 ? 1 : (B < 1024 ? 4 : 16);
+  const int S = B < 64 ? 1 : (B < 1024 ? 4 : rb::slices(B, N));
   const int chunk = ceil_div(B, S);
   dim3 grid(ceil_div(N / 4, 256), S);
   if (L == 8) hipLaunchKernelGGL(rb::k_rev_fwd<8>, grid, dim3(256), 0, stream, z, W, bias, H, B, N, chunk);
@@ -164,7 +175,7 @@ int coskad_rev_btlnk_bwd_f32(const float* dH, const float* z, const float* W, fl
   if (!dH || !z || !W || !dz || !dW || !ws) return fail(COSKAD_ERR_ARG, "rev_btlnk_bwd: null pointer");
   if (B <= 0 || N <= 0 || N % 4 || (L != 8 && L != 16)) return fail(COSKAD_ERR_SHAPE, "rev_btlnk_bwd: B=%d N=%d L=%d (L in {8,16}, N %% 4 == 0)", B, N, L);
   if ((size_t)dH & 15) return fail(COSKAD_ERR_ARG, "rev_btlnk_bwd: dH must be 16-byte aligned");
-  const int S = rb::slices(B), chunk = ceil_div(B, S);
+  const int S = rb::slices(B, N), chunk = ceil_div(B, S);
   dim3 grid(ceil_div(N / 4, 256), S);
   int rc;
   if (L == 8) {
