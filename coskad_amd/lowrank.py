@@ -46,6 +46,8 @@ GRAPH_FOLD = False
 # step instead of ~215, 1.3 ms less host time -- the 17-joint VAE step was host-bound on the autograd fold (4.10 ms for 3.4 ms of
 # kernels).  False: torch autograd (the form the tests hold the explicit one against); identity-residual layers always take it.
 EXPLICIT = True
+# with the explicit fold: its statistics algebra on csrc/lowrank_fold.hip (one launch each way; latent 8) / as ~35 torch launches
+FOLD_KERNEL = True
 
 
 class LowRankFirstLayer:
@@ -142,6 +144,9 @@ class LowRankFirstLayer:
             X = torch.empty(2, K, Co, TV, device=G.device, dtype=torch.float32)
             torch.matmul(tc.weight.view(Co, Ci), Zb.view(K, Ci, TV), out=X[0])
             torch.matmul(rc.weight.view(Co, Ci), Hb.view(K, Ci, TV), out=X[1])
+            if FOLD_KERNEL and ops.lowrank_fold_ok(rev.in_features, TV):      # the statistics algebra as ONE kernel (csrc/lowrank_fold.hip)
+                Mw, Mb, kctx = ops.lowrank_fold_fwd(X, G, tb, rb, tc.bias, rc.bias, n_pos)
+                return Mw, Mb, ("kernel", Hb, Zb, X, kctx, n_pos)
             Xd = X.double()
             xbar = Xd.sum(-1)                                                # [2, K, Co]
             s = G[:, K - 1]
@@ -165,16 +170,21 @@ class LowRankFirstLayer:
             M[K - 1] += (beta - a * mean).sum(0).float().view(Co, 1)
             Mw = M[:K - 1].reshape(K - 1, Co * TV).t().contiguous()
             Mb = M[K - 1].reshape(-1).contiguous()
-        return Mw, Mb, (Hb, Zb, X, xbar, XX, mean, istd, a, gamma, n_pos)
+        return Mw, Mb, ("torch", Hb, Zb, X, xbar, XX, mean, istd, a, gamma, n_pos)
 
     def _fold_explicit_bwd(self, G: Tensor, ctx, dMw: Tensor, dMb: Tensor):
         """-> gradients in _params() order, then dG"""
-        Hb, Zb, X, xbar, XX, mean, istd, a, gamma, n_pos = ctx
         rev, lay = self.rev, self.layer
         K = rev.in_features + 1
         Ci, Co, T, V = lay.in_channels, lay.out_channels, lay.time_dim, lay.joints_dim
         TV = T * V
         tc, rc = lay.tcn[0], lay.residual[0]
+        if ctx[0] == "kernel":
+            _, Hb, Zb, X, kctx, n_pos = ctx
+            with torch.no_grad():
+                dX, dgam, dbeta, dG = ops.lowrank_fold_bwd(X, G, dMw, dMb, kctx, lay.tcn[1].weight, lay.residual[1].weight, n_pos)
+                return self._fold_tail(Hb, Zb, dX, dgam[0], dgam[1], dbeta) + [dG]
+        _, Hb, Zb, X, xbar, XX, mean, istd, a, gamma, n_pos = ctx
         with torch.no_grad():
             dM = torch.empty(K, Co, TV, device=G.device, dtype=torch.float32)
             dM[:K - 1] = dMw.t().view(K - 1, Co, TV)
@@ -190,17 +200,24 @@ class LowRankFirstLayer:
                   + (2.0 * dvar / n_pos).float().view(2, 1, Co, 1) * GX)
             dG = (dvar.view(2, Co, 1, 1) * XX).sum((0, 1)) / n_pos
             dG[:, K - 1] += (dmean.view(2, 1, Co) * xbar).sum((0, 2)) / n_pos
-            dP, dQ = dX[0], dX[1]
-            dWt = torch.einsum('kop,kcp->oc', dP, Zb.view(K, Ci, TV))
-            dWr = torch.einsum('kop,kcp->oc', dQ, Hb.view(K, Ci, TV))
-            dZb = torch.matmul(tc.weight.view(Co, Ci).t(), dP).view(K, Ci, T, V)
-            dHr = torch.matmul(rc.weight.view(Co, Ci).t(), dQ).view(K, Ci, T, V)
-            dA, dT, dHb = ops.gcn_bwd_params_dx(Hb, dZb, lay.gcn.A, lay.gcn.T, add=dHr)
-            dHb = dHb.view(K, Ci * TV)
             S1f = S1.float()
-            grads = [dHb[:K - 1].t(), dHb[K - 1], dA, dT, dWt.view_as(tc.weight), dgamma[0].float(), S1f,
-                     dWr.view_as(rc.weight), dgamma[1].float(), S1f]
-        return grads + [dG]
+            return self._fold_tail(Hb, Zb, dX, dgamma[0].float(), dgamma[1].float(), S1f) + [dG]
+
+    def _fold_tail(self, Hb, Zb, dX, dgamma_t, dgamma_r, dbeta):
+        """back through P = Wt gcn(Hb), Q = Wr Hb and Hb = (columns of Wrev, brev): gradients in _params() order"""
+        rev, lay = self.rev, self.layer
+        K = rev.in_features + 1
+        Ci, Co, T, V = lay.in_channels, lay.out_channels, lay.time_dim, lay.joints_dim
+        TV = T * V
+        tc, rc = lay.tcn[0], lay.residual[0]
+        dP, dQ = dX[0], dX[1]
+        dWt = torch.einsum('kop,kcp->oc', dP, Zb.view(K, Ci, TV))
+        dWr = torch.einsum('kop,kcp->oc', dQ, Hb.view(K, Ci, TV))
+        dZb = torch.matmul(tc.weight.view(Co, Ci).t(), dP).view(K, Ci, T, V)
+        dHr = torch.matmul(rc.weight.view(Co, Ci).t(), dQ).view(K, Ci, T, V)
+        dA, dT, dHb = ops.gcn_bwd_params_dx(Hb, dZb, lay.gcn.A, lay.gcn.T, add=dHr)
+        dHb = dHb.view(K, Ci * TV)
+        return [dHb[:K - 1].t(), dHb[K - 1], dA, dT, dWt.view_as(tc.weight), dgamma_t, dbeta, dWr.view_as(rc.weight), dgamma_r, dbeta]
 
     def _bns(self):
         lay = self.layer

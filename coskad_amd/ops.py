@@ -901,6 +901,45 @@ def poincare_logmap0(y):
     return out
 
 
+def lowrank_fold_ok(latent: int, TV: int) -> bool:
+    return bool(_lib.lib().coskad_lowrank_fold_ok(i32(latent), i32(TV)))
+
+
+def lowrank_fold_fwd(X: Tensor, G: Tensor, bn_t, bn_r, bias_t, bias_r, n_pos: float):
+    """csrc/lowrank_fold.hip: X [2, 9, Co, TV] fp32, G [9, 9] fp64 -> (Mw [Co TV, 8], Mb [Co TV], ctx); updates the running statistics of
+    the two BatchNorm modules (call once per training forward)."""
+    R, K, Co, TV = X.shape
+    _chk(X, "X", (2, 9, Co, TV)); _chk(G, "G", (9, 9), dtype=torch.float64)
+    dev = X.device
+    Mw = torch.empty(Co * TV, K - 1, device=dev, dtype=torch.float32)
+    Mb = torch.empty(Co * TV, device=dev, dtype=torch.float32)
+    saved = torch.empty(3, 2, Co, device=dev, dtype=torch.float64)
+    xbar = torch.empty(2, K, Co, device=dev, dtype=torch.float64)
+    xx = torch.empty(2, Co, K, K, device=dev, dtype=torch.float64)
+    args = []
+    for bn, cb in ((bn_t, bias_t), (bn_r, bias_r)):
+        args += [ptr(bn.weight), ptr(bn.bias), ptr(cb), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                 ctypes.c_float(bn_momentum(bn)), ctypes.c_float(bn.eps)]
+    call("coskad_lowrank_fold_fwd_f32", ptr(X), ptr(G), *args, ctypes.c_double(n_pos), ptr(Mw), ptr(Mb), ptr(saved), ptr(xbar), ptr(xx),
+         i32(Co), i32(TV), _stream())
+    return Mw, Mb, (saved, xbar, xx)
+
+
+def lowrank_fold_bwd(X: Tensor, G: Tensor, dMw: Tensor, dMb: Tensor, ctx, gamma_t: Tensor, gamma_r: Tensor, n_pos: float):
+    """-> (dX [2, 9, Co, TV], dgamma [2, Co], dbeta [Co], dG [9, 9] fp64)"""
+    R, K, Co, TV = X.shape
+    saved, xbar, xx = ctx
+    _chk(dMw, "dMw", (Co * TV, K - 1)); _chk(dMb, "dMb", (Co * TV,))
+    dev = X.device
+    dX = torch.empty_like(X)
+    dgamma = torch.empty(2, Co, device=dev, dtype=torch.float32)
+    dbeta = torch.empty(Co, device=dev, dtype=torch.float32)
+    dGc = torch.empty(Co, K, K, device=dev, dtype=torch.float64)
+    call("coskad_lowrank_fold_bwd_f32", ptr(X), ptr(G), ptr(dMw), ptr(dMb), ptr(saved), ptr(xbar), ptr(xx), ptr(gamma_t), ptr(gamma_r),
+         ctypes.c_double(n_pos), ptr(dX), ptr(dgamma), ptr(dbeta), ptr(dGc), i32(Co), i32(TV), _stream())
+    return dX, dgamma, dbeta, dGc.sum(0)
+
+
 def narrow_conv_ok(Ci: int, J: int, TV: int) -> bool:
     return Ci in (16, 32, 64) and J in (2, 4, 6, 8) and TV % 4 == 0
 

@@ -406,6 +406,23 @@ int coskad_poincare_dist_f32(const float* zh, const float* c, float* score, int 
  * never call it, so it stands alone (no gradient entry). */
 int coskad_poincare_logmap0_f32(const float* y, float* out, int B, int L, hipStream_t stream);
 
+/* The statistics algebra of the folded first decoder layer (coskad_amd/lowrank.py: rev_btlnk, models/sts/ae.py:223-227, + the first
+ * ST_GCNN layer of the decoder, models/graph_layers/stsgcn.py:106-110, on a rank-(latent + 1) input) for latent 8: X [2, 9, Co, TV] holds
+ * the nine basis images of the two BatchNorm branches, G [9, 9] (fp64) the latents' Gram matrix sum_n [z, 1][z, 1]^T.
+ *   fwd: batch statistics of both branches from G (fp64), running-statistics update (momentum, unbiased variance; conv biases shift
+ *        the running means only), folded images in the rev_btlnk kernels' weight layout Mw [Co TV, 8], Mb [Co TV]; saved / xbar / xx:
+ *        fp64 scratch of 6 Co / 18 Co / 162 Co doubles for the backward
+ *   bwd: from dMw / dMb: dX [2, 9, Co, TV], dgamma [2][Co], dbeta [Co] (both BatchNorms'), dGc [Co][9][9] (its sum over Co is dG) */
+int coskad_lowrank_fold_ok(int latent, int TV);
+int coskad_lowrank_fold_fwd_f32(const float* X, const double* G, const float* gamma0, const float* beta0, const float* cbias0,
+                                float* rmean0, float* rvar0, long long* nbt0, float momentum0, float eps0, const float* gamma1,
+                                const float* beta1, const float* cbias1, float* rmean1, float* rvar1, long long* nbt1, float momentum1,
+                                float eps1, double n_pos, float* Mw, float* Mb, double* saved, double* xbar, double* xx, int Co, int TV,
+                                hipStream_t stream);
+int coskad_lowrank_fold_bwd_f32(const float* X, const double* G, const float* dMw, const float* dMb, const double* saved,
+                                const double* xbar, const double* xx, const float* gamma0, const float* gamma1, double n_pos, float* dX,
+                                float* dgamma, float* dbeta, double* dGc, int Co, int TV, hipStream_t stream);
+
 /* Narrow-output layers (C_out <= 4 behind 16 / 32 / 64 input channels: the decoder's last layer, models/common/components.py:143-179 ->
  * models/graph_layers/stsgcn.py:94-116) by commutation -- the mixing acts per channel, a 1x1 convolution per position, so
  * Wt gcn(X) = gcn(Wt X): both convolutions of the layer run first, as one streaming pass over the wide input, and mixing / BatchNorm /

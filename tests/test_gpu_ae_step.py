@@ -234,7 +234,7 @@ def test_power_spherical_head_kernels_vs_torch_autograd(L):
     np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-3, atol=2e-6 + 2e-4 * np.abs(ref[ok]).max())
 
 
-@pytest.mark.parametrize("variant", ["explicit", "autograd", "graph"])
+@pytest.mark.parametrize("variant", ["kernel", "explicit", "autograd", "graph"])
 @pytest.mark.parametrize("name", ["stsae_small.npz", "stsae_v25.npz"])
 def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name, variant, monkeypatch):
     """coskad_amd/lowrank.py (rev_btlnk + the decoder's first layer as ONE streaming pass over a rank-(latent + 1) input) against
@@ -248,7 +248,8 @@ def test_folded_first_decoder_layer_equals_the_layer_by_layer_path(golden, name,
     res = {}
     graph = variant == "graph"
     monkeypatch.setattr(lowrank, "GRAPH_FOLD", graph)      # the fold replayed as two hipGraphs / launched eagerly ...
-    monkeypatch.setattr(lowrank, "EXPLICIT", variant == "explicit")   # ... its backward written out / torch autograd
+    monkeypatch.setattr(lowrank, "EXPLICIT", variant in ("explicit", "kernel"))   # ... its backward written out / torch autograd
+    monkeypatch.setattr(lowrank, "FOLD_KERNEL", variant == "kernel")              # ... the statistics algebra on csrc/lowrank_fold.hip
     for mode in ("never", "always"):
         monkeypatch.setattr(lowrank, "MODE", mode)
         m, st = _build(g, STSAE)
