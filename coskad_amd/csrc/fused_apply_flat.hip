@@ -28,13 +28,14 @@ constexpr int window_stride(int tv) {
   return l;
 }
 
-// CT: 16-row groups of the input; OT: 16-channel output tiles
-template <int TVg, int CT, int OT>
+// CT: 16-row groups of the input; OT: 16-channel output tiles; XO: the product runs over the layer input alone (out = W . PReLU(in) + b:
+// the commuted convolutions of csrc/commute_layer.hip; `Zg` unused, `wfold` [Ci x CoP])
+template <int TVg, int CT, int OT, bool XO = false>
 __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __restrict__ in, const float* __restrict__ Zg,
                                                             const float* __restrict__ wfold, const float* __restrict__ bias,
                                                             const float* __restrict__ in_slope, float* __restrict__ out, int B) {
   static_assert(TVg % 4 == 0, "rows are staged as float4");
-  constexpr int Ci = 16 * CT, Co = 16 * OT, CoP = Co, NG = 2 * CT;
+  constexpr int Ci = 16 * CT, Co = 16 * OT, CoP = Co, NG = XO ? CT : 2 * CT;
   constexpr int R4 = TVg / 4;                            // float4 per row
   constexpr int LDg = TVg + 2;                           // flush image stride (two padding columns: masked lanes store there)
   constexpr int LDWg = window_stride(TVg);
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
   };
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
-  const BufRes wres = make_res(wfold, 2 * Ci * CoP * 4u);
+  const BufRes wres = make_res(wfold, NG * 16 * CoP * 4u);
   const BufRes bres = make_res(bias, CoP * 4u);
   auto clip_res = [&](const float* base, int c, int rows) {
     const bool in_range = c < B;
@@ -86,16 +87,19 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
 
   int clip = blockIdx.x;
   {
-    const BufRes z0 = clip_res(Zg, clip, Ci);
+    const BufRes z0 = clip_res(XO ? in : Zg, clip, Ci);
 #pragma unroll
     for (int q = 0; q < 4; ++q) qload(z0, 0, q, gq[q]);
   }
   for (; clip < B; clip += gridDim.x) {
-    const BufRes xres = clip_res(in, clip, Ci), zres = clip_res(Zg, clip, Ci), ores = clip_res(out, clip, Co);
-    const BufRes znext = clip_res(Zg, clip + gridDim.x, Ci);
-    // group g of this clip: Z rows first (CT groups), then the layer input; beyond: the next clip's first group
+    const BufRes xres = clip_res(in, clip, Ci), zres = clip_res(XO ? in : Zg, clip, Ci), ores = clip_res(out, clip, Co);
+    const BufRes znext = clip_res(XO ? in : Zg, clip + gridDim.x, Ci);
+    // group g of this clip: Z rows first (CT groups), then the layer input (XO: the input alone); beyond: the next clip's first group
     auto gload = [&](int g, int q, float4 (&dst)[NQ]) {
-      if (g < CT) qload(zres, 16 * g, q, dst);
+      if (XO) {
+        if (g < NG) qload(xres, 16 * g, q, dst);
+        else qload(znext, 0, q, dst);
+      } else if (g < CT) qload(zres, 16 * g, q, dst);
       else if (g < NG) qload(xres, 16 * (g - CT), q, dst);
       else qload(znext, 0, q, dst);
     };
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
     // entry: the registers hold group 0 (fetched during the previous clip; its flush ended with a barrier)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      qstore(q, gq[q], false);
+      qstore(q, gq[q], XO && pre);
       gload(1, q, gq[q]);
     }
     const int lq = (L.q * CoP + 16 * ot + L.j) * 4;        // this wave's output tile of the folded weights
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
         // every wave has read rows 4s .. 4s+3 (a k-step ago); in the last group: its fourth quarter (stored a k-step ago) is visible
         if (g + 1 < NG || s == 0) __syncthreads();
         if (g + 1 < NG) {
-          qstore(s, gq[s], g + 1 >= CT && pre);
+          qstore(s, gq[s], (XO || g + 1 >= CT) && pre);
           gload(g + 2, s, gq[s]);                          // (beyond this clip: the next clip's first group)
         }
         // (a wave with one tile fewer multiplies its first tile twice instead of branching: that sum is never stored)
@@ -210,6 +214,19 @@ int launch_layer_apply_flat(const float* Z, const float* in, float* out, const f
   }
 #undef LAUNCH_FPF
   return check_launch("layer_apply_flat");
+}
+
+// out [B, 32, TV] = W . PReLU(in [B, 32, TV]) + bias with w [32 (k) x 32 (out)]: the commuted convolutions of a 32 -> 16 layer
+// (csrc/commute_layer.hip) on the K-ring GEMM above
+int launch_layer_apply_flat_x(const float* in, float* out, const float* w, const float* bias, const float* in_slope, int B, int Ci, int Jo,
+                              int TV_, hipStream_t st) {
+  if (TV_ != 300 || Ci != 32 || Jo != 32) return fail(COSKAD_ERR_SHAPE, "apply_flat_x: built for 300 positions, 32 -> 32 (%d, %d -> %d)", TV_, Ci, Jo);
+  constexpr int TVg = 300;
+  const size_t lds = (size_t)(16 * fpf::window_stride(TVg) + 32 * (TVg + 2)) * sizeof(float);
+  const int grid = B < 512 ? B : 512;
+  auto k = fpf::k_layer_apply_flat<TVg, 2, 2, true>;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, (const float*)nullptr, w, bias, in_slope, out, B);
+  return check_launch("layer_apply_flat_x");
 }
 
 }  // namespace coskad

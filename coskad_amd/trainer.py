@@ -91,7 +91,11 @@ class STSETrainStep:
         self.lr = float(lr)
         # an encoder with layers beyond the LDS tile kernels (the wide C = 2 -> 256 stack, dropout) runs as a _FlatStack: tile runs
         # through engine.chain_*, wide layers through their explicit forward / backward -- same flat buffers, same fused Adam
+        # (so does an encoder with a layer the commuted kernels take -- 32 -> 16 on the 25-joint layout -- unless the step is asked for
+        # something only the plain chain does: hipGraph capture, the side stream, SyncBN)
         self.wide = any(l.is_wide for l in model.encoder.model)
+        if not self.wide and not (use_graph or side_stream or sync_bn):
+            self.wide = any(_is_commute(l) for l in model.encoder.model)
         self.layers = [] if self.wide else [layer_tensors(l) for l in model.encoder.model]
         self.stack = _FlatStack(list(model.encoder.model), self.fp, "encoder.model.") if self.wide else None
         self.ws = engine.Workspace()
@@ -287,6 +291,18 @@ def _is_narrow(m) -> bool:
             and ops.narrow_conv_ok(m.in_channels, 2 * m.out_channels, m.time_dim * m.joints_dim))
 
 
+# Layers with fewer output than input channels (32 -> 16 on the 25-joint layout) by commutation as well, on their own kernels
+# (csrc/commute_layer.hip): convolutions first, mixing / BatchNorm statistics / both adjoints / dA, dT on 16 channels.
+COMMUTE = True
+
+
+def _is_commute(m) -> bool:
+    tb, rb = m.tcn[1], (m.residual[1] if not isinstance(m.residual, torch.nn.Identity) else None)
+    return (COMMUTE and not m.is_wide and rb is not None and ops.commute_ok(m.time_dim, m.joints_dim, m.in_channels, m.out_channels)
+            and all(b.momentum is not None and b.affine and b.track_running_stats for b in (tb, rb)) and tb.eps == rb.eps
+            and tb.momentum == rb.momentum)
+
+
 def _virtual_narrow_layer(mod, fp: "FlatParams", prefix: str):
     """The (2 C_out -> C_out) layer that remains behind the commuted convolutions: input [Y; R] = [Wt X; Wr X], `tcn` convolution =
     selector of the Y channels (+ the real bias), `residual` convolution = selector of the R channels (+ the real bias); mixing
@@ -336,15 +352,19 @@ class _FlatStack:
                 pre = f"{prefix}{first + i}."
                 self.segs.append(('narrow', modules[i], pre) + _virtual_narrow_layer(modules[i], fp, pre))
                 i += 1
+            elif _is_commute(modules[i]):
+                self.segs.append(('commute', modules[i], f"{prefix}{first + i}."))
+                i += 1
             else:
                 j = i
-                while j < n and not modules[j].is_wide and not _is_narrow(modules[j]):
+                while j < n and not modules[j].is_wide and not _is_narrow(modules[j]) and not _is_commute(modules[j]):
                     j += 1
                 self.segs.append(('tile', [layer_tensors(m) for m in modules[i:j]],
                                   [_layer_grad_views(fp, f"{prefix}{first + k}.") for k in range(i, j)]))
                 i = j
         self.fp = fp
-        self.last_slope_grad = fp.gviews[f"{prefix}{first + n - 1}.prelu.weight"] if self.segs[-1][0] in ('tile', 'narrow') else None
+        self.last_slope_grad = (fp.gviews[f"{prefix}{first + n - 1}.prelu.weight"]
+                                if self.segs[-1][0] in ('tile', 'narrow', 'commute') else None)
 
     def forward(self, x: Tensor, ws: engine.Workspace, in_slope: Optional[Tensor] = None):
         """x: the stack's input, activated (in_slope None) or a pre-activation whose PReLU weight is `in_slope`
@@ -364,6 +384,17 @@ class _FlatStack:
                 u, ctx = engine.chain_forward(YR, [virt], True, ws, want_ctx=True)
                 saved.append((ctx, h, slope, W4))
                 h, slope = u, virt.slope
+            elif seg[0] == 'commute':
+                mod = seg[1]
+                Co, Ci = mod.out_channels, mod.in_channels
+                tc, tb, rc, rb = mod.tcn[0], mod.tcn[1], mod.residual[0], mod.residual[1]
+                W4 = torch.cat([tc.weight.view(Co, Ci), rc.weight.view(Co, Ci)], 0)
+                mod.__dict__.get("_fold_cache", {}).clear()
+                u, sv = ops.commute_fwd(h, slope, W4, mod.gcn.A, mod.gcn.T, tb.weight, tb.bias, rb.weight, rb.bias, tc.bias, rc.bias,
+                                        tb.running_mean, tb.running_var, rb.running_mean, rb.running_var, tb.num_batches_tracked,
+                                        rb.num_batches_tracked, tb.momentum, tb.eps)
+                saved.append(sv)
+                h, slope = u, mod.prelu.weight
             else:
                 from .models.graph_layers.stsgcn import wide_forward
                 pre_u, pre_slope = (h, slope) if slope is not None else (None, None)
@@ -384,13 +415,39 @@ class _FlatStack:
         the producer of d_last formed them (engine.btlnk_backward); in_slope_grad: where the gradient of forward's `in_slope`
         goes (the returned gradient is then w.r.t. the PRE-activation input)."""
         d = d_last
+
+        def below_slope_grad(k):
+            """where the PReLU-weight gradient of segment k's INPUT goes: the segment below's last slope, or the caller's"""
+            if k == 0:
+                return in_slope_grad
+            below = self.segs[k - 1]
+            if below[0] == 'tile':
+                return below[2][-1]["slope"]
+            if below[0] == 'narrow':
+                return below[4]["slope"]
+            if below[0] == 'commute':
+                return self.fp.gviews[below[2] + "prelu.weight"]
+            return None
+
         for k in range(len(self.segs) - 1, -1, -1):
             seg, sv = self.segs[k], saved[k]
             first = k == 0
             if seg[0] == 'tile':
                 d = engine.chain_backward(sv, seg[1], d, ws, seg[2], need_dx=need_dx or not first,
                                           stats_in=top_stats if k == len(self.segs) - 1 else None,
-                                          in_slope_grad=in_slope_grad if first else None)
+                                          in_slope_grad=below_slope_grad(k) if (first or self.segs[k - 1][0] == 'commute') else None)
+            elif seg[0] == 'commute':
+                prefix, gv = seg[2], self.fp.gviews
+                into = {"A": gv[prefix + "gcn.A"], "T": gv[prefix + "gcn.T"], "Wt": gv[prefix + "tcn.0.weight"],
+                        "Wr": gv[prefix + "residual.0.weight"], "gt": gv[prefix + "tcn.1.weight"], "bet": gv[prefix + "tcn.1.bias"],
+                        "gr": gv[prefix + "residual.1.weight"], "ber": gv[prefix + "residual.1.bias"]}
+                if sv[1] is not None:
+                    into["in_slope"] = below_slope_grad(k)
+                    if into["in_slope"] is None:
+                        raise RuntimeError("commuted layer: nowhere to put the gradient of its input's PReLU weight")
+                d = ops.commute_bwd(sv, d.contiguous(), into)
+                if not (need_dx or not first):
+                    d = None
             elif seg[0] == 'narrow':
                 mod, prefix, virt, vg = seg[1], seg[2], seg[3], seg[4]
                 ctx, pre_u, pre_slope, W4 = sv
