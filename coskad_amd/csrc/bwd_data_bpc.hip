@@ -34,13 +34,19 @@ constexpr int window_stride(int tv) {
   return l;
 }
 
-// CT: 16-row groups of the input; OT: 16-channel tiles of the output (rows of dU)
-template <int V, int CT, int OT>
+// CT: 16-row groups of the input; OT: 16-channel tiles of the output (rows of dU); FP: the mixing-parameter gradients are formed
+// here as well (dZ never leaves the CU; no k_gcn_params_bpc launch):
+//     dA[t] += Yt_t^T dZ_t   (Yt = temporal mix of X, 16 rows at a time through the K window once the GEMM is done with it)
+//     dT[v] += X_v^T dYs_v   (dYs = spatial adjoint of dZ; X halves through the window again)
+// a wave owns its frames of dA and its joints of dT from the first clip to the last (76 accumulator registers) and writes its part of the
+// workgroup's partial row [dA | dT] (`gpart`, summed by k_reduce_gcn).
+template <int V, int CT, int OT, bool FP>
 __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict__ in, const float* __restrict__ Zg,
                                                         const float* __restrict__ dU, const float* __restrict__ Aw,
                                                         const float* __restrict__ Tw, const float* __restrict__ coef,
                                                         const float* __restrict__ in_slope, float* __restrict__ dIn,
-                                                        float* __restrict__ dZout, float* __restrict__ dap, int B) {
+                                                        float* __restrict__ dZout, float* __restrict__ dap, int B,
+                                                        float* __restrict__ gpart) {
   constexpr int T = 12, TVg = T * V, Ci = 16 * CT, Co = 16 * OT, CiP = Ci, NG = OT + 2 * CT;
   static_assert(TVg % 4 == 0, "rows are staged as float4");
   constexpr int KT0 = (Co + Ci) * CiP, DX0 = KT0 + CiP, KR0 = DX0 + (Co + Ci) * CiP;
@@ -55,7 +61,13 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
   float* r1 = lds + 16 * LDWg;       // 32-row image (stride LDg)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Lane L{lane & 15, lane >> 4};
+  // (lane geometry behind an optimisation barrier per phase: its address arithmetic is recomputed there, not held across the K loop)
+  auto geo = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return Lane{l & 15, l >> 4};
+  };
+  Lane L = geo();
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
   const BufRes cres = make_res(coef, (KR0 + CiP) * 4u);
@@ -67,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
   const int t0 = CT == 2 ? (wave >> 1) * MAXT : wave * MAXT;
   const int nt = NT - t0 < MAXT ? NT - t0 : MAXT;
   float4 gq[4][NQ];
+  constexpr bool CARRY = !(FP && CT == 2);
   auto qload = [&](const BufRes& res, int row0, int q, float4 (&dst)[NQ]) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -87,8 +100,44 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
     }
   };
   float da = 0.f;
+  // (FP) sums over all the workgroup's clips, and a 16-row half of the layer input as the threads own it
+  constexpr int H4 = 16 * R4, HL = (H4 + 255) / 256;
+  f32x4 accA[FP ? MAXF : 1][NTV][NTV], accT[FP ? MAXJ : 1];
+#pragma unroll
+  for (int a = 0; a < (FP ? MAXF : 1); ++a)
+#pragma unroll
+    for (int b = 0; b < NTV; ++b)
+#pragma unroll
+      for (int c = 0; c < NTV; ++c) accA[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < (FP ? MAXJ : 1); ++k) accT[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto hload = [&](int clip_, int h, float4 (&dst)[HL]) {
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const float4* g4 = reinterpret_cast<const float4*>(in + ((size_t)clip_ * Ci + 16 * h) * TVg);
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+      const int e = tl + 256 * i;
+      dst[i] = e < H4 ? g4[e] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto hstore = [&](const float4 (&src)[HL]) {           // X = PReLU(U_prev) half -> window rows at the IMAGE's stride (row-per-lane reads)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+      const int e = tl + 256 * i;
+      if (e < H4) {
+        const int row = e / R4, col = 4 * (e - row * R4);
+        float4 v = src[i];
+        if (pre) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
+        *reinterpret_cast<float2*>(r2 + row * LDg + col) = float2{v.x, v.y};
+        *reinterpret_cast<float2*>(r2 + row * LDg + col + 2) = float2{v.z, v.w};
+      }
+    }
+  };
   int clip = blockIdx.x;
-  {
+  if constexpr (CARRY) {
     const BufRes du0 = clip_res(dU, clip, Co);
 #pragma unroll
     for (int q = 0; q < 4; ++q) qload(du0, 0, q, gq[q]);
@@ -128,7 +177,12 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
         acc2[t] = f32x4{k2.x, k2.y, k2.z, k2.w};
       }
     }
-    // entry: the registers hold group 0 (fetched during the previous clip, whose row pass ended with a barrier)
+    // entry: the registers hold group 0 (fetched during the previous clip, whose row pass ended with a barrier; !CARRY: fetched here --
+    // 32 channels with the dA / dT sums have no registers to carry it through the mixing phases)
+    if constexpr (!CARRY) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) qload(dures, 0, q, gq[q]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       qstore(q, gq[q], false);
@@ -148,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
         if (g + 1 < NG || s == 0) __syncthreads();
         if (g + 1 < NG) {
           qstore(s, gq[s], g + 1 >= OT + CT && pre);
-          gload(g + 2, s, gq[s]);
+          if (CARRY || g + 2 < NG) gload(g + 2, s, gq[s]);
         }
         if (g < OT + CT) {
 #pragma unroll
@@ -169,23 +223,37 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
       // loop: held for the whole launch they cost the loop 63 registers it does not have at 32 channels)
     //   spatial adjoint   dY[t,v] = sum_w dZ[t,w] A[t][v][w]:   B[k = w][j = v]
     //   temporal adjoint  dX[t,v] = sum_q dY[q,v] T[v][t][q]:   B[k = q][j = t]
-    float sbv[MAXF][NTV][KV], tbv[MAXJ][3];
-  #pragma unroll
-    for (int tt = 0; tt < MAXF; ++tt) {
-      const int t = wave + 4 * tt;
-  #pragma unroll
-      for (int c = 0; c < NTV; ++c)
-  #pragma unroll
-        for (int s = 0; s < KV; ++s)
-          sbv[tt][c][s] = (16 * c + L.j < V && 4 * s + L.q < V) ? Aw[(t * V + 16 * c + L.j) * V + 4 * s + L.q] : 0.f;
-    }
-  #pragma unroll
-    for (int k = 0; k < MAXJ; ++k) {
-      const int v = wave + 4 * k;
-  #pragma unroll
-      for (int s = 0; s < 3; ++s) tbv[k][s] = (v < V && L.j < T) ? Tw[(v * T + L.j) * T + 4 * s + L.q] : 0.f;
-    }
+    // (the table pointers go through an optimisation barrier per clip: hoisted out of the clip loop the loads would hold their 63
+    //  registers through the K loop)
+    const float* Awc = Aw;
+    const float* Twc = Tw;
+    asm volatile("" : "+s"(Awc), "+s"(Twc));
+    L = geo();
+    float sbv[MAXF][NTV][KV];
+    auto load_sbv = [&]() {
+#pragma unroll
+      for (int tt = 0; tt < MAXF; ++tt) {
+        const int t = wave + 4 * tt;
+#pragma unroll
+        for (int c = 0; c < NTV; ++c)
+#pragma unroll
+          for (int s = 0; s < KV; ++s)
+            sbv[tt][c][s] = (16 * c + L.j < V && 4 * s + L.q < V) ? Awc[(t * V + 16 * c + L.j) * V + 4 * s + L.q] : 0.f;
+      }
+    };
+    float tbv[MAXJ][3];
+    auto load_tbv = [&]() {
+#pragma unroll
+      for (int k = 0; k < MAXJ; ++k) {
+        const int v = wave + 4 * k;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) tbv[k][s] = (v < V && L.j < T) ? Twc[(v * T + L.j) * T + 4 * s + L.q] : 0.f;
+      }
+    };
+    if constexpr (!FP) { load_sbv(); load_tbv(); }       // (FP: fetched where the dA / dT sums leave room for them)
     // ---- dZ -> image (the previous clip's row pass ended with a barrier) -> HBM for the dA / dT kernel ------------------------------
+    float4 xh[FP ? HL : 1];
+    if constexpr (FP) hload(clip, 0, xh);                // the first X half takes off
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       const int p = 16 * (t0 + t) + L.j;
@@ -194,8 +262,61 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
         dst[0] = acc1[t][0]; dst[LDg] = acc1[t][1]; dst[2 * LDg] = acc1[t][2]; dst[3 * LDg] = acc1[t][3];
       }
     }
-    __syncthreads();                                     // the image holds dZ
-    {
+    __syncthreads();                                     // the image holds dZ (and every wave is done with the K window)
+    if constexpr (FP) {
+      // ---- dA[t] += Yt_t^T dZ_t: X halves -> window, temporal mix there by joint, products by frame ------------------------------
+      //   temporal   Yt[q,v] = sum_t X[t,v] T[v][t][q]:   B[k = t][j = q]
+      float tf[MAXJ][3];
+#pragma unroll
+      for (int k = 0; k < MAXJ; ++k) {
+        const int v = wave + 4 * k;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) tf[k][s] = (v < V && L.j < T) ? Twc[(v * T + 4 * s + L.q) * T + L.j] : 0.f;
+      }
+#pragma unroll
+      for (int h = 0; h < CT; ++h) {
+        hstore(xh);
+        if (h + 1 < CT) hload(clip, h + 1, xh);
+        __syncthreads();                                 // the window holds X rows 16 h ..
+#pragma unroll
+        for (int k = 0; k < MAXJ; ++k) {
+          const int v = wave + 4 * k;
+          if (v < V) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) d = mfma(r2[L.j * LDg + (4 * s + L.q) * V + v], tf[k][s], d);
+            if (L.j < T) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) r2[(4 * L.q + r) * LDg + L.j * V + v] = d[r];
+            }
+          }
+        }
+        __syncthreads();                                 // the window holds Yt
+#pragma unroll
+        for (int tt = 0; tt < MAXF; ++tt) {
+          const int t = wave + 4 * tt;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int row = 4 * s + L.q;
+            float a[NTV], b[NTV];
+#pragma unroll
+            for (int c = 0; c < NTV; ++c) {
+              const bool ok = 16 * c + L.j < V;
+              a[c] = ok ? r2[row * LDg + t * V + 16 * c + L.j] : 0.f;
+              b[c] = ok ? r1[(16 * h + row) * LDg + t * V + 16 * c + L.j] : 0.f;
+            }
+#pragma unroll
+            for (int ta = 0; ta < NTV; ++ta)
+#pragma unroll
+              for (int tb2 = 0; tb2 < NTV; ++tb2) accA[tt][ta][tb2] = mfma(a[ta], b[tb2], accA[tt][ta][tb2]);
+          }
+        }
+        if (h + 1 < CT) __syncthreads();                 // Yt's readers are done: the next half over it
+      }
+      hload(clip, 0, xh);                                // dT's first X half takes off behind the spatial adjoint
+      load_sbv();
+    }
+    if constexpr (!FP) {
       float4* g4 = reinterpret_cast<float4*>(dZout + (size_t)clip * Ci * TVg);
 #pragma unroll
       for (int i = 0; i < XL; ++i) {
@@ -208,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
         }
       }
     }
-    __syncthreads();                                     // the rows have left: the image may be mixed in place
+    if constexpr (!FP) __syncthreads();                  // the rows have left: the image may be mixed in place
     // ---- dY = spatial adjoint of dZ, in place: frames t = wave, wave + 4, wave + 8 (a frame is touched by its owner only) -------
 #pragma unroll
     for (int tt = 0; tt < MAXF; ++tt) {
@@ -233,7 +354,31 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
           }
       }
     }
-    __syncthreads();                                     // the image holds dY
+    __syncthreads();                                     // the image holds dY (FP: and every wave has read Yt in the window)
+    if constexpr (FP) {
+      // ---- dT[v] += X_v^T dYs_v for this wave's joints: X halves through the window ---------------------------------------------
+#pragma unroll
+      for (int h = 0; h < CT; ++h) {
+        hstore(xh);
+        if (h + 1 < CT) hload(clip, h + 1, xh);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAXJ; ++k) {
+          const int v = wave + 4 * k;
+          if (v < V) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int row = 4 * s + L.q;
+              const float a = L.j < T ? r2[row * LDg + L.j * V + v] : 0.f;
+              const float b = L.j < T ? r1[(16 * h + row) * LDg + L.j * V + v] : 0.f;
+              accT[k] = mfma(a, b, accT[k]);
+            }
+          }
+        }
+        if (h + 1 < CT) __syncthreads();                 // the half's readers are done
+      }
+      load_tbv();
+    }
     // ---- temporal adjoint, in place: joints v = wave, wave + 4, .. ---------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < MAXJ; ++k) {
@@ -296,6 +441,35 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
     }
     __syncthreads();                                     // (the image and the window are rewritten next)
   }
+  if constexpr (FP) {
+    // every wave owns its frames of dA and its joints of dT: its part of the workgroup's partial row [dA | dT]
+    float* dstA = gpart + (size_t)blockIdx.x * (T * V * V + V * T * T);
+    float* dstT = dstA + T * V * V;
+#pragma unroll
+    for (int tt = 0; tt < MAXF; ++tt) {
+      const int t = wave + 4 * tt;
+#pragma unroll
+      for (int ta = 0; ta < NTV; ++ta)
+#pragma unroll
+        for (int tb2 = 0; tb2 < NTV; ++tb2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int v = 16 * ta + 4 * L.q + r, w = 16 * tb2 + L.j;
+            if (v < V && w < V) dstA[(t * V + v) * V + w] = accA[tt][ta][tb2][r];
+          }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXJ; ++k) {
+      const int v = wave + 4 * k;
+      if (v < V) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t1 = 4 * L.q + r, t2 = L.j;
+          if (t1 < T && t2 < T) dstT[(v * T + t1) * T + t2] = accT[k][r];
+        }
+      }
+    }
+  }
   if (dap) {
     __shared__ float sred[4];
     da = wave_sum(da);
@@ -312,18 +486,25 @@ bool bwd_data_bpc_ok(int T_, int V_, int Ci, int Co) {
 }
 
 // dZout, dIn: [B, Ci, T, V]; dap: >= *rows_out (<= 512) floats (NULL: no slope gradient)
+// gpart != NULL: dA / dT are formed here too, >= *rows_out rows of T V V + V T T floats (dZout is not written)
 int launch_bwd_data_bpc(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw, const float* coef,
                         const float* in_slope, float* dIn, float* dZout, float* dap, int B, int Ci, int Co, int T_, int V_,
-                        hipStream_t st, int* rows_out) {
-  if (!bwd_data_bpc_ok(T_, V_, Ci, Co) || !Zg || !dIn || !dZout)
+                        hipStream_t st, int* rows_out, float* gpart) {
+  if (!bwd_data_bpc_ok(T_, V_, Ci, Co) || !Zg || !dIn || !(dZout || gpart))
     return fail(COSKAD_ERR_SHAPE, "bwd_data_bpc: built for 12 x 25, 16 / 32 -> 16 / 32 / 64 channels, stored Z");
   constexpr int V = 25;
   const size_t lds = (size_t)(16 * bd::window_stride(12 * V) + 32 * (12 * V + 2)) * sizeof(float);
   const int grid = B < 512 ? B : 512;
   *rows_out = grid;
 #define LAUNCH_BD(CT, OT)                                                                                        \
-  hipLaunchKernelGGL((bd::k_bwd_data_bpc<V, CT, OT>), dim3(grid), dim3(256), lds, st, in, Zg, dU, Aw, Tw, coef, in_slope, dIn, \
-                     dZout, dap, B)
+  do {                                                                                                           \
+    if (gpart)                                                                                                   \
+      hipLaunchKernelGGL((bd::k_bwd_data_bpc<V, CT, OT, true>), dim3(grid), dim3(256), lds, st, in, Zg, dU, Aw, Tw, coef, in_slope, \
+                         dIn, dZout, dap, B, gpart);                                                             \
+    else                                                                                                         \
+      hipLaunchKernelGGL((bd::k_bwd_data_bpc<V, CT, OT, false>), dim3(grid), dim3(256), lds, st, in, Zg, dU, Aw, Tw, coef, in_slope, \
+                         dIn, dZout, dap, B, gpart);                                                             \
+  } while (0)
   if (Ci == 16 && Co == 16) LAUNCH_BD(1, 1);
   else if (Ci == 16 && Co == 32) LAUNCH_BD(1, 2);
   else if (Ci == 16 && Co == 64) LAUNCH_BD(1, 4);

@@ -19,8 +19,9 @@
 
 namespace coskad {
 
-int launch_layer_apply_flat_x(const float* in, float* out, const float* w, const float* bias, const float* in_slope, int B, int Ci, int Jo,
-                              int TV_, hipStream_t st);
+// fused_apply_flat.hip: [Y; R] = [Wt; Wr] PReLU(in), Zy = gcn(Y), per-workgroup row sums of Zy, Zy^2, R, R^2
+int launch_commute_apply_mix(const float* in, float* out, const float* wt, const float* wr, const float* in_slope, const float* Aw,
+                             const float* Tw, float* zy, float* mixpart, int B, int Ci, int Jo, int TV_, hipStream_t st, int* rows_out);
 
 namespace cm {
 
@@ -40,135 +41,6 @@ constexpr int window_stride(int tv) {
   int l = (tv + 3) / 4 * 4;
   while (l % 64 != 16 && l % 64 != 48) l += 4;
   return l;
-}
-
-// ---- forward 2: Zy = gcn(Y) in place, row sums of Zy and R ------------------------------------------------------------------------
-template <int V>
-__global__ __launch_bounds__(256, 3) void k_commute_mix(const float* __restrict__ YR, const float* __restrict__ Aw,
-                                                       const float* __restrict__ Tw, float* __restrict__ Zy,
-                                                       float* __restrict__ partials, int B) {
-  constexpr int TV = T * V, LD = TV + 2, R4 = TV / 4;
-  static_assert(TV % 4 == 0, "rows are staged as float4");
-  constexpr int N4 = 32 * R4, XL = (N4 + 255) / 256, Z4 = C * R4, ZL = (Z4 + 255) / 256;
-  constexpr int NTV = (V + 15) / 16, KV = (V + 3) / 4, MAXF = T / 4, MAXJ = (V + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) float img[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Lane L{lane & 15, lane >> 4};
-  float tbv[MAXJ][3], bbv[MAXF][NTV][KV];
-#pragma unroll
-  for (int k = 0; k < MAXJ; ++k) {
-    const int v = wave + 4 * k;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) tbv[k][s] = (v < V && L.j < T) ? Tw[(v * T + 4 * s + L.q) * T + L.j] : 0.f;
-  }
-#pragma unroll
-  for (int tt = 0; tt < MAXF; ++tt) {
-    const int t = wave + 4 * tt;
-#pragma unroll
-    for (int c = 0; c < NTV; ++c)
-#pragma unroll
-      for (int s = 0; s < KV; ++s)
-        bbv[tt][c][s] = (16 * c + L.j < V && 4 * s + L.q < V) ? Aw[(t * V + 4 * s + L.q) * V + 16 * c + L.j] : 0.f;
-  }
-  // this wave's rows wave, wave + 4, .. of Zy and of R: per-lane sums over all the workgroup's clips
-  float sz[4], sz2[4], sr[4], sr2[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { sz[k] = 0.f; sz2[k] = 0.f; sr[k] = 0.f; sr2[k] = 0.f; }
-  float4 px[XL];
-  auto xload = [&](int clip) {
-    const float4* g4 = reinterpret_cast<const float4*>(YR + (size_t)(clip < B ? clip : 0) * 32 * TV);
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-      const int e = tid + 256 * i;
-      px[i] = (e < N4 && clip < B) ? g4[e] : float4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  int clip = blockIdx.x;
-  xload(clip);
-  for (; clip < B; clip += gridDim.x) {
-    __syncthreads();                                     // the previous clip's readers of the image are done
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-      const int e = tid + 256 * i;
-      if (e < N4) {
-        const int row = e / R4, col = 4 * (e - row * R4);
-        *reinterpret_cast<float2*>(img + row * LD + col) = float2{px[i].x, px[i].y};
-        *reinterpret_cast<float2*>(img + row * LD + col + 2) = float2{px[i].z, px[i].w};
-      }
-    }
-    xload(clip + gridDim.x);
-    __syncthreads();                                     // the image holds [Y; R]
-    // ---- temporal mix of Y (rows 0 .. 15), in place: joints v = wave, wave + 4, .. ------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < MAXJ; ++k) {
-      const int v = wave + 4 * k;
-      if (v < V) {
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 3; ++s) d = mfma(img[L.j * LD + (4 * s + L.q) * V + v], tbv[k][s], d);
-        if (L.j < T) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) img[(4 * L.q + r) * LD + L.j * V + v] = d[r];
-        }
-      }
-    }
-    __syncthreads();
-    // ---- spatial mix, in place: frames t = wave, wave + 4, wave + 8 ---------------------------------------------------------------
-#pragma unroll
-    for (int tt = 0; tt < MAXF; ++tt) {
-      const int t = wave + 4 * tt;
-      float a[KV];
-#pragma unroll
-      for (int s = 0; s < KV; ++s) a[s] = 4 * s + L.q < V ? img[L.j * LD + t * V + 4 * s + L.q] : 0.f;
-      f32x4 d[NTV];
-#pragma unroll
-      for (int c = 0; c < NTV; ++c) {
-        d[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KV; ++s) d[c] = mfma(a[s], bbv[tt][c][s], d[c]);
-      }
-#pragma unroll
-      for (int c = 0; c < NTV; ++c)
-        if (16 * c + L.j < V) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) img[(4 * L.q + r) * LD + t * V + 16 * c + L.j] = d[c][r];
-        }
-    }
-    __syncthreads();                                     // rows 0 .. 15 hold Zy
-    {
-      float4* g4 = reinterpret_cast<float4*>(Zy + (size_t)clip * C * TV);
-#pragma unroll
-      for (int i = 0; i < ZL; ++i) {
-        const int e = tid + 256 * i;
-        if (e < Z4) {
-          const int row = e / R4, col = 4 * (e - row * R4);
-          const float2 g0 = *reinterpret_cast<const float2*>(img + row * LD + col);
-          const float2 g1 = *reinterpret_cast<const float2*>(img + row * LD + col + 2);
-          g4[e] = float4{g0.x, g0.y, g1.x, g1.y};
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float* pz = img + (wave + 4 * k) * LD;
-      const float* pr = pz + C * LD;
-      for (int p = lane; p < TV; p += 64) {
-        const float z = pz[p], r = pr[p];
-        sz[k] += z; sz2[k] = fmaf(z, z, sz2[k]);
-        sr[k] += r; sr2[k] = fmaf(r, r, sr2[k]);
-      }
-    }
-  }
-  float* dst = partials + (size_t)blockIdx.x * kMixCols;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float a = wave_sum(sz[k]), b = wave_sum(sz2[k]), c = wave_sum(sr[k]), d = wave_sum(sr2[k]);
-    if (lane == 0) {
-      const int row = wave + 4 * k;
-      dst[row] = a; dst[C + row] = b; dst[2 * C + row] = c; dst[3 * C + row] = d;
-    }
-  }
 }
 
 // sums the P partial rows of `cols` (<= 64) columns in fp64 (fixed order; common.h: 64 columns x 16 row slices, eight loads in flight)
@@ -304,7 +176,7 @@ __global__ __launch_bounds__(1024) void k_commute_bfold(const float* __restrict_
 template <int V>
 __global__ __launch_bounds__(256, 2) void k_commute_bwd(const float* __restrict__ Uprev, const float* __restrict__ YR,
                                                        const float* __restrict__ Zy, const float* __restrict__ dU,
-                                                       const float* __restrict__ coef, const float* __restrict__ W4,
+                                                       const float* __restrict__ coef, const float* __restrict__ Wt, const float* __restrict__ Wr,
                                                        const float* __restrict__ Aw, const float* __restrict__ Tw,
                                                        const float* __restrict__ in_slope, float* __restrict__ dIn,
                                                        float* __restrict__ gpart, float* __restrict__ wpart, int B, int skip) {
@@ -336,12 +208,12 @@ __global__ __launch_bounds__(256, 2) void k_commute_bwd(const float* __restrict_
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
   if (tid0 < kCoef) cbs[tid0] = coef[tid0];
-  // dX = W4^T D: this wave's 16 input channels (ot) x half of the position tiles; A[i = L.j][k = 4 s + L.q] = W4[k][16 ot + i]
+  // dX = [Wt; Wr]^T D: this wave's 16 input channels (ot) x half of the position tiles; A[i = L.j][k = 4 s + L.q] = [Wt; Wr][k][16 ot + i]
   const int ot = wave & 1, t0 = (wave >> 1) * MAXT;
   const int nt = NT - t0 < MAXT ? NT - t0 : MAXT;
   float wa[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) wa[s] = W4[(4 * s + L.q) * 32 + 16 * ot + L.j];
+  for (int s = 0; s < 8; ++s) wa[s] = (s < 4 ? Wt : Wr)[(4 * (s & 3) + L.q) * 32 + 16 * ot + L.j];
   f32x4 accA[MAXF][NTV][NTV], accT[MAXJ], accW[4];
 #pragma unroll
   for (int a = 0; a < MAXF; ++a)
@@ -691,11 +563,10 @@ __global__ __launch_bounds__(1024) void k_commute_reduce(const float* __restrict
 template <int V>
 struct Geo {
   static constexpr int TV = T * V;
-  static constexpr size_t mix_lds = (size_t)32 * (TV + 2) * sizeof(float);
   static constexpr size_t bwd_lds = (size_t)48 * (TV + 2) * sizeof(float);
 };
 
-inline int mix_rows(int B) { return B < 768 ? B : 768; }
+inline int mix_rows(int B) { return B < 512 ? B : 512; }
 inline int sum_rows(int B) { return B < 1024 ? B : 1024; }
 inline int bwd_rows(int B) { return B < 512 ? B : 512; }
 
@@ -714,26 +585,23 @@ size_t coskad_commute_ws_floats(int B, int T_, int V_) {
          cm::kCoef + 64;
 }
 
-/* Forward of a (32 -> 16) layer in training mode.  u_prev [B, 32, T, V] (in_slope NULL: already activated), w4t [32 in][32 out] =
- * [Wt; Wr]^T, zero32: 32 zeros (the GEMM's bias operand); YR [B, 32, TV], Zy [B, 16, TV], U [B, 16, TV] (pre-activation output),
- * stat [128] are written and kept for the backward.  Running statistics are updated as torch.nn.BatchNorm2d does (NULL: not
- * tracked); momentum must be a number (cumulative averaging is not built here). */
-int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const float* w4t, const float* zero32, const float* A,
-                           const float* Tm, const float* gamma_t, const float* beta_t, const float* gamma_r, const float* beta_r,
-                           const float* bias_t, const float* bias_r, float* rm_t, float* rv_t, float* rm_r, float* rv_r,
-                           long long* nbt_t, long long* nbt_r, float momentum, float eps, float* YR, float* Zy, float* U, float* stat,
-                           float* ws, size_t ws_floats, int B, int T_, int V_, hipStream_t stream) {
-  if (!u_prev || !w4t || !zero32 || !A || !Tm || !gamma_t || !beta_t || !gamma_r || !beta_r || !YR || !Zy || !U || !stat || !ws)
+/* Forward of a (32 -> 16) layer in training mode.  u_prev [B, 32, T, V] (in_slope NULL: already activated), wt / wr [16, 32] the two
+ * convolutions' weights; YR [B, 32, TV] = [Wt X; Wr X], Zy [B, 16, TV] = gcn(Wt X), U [B, 16, TV] (pre-activation output) and stat [128]
+ * are written and kept for the backward.  Running statistics are updated as torch.nn.BatchNorm2d does (NULL: not tracked); momentum
+ * must be a number (cumulative averaging is not built here). */
+int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm,
+                           const float* gamma_t, const float* beta_t, const float* gamma_r, const float* beta_r, const float* bias_t,
+                           const float* bias_r, float* rm_t, float* rv_t, float* rm_r, float* rv_r, long long* nbt_t, long long* nbt_r,
+                           float momentum, float eps, float* YR, float* Zy, float* U, float* stat, float* ws, size_t ws_floats, int B,
+                           int T_, int V_, hipStream_t stream) {
+  if (!u_prev || !wt || !wr || !A || !Tm || !gamma_t || !beta_t || !gamma_r || !beta_r || !YR || !Zy || !U || !stat || !ws)
     return fail(COSKAD_ERR_ARG, "commute_fwd: null pointer");
   if (B <= 0 || !coskad_commute_ok(T_, V_, 32, 16)) return fail(COSKAD_ERR_SHAPE, "commute_fwd: built for 12 x 25, 32 -> 16");
   if (ws_floats < coskad_commute_ws_floats(B, T_, V_)) return fail(COSKAD_ERR_WORKSPACE, "commute_fwd: scratch too small");
-  constexpr int V = 25;
-  const int TV = 12 * V;
-  int rc = launch_layer_apply_flat_x(u_prev, YR, w4t, zero32, in_slope, B, 32, 32, TV, stream);
+  const int TV = T_ * V_;
+  int rows = 0;
+  int rc = launch_commute_apply_mix(u_prev, YR, wt, wr, in_slope, A, Tm, Zy, ws, B, 32, 32, TV, stream, &rows);
   if (rc) return rc;
-  const int rows = cm::mix_rows(B);
-  hipLaunchKernelGGL((cm::k_commute_mix<V>), dim3(rows), dim3(256), cm::Geo<V>::mix_lds, stream, YR, A, Tm, Zy, ws, B);
-  if ((rc = check_launch("commute_mix"))) return rc;
   cm::FoldArgs fa{gamma_t, beta_t, gamma_r, beta_r, bias_t, bias_r, rm_t, rv_t, rm_r, rv_r, nbt_t, nbt_r, momentum, eps};
   hipLaunchKernelGGL(cm::k_commute_fold, dim3(1), dim3(1024), 0, stream, ws, rows, (double)B * TV, fa, stat);
   if ((rc = check_launch("commute_fold"))) return rc;
@@ -742,12 +610,12 @@ int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const flo
 }
 
 /* Backward: dU [B, 16, TV] -> d_in [B, 32, TV] (gradient of u_prev, PReLU mask applied), dA [T, V, V], dT [V, T, T], dWt / dWr [16, 32],
- * dgamma / dbeta [16] of both BatchNorms, dslope [1] (NULL with in_slope NULL): all OVERWRITTEN.  w4 [32][32] = [Wt; Wr] row-major. */
-int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const float* w4, const float* A, const float* Tm, const float* YR,
+ * dgamma / dbeta [16] of both BatchNorms, dslope [1] (NULL with in_slope NULL): all OVERWRITTEN. */
+int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm, const float* YR,
                            const float* Zy, const float* stat, const float* dU, float* d_in, float* dA, float* dT, float* dWt, float* dWr,
                            float* dgamma_t, float* dbeta_t, float* dgamma_r, float* dbeta_r, float* dslope, float* ws, size_t ws_floats,
                            int B, int T_, int V_, hipStream_t stream) {
-  if (!u_prev || !w4 || !A || !Tm || !YR || !Zy || !stat || !dU || !d_in || !dA || !dT || !dWt || !dWr || !dgamma_t || !dbeta_t ||
+  if (!u_prev || !wt || !wr || !A || !Tm || !YR || !Zy || !stat || !dU || !d_in || !dA || !dT || !dWt || !dWr || !dgamma_t || !dbeta_t ||
       !dgamma_r || !dbeta_r || !ws)
     return fail(COSKAD_ERR_ARG, "commute_bwd: null pointer");
   if (B <= 0 || !coskad_commute_ok(T_, V_, 32, 16)) return fail(COSKAD_ERR_SHAPE, "commute_bwd: built for 12 x 25, 32 -> 16");
@@ -768,7 +636,7 @@ int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const flo
   if ((rc = check_launch("commute_bfold"))) return rc;
   auto k = cm::k_commute_bwd<V>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cm::Geo<V>::bwd_lds);
-  hipLaunchKernelGGL(k, dim3(prow), dim3(256), cm::Geo<V>::bwd_lds, stream, u_prev, YR, Zy, dU, coef, w4, A, Tm, in_slope, d_in, gpart,
+  hipLaunchKernelGGL(k, dim3(prow), dim3(256), cm::Geo<V>::bwd_lds, stream, u_prev, YR, Zy, dU, coef, wt, wr, A, Tm, in_slope, d_in, gpart,
                      wpart, B, getenv("COSKAD_CM_SKIP") ? atoi(getenv("COSKAD_CM_SKIP")) : 0);
   if ((rc = check_launch("commute_bwd"))) return rc;
   const int nblk = ceil_div(nA + nT, cm::kRedCols) + ceil_div(1025, cm::kRedCols);

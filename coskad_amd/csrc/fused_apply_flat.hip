@@ -28,12 +28,17 @@ constexpr int window_stride(int tv) {
   return l;
 }
 
-// CT: 16-row groups of the input; OT: 16-channel output tiles; XO: the product runs over the layer input alone (out = W . PReLU(in) + b:
-// the commuted convolutions of csrc/commute_layer.hip; `Zg` unused, `wfold` [Ci x CoP])
+// CT: 16-row groups of the input; OT: 16-channel output tiles; XO: the commuted convolutions of csrc/commute_layer.hip -- the product
+// runs over the layer input alone, [Y; R] = [Wt; Wr] . PReLU(in) with the two [16 x Ci] weights as the parameters store them (`wfold` =
+// Wt, `Zg` = Wr, no bias), and the clip's rows, which the flush holds on chip anyway, are mixed before the workgroup moves on:
+// Zy = gcn(Y) in place (by joint, then by frame; a wave's operands of both mixes in 63 registers for the launch) -> `Zy`, and the
+// per-channel sums of Zy, Zy^2, R, R^2 over the workgroup's clips -> `mixpart` [grid][64] (both BatchNorms' batch statistics).
 template <int TVg, int CT, int OT, bool XO = false>
 __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __restrict__ in, const float* __restrict__ Zg,
                                                             const float* __restrict__ wfold, const float* __restrict__ bias,
-                                                            const float* __restrict__ in_slope, float* __restrict__ out, int B) {
+                                                            const float* __restrict__ in_slope, float* __restrict__ out, int B,
+                                                            const float* __restrict__ Aw, const float* __restrict__ Tw,
+                                                            float* __restrict__ Zy, float* __restrict__ mixpart) {
   static_assert(TVg % 4 == 0, "rows are staged as float4");
   constexpr int Ci = 16 * CT, Co = 16 * OT, CoP = Co, NG = XO ? CT : 2 * CT;
   constexpr int R4 = TVg / 4;                            // float4 per row
@@ -56,13 +61,14 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
   };
   const bool pre = in_slope != nullptr;
   const float a_in = pre ? in_slope[0] : 0.f;
-  const BufRes wres = make_res(wfold, NG * 16 * CoP * 4u);
-  const BufRes bres = make_res(bias, CoP * 4u);
+  const int ot = OT == 4 ? wave : (OT == 2 ? (wave & 1) : 0);
+  // (XO: this wave's output tile is rows of Wt (ot = 0) or of Wr (ot = 1), read transposed)
+  const BufRes wres = XO ? make_res(ot ? Zg : wfold, 16 * Ci * 4u) : make_res(wfold, NG * 16 * CoP * 4u);
+  const BufRes bres = make_res(XO ? wfold : bias, CoP * 4u);
   auto clip_res = [&](const float* base, int c, int rows) {
     const bool in_range = c < B;
     return make_res(base + (size_t)(in_range ? c : 0) * rows * TVg, in_range ? rows * TVg * 4u : 0u);
   };
-  const int ot = OT == 4 ? wave : (OT == 2 ? (wave & 1) : 0);
   const int t0 = OT == 4 ? 0 : (OT == 2 ? (wave >> 1) * MAXT : wave * MAXT);
   const int nt = NT - t0 < MAXT ? NT - t0 : MAXT;        // (> 0 for every wave at the shapes built)
   // K ring: one group in flight, a quarter = NQ float4 per thread
@@ -85,6 +91,30 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
     }
   };
 
+  // (XO) a wave's joints and frames are the same for every clip: its B operands of both mixes stay in registers
+  //   temporal  Y[q,v] = sum_t X[t,v] T[v][t][q]:   B[k = t][j = q];   spatial  Z[t,w] = sum_v Y[t,v] A[t][v][w]:   B[k = v][j = w]
+  constexpr int MV = TVg / 12;
+  float mixt[XO ? (MV + 3) / 4 : 1][3], mixa[XO ? 3 : 1][(MV + 15) / 16][(MV + 3) / 4], msum[4][4];
+  if constexpr (XO) {
+    const Lane L0 = geo();
+#pragma unroll
+    for (int k = 0; k < (MV + 3) / 4; ++k) {
+      const int v = wave + 4 * k;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) mixt[k][s] = (v < MV && L0.j < 12) ? Tw[(v * 12 + 4 * s + L0.q) * 12 + L0.j] : 0.f;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+      const int t = wave + 4 * tt;
+#pragma unroll
+      for (int c = 0; c < (MV + 15) / 16; ++c)
+#pragma unroll
+        for (int s = 0; s < (MV + 3) / 4; ++s)
+          mixa[tt][c][s] = (16 * c + L0.j < MV && 4 * s + L0.q < MV) ? Aw[(t * MV + 4 * s + L0.q) * MV + 16 * c + L0.j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { msum[k][0] = 0.f; msum[k][1] = 0.f; msum[k][2] = 0.f; msum[k][3] = 0.f; }
+  }
   int clip = blockIdx.x;
   {
     const BufRes z0 = clip_res(XO ? in : Zg, clip, Ci);
@@ -118,10 +148,11 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
       qstore(q, gq[q], XO && pre);
       gload(1, q, gq[q]);
     }
-    const int lq = (L.q * CoP + 16 * ot + L.j) * 4;        // this wave's output tile of the folded weights
+    const int lq = XO ? (L.j * Ci + L.q) * 4 : (L.q * CoP + 16 * ot + L.j) * 4;   // this wave's output tile of the folded weights
+    constexpr int WK = XO ? 1 : CoP;                       // floats between consecutive k of the weight operand
     float wc[2][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wc[0][s] = buf_load1(wres, lq, (4 * s) * CoP * 4);
+    for (int s = 0; s < 4; ++s) wc[0][s] = buf_load1(wres, lq, (4 * s) * WK * 4);
     __syncthreads();                                       // the window holds group 0
     float b[MAXT];
 #pragma unroll
@@ -130,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
     for (int g = 0; g < NG; ++g) {
       if (g + 1 < NG) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wc[(g + 1) & 1][s] = buf_load1(wres, lq, ((16 * (g + 1) + 4 * s) * CoP) * 4);
+        for (int s = 0; s < 4; ++s) wc[(g + 1) & 1][s] = buf_load1(wres, lq, ((16 * (g + 1) + 4 * s) * WK) * 4);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -151,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
       }
     }
     L = geo();
-    const float4 b4 = buf_load4(bres, L.q * 16, (16 * ot) * 4);
+    const float4 b4 = XO ? float4{0.f, 0.f, 0.f, 0.f} : buf_load4(bres, L.q * 16, (16 * ot) * 4);
     const f32x4 bq = {b4.x, b4.y, b4.z, b4.w};
     // ---- flush: 32 channels at a time through the image, full lines to HBM ---------------------------------------------------
     constexpr int NR = (Co + 31) / 32;
@@ -183,6 +214,81 @@ __global__ __launch_bounds__(256, 2) void k_layer_apply_flat(const float* __rest
       }
       __syncthreads();                                     // (the image / the window are rewritten next)
     }
+    if constexpr (XO) {
+      // ---- Zy = gcn(Y) on rows 0 .. 15 of the image, in place; row sums -----------------------------------------------------------
+      constexpr int V = TVg / 12, T = 12, MAXJ = (V + 3) / 4, MAXF = T / 4, NTV = (V + 15) / 16, KV = (V + 3) / 4;
+      L = geo();
+#pragma unroll
+      for (int k = 0; k < MAXJ; ++k) {
+        const int v = wave + 4 * k;
+        if (v < V) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 3; ++s) d = mfma(r1[L.j * LDg + (4 * s + L.q) * V + v], mixt[k][s], d);
+          if (L.j < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r1[(4 * L.q + r) * LDg + L.j * V + v] = d[r];
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int tt = 0; tt < MAXF; ++tt) {
+        const int t = wave + 4 * tt;
+        float a[KV];
+#pragma unroll
+        for (int s = 0; s < KV; ++s) a[s] = 4 * s + L.q < V ? r1[L.j * LDg + t * V + 4 * s + L.q] : 0.f;
+        f32x4 d[NTV];
+#pragma unroll
+        for (int c = 0; c < NTV; ++c) {
+          d[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KV; ++s) d[c] = mfma(a[s], mixa[tt][c][s], d[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NTV; ++c)
+          if (16 * c + L.j < V) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r1[(4 * L.q + r) * LDg + t * V + 16 * c + L.j] = d[c][r];
+          }
+      }
+      __syncthreads();                                     // rows 0 .. 15 hold Zy
+      {
+        const BufRes zres = clip_res(Zy, clip, 16);
+        constexpr int n4 = 16 * R4;
+#pragma unroll
+        for (int i = 0; i < (n4 + 255) / 256; ++i) {
+          const int e4 = tid + 256 * i;
+          const bool ok = e4 < n4;
+          const int row = e4 / R4, col = 4 * (e4 - row * R4);
+          const float* p = r1 + (ok ? row * LDg + col : TVg);
+          const float2 g0 = *reinterpret_cast<const float2*>(p), g1 = *reinterpret_cast<const float2*>(ok ? p + 2 : p);
+          buf_store4(zres, ok ? e4 * 16 : 0x7ffffff0, 0, float4{g0.x, g0.y, g1.x, g1.y});
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* pz = r1 + (wave + 4 * k) * LDg;
+        const float* pr = pz + 16 * LDg;
+        for (int p = lane; p < TVg; p += 64) {
+          const float z = pz[p], r = pr[p];
+          msum[k][0] += z; msum[k][1] = fmaf(z, z, msum[k][1]);
+          msum[k][2] += r; msum[k][3] = fmaf(r, r, msum[k][3]);
+        }
+      }
+      __syncthreads();                                     // (the image is rewritten next)
+    }
+  }
+  if constexpr (XO) {
+    float* dst = mixpart + (size_t)blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = wave_sum(msum[k][0]), b = wave_sum(msum[k][1]), c = wave_sum(msum[k][2]), d = wave_sum(msum[k][3]);
+      if (lane == 0) {
+        const int row = wave + 4 * k;
+        dst[row] = a; dst[16 + row] = b; dst[32 + row] = c; dst[48 + row] = d;
+      }
+    }
   }
 }
 
@@ -201,7 +307,8 @@ int launch_layer_apply_flat(const float* Z, const float* in, float* out, const f
 #define LAUNCH_FPF(CT, OT)                                                                                       \
   do {                                                                                                           \
     auto k = fpf::k_layer_apply_flat<TVg, CT, OT>;                                                               \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Z, wfold, bias, in_slope, out, B);                 \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, Z, wfold, bias, in_slope, out, B, (const float*)nullptr, \
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr);                                 \
   } while (0)
   {
     ProbeScope probe(KID_LAYER_APPLY, Ci, Co, st);
@@ -216,17 +323,18 @@ int launch_layer_apply_flat(const float* Z, const float* in, float* out, const f
   return check_launch("layer_apply_flat");
 }
 
-// out [B, 32, TV] = W . PReLU(in [B, 32, TV]) + bias with w [32 (k) x 32 (out)]: the commuted convolutions of a 32 -> 16 layer
-// (csrc/commute_layer.hip) on the K-ring GEMM above
-int launch_layer_apply_flat_x(const float* in, float* out, const float* w, const float* bias, const float* in_slope, int B, int Ci, int Jo,
-                              int TV_, hipStream_t st) {
-  if (TV_ != 300 || Ci != 32 || Jo != 32) return fail(COSKAD_ERR_SHAPE, "apply_flat_x: built for 300 positions, 32 -> 32 (%d, %d -> %d)", TV_, Ci, Jo);
+// [Y; R] = [Wt; Wr] . PReLU(in [B, 32, TV]) -> out [B, 32, TV]; Zy = gcn(Y) -> zy [B, 16, TV]; row sums -> mixpart [*rows_out][64]: the
+// forward of a commuted 32 -> 16 layer up to its BatchNorm statistics (csrc/commute_layer.hip) on the K-ring GEMM above
+int launch_commute_apply_mix(const float* in, float* out, const float* wt, const float* wr, const float* in_slope, const float* Aw,
+                             const float* Tw, float* zy, float* mixpart, int B, int Ci, int Jo, int TV_, hipStream_t st, int* rows_out) {
+  if (TV_ != 300 || Ci != 32 || Jo != 32) return fail(COSKAD_ERR_SHAPE, "commute_apply_mix: built for 300 positions, 32 -> 16 + 16 (%d, %d -> %d)", TV_, Ci, Jo);
   constexpr int TVg = 300;
   const size_t lds = (size_t)(16 * fpf::window_stride(TVg) + 32 * (TVg + 2)) * sizeof(float);
   const int grid = B < 512 ? B : 512;
+  *rows_out = grid;
   auto k = fpf::k_layer_apply_flat<TVg, 2, 2, true>;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, (const float*)nullptr, w, bias, in_slope, out, B);
-  return check_launch("layer_apply_flat_x");
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, wr, wt, (const float*)nullptr, in_slope, out, B, Aw, Tw, zy, mixpart);
+  return check_launch("commute_apply_mix");
 }
 
 }  // namespace coskad

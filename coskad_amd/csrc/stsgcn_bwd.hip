@@ -1258,7 +1258,7 @@ int launch_bwd_stats_bpc(const float* in, const float* Zg, const float* dU, cons
 bool bwd_data_bpc_ok(int T_, int V_, int Ci, int Co);
 int launch_bwd_data_bpc(const float* in, const float* Zg, const float* dU, const float* Aw, const float* Tw, const float* coef,
                         const float* in_slope, float* dIn, float* dZout, float* dap, int B, int Ci, int Co, int T_, int V_,
-                        hipStream_t st, int* rows_out);
+                        hipStream_t st, int* rows_out, float* gpart);
 // gcn_params_bpc.hip
 bool gcn_params_bpc_ok(int T_, int V_);
 int launch_gcn_params_bpc(const float* in, const float* in_slope, const float* dz, const float* Aw, const float* Tw, float* partials,
@@ -1548,10 +1548,23 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   const float* dap_sum = nullptr;   // block partials of the producer's slope gradient (summed by stage 4's reduce)
   if (Zg && dIn && !dz_ext && bwd_data_bpc_ok(T, V, Ci, Co)) {
     // the 25-joint layout, stored Z: one clip per four-wave workgroup (bwd_data_bpc.hip)
+    // 16 input channels: dA / dT in the same kernel (dZ never leaves the CU: 226 -> 207 us at 16 -> 32, B = 4096).  At 32 channels the
+    // 76 accumulator registers of the sums do not fit beside the two K-pass accumulator sets (116 B of scratch per lane, the next
+    // clip's first group no longer carried: 480 us against 325 + 146 for the two kernels), so that shape keeps the dZ round trip.
+    // COSKAD_V25_SPLIT=1 / =0 force the two-kernel / the one-kernel form (A/B)
+    static const int force = [] { const char* e = getenv("COSKAD_V25_SPLIT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool split = force >= 0 ? force == 1 : Ci != 16;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
     {
       ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
-      if ((rc = launch_bwd_data_bpc(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.dz, dap, B, Ci, Co, T, V, st, &grid_d))) return rc;
+      if ((rc = launch_bwd_data_bpc(in, Zg, dU, Aw, Tw, w.coef, in_slope, dIn, w.dz, dap, B, Ci, Co, T, V, st, &grid_d,
+                                    split ? nullptr : w.partials)))
+        return rc;
+    }
+    if (!split) {
+      hipLaunchKernelGGL(k_reduce_gcn, dim3(ceil_div(T * V * V + V * T * T, kGcnCols) + (dap ? 1 : 0)), dim3(1024), 0, st, w.partials, grid_d,
+                         T * V * V, V * T * T, dA, dT, dap, grid_d, dslope_in, accumulate);
+      return check_launch("bwd_gcn_reduce");
     }
     dap_sum = dap;
   } else {

@@ -990,39 +990,41 @@ def _commute_scratch(B: int, T: int, V: int, dev) -> Tensor:
     return ws
 
 
-def commute_fwd(U_prev: Tensor, in_slope: Optional[Tensor], W4: Tensor, A: Tensor, Tm: Tensor, gamma_t: Tensor, beta_t: Tensor,
+def commute_fwd(U_prev: Tensor, in_slope: Optional[Tensor], Wt: Tensor, Wr: Tensor, A: Tensor, Tm: Tensor, gamma_t: Tensor, beta_t: Tensor,
                 gamma_r: Tensor, beta_r: Tensor, bias_t: Optional[Tensor], bias_r: Optional[Tensor], rm_t: Optional[Tensor],
                 rv_t: Optional[Tensor], rm_r: Optional[Tensor], rv_r: Optional[Tensor], nbt_t: Optional[Tensor],
                 nbt_r: Optional[Tensor], momentum: float, eps: float):
     """Training-mode forward of a 32 -> 16 ST_GCNN layer by commutation (csrc/commute_layer.hip; reference
-    models/graph_layers/stsgcn.py:94-116): U_prev [B, 32, T, V] (pre-activation when in_slope is given), W4 [32, 32] = [Wt; Wr]
-    -> (U [B, 16, T, V] pre-activation output, saved)."""
+    models/graph_layers/stsgcn.py:94-116): U_prev [B, 32, T, V] (pre-activation when in_slope is given), Wt / Wr [16, 32(, 1, 1)] the
+    two convolutions' weights -> (U [B, 16, T, V] pre-activation output, saved)."""
     B, Ci, T, V = U_prev.shape
-    _chk(U_prev, "U_prev"); _chk(W4, "W4", (32, 32)); _chk(in_slope, "in_slope", (1,), optional=True)
+    _chk(U_prev, "U_prev"); _chk(in_slope, "in_slope", (1,), optional=True)
+    for n, t in (("Wt", Wt), ("Wr", Wr)):
+        _cuda_f32(t, n)
+        if t.numel() != 512 or not t.is_contiguous():
+            raise ValueError(f"{n}: expected a contiguous [16, 32] weight")
     _chk(A, "A", (T, V, V)); _chk(Tm, "T", (V, T, T))
     for n, t in (("gamma_t", gamma_t), ("beta_t", beta_t), ("gamma_r", gamma_r), ("beta_r", beta_r)):
         _chk(t, n, (16,))
     for n, t in (("bias_t", bias_t), ("bias_r", bias_r), ("rm_t", rm_t), ("rv_t", rv_t), ("rm_r", rm_r), ("rv_r", rv_r)):
         _chk(t, n, (16,), optional=True)
     dev = U_prev.device
-    w4t = W4.t().contiguous()
-    zero = torch.zeros(32, device=dev, dtype=torch.float32)
     YR = torch.empty(B, 32, T, V, device=dev, dtype=torch.float32)
     Zy = torch.empty(B, 16, T, V, device=dev, dtype=torch.float32)
     U = torch.empty(B, 16, T, V, device=dev, dtype=torch.float32)
     stat = torch.empty(128, device=dev, dtype=torch.float32)
     ws = _commute_scratch(B, T, V, dev)
-    call("coskad_commute_fwd_f32", ptr(U_prev), ptr(in_slope), ptr(w4t), ptr(zero), ptr(A), ptr(Tm), ptr(gamma_t), ptr(beta_t),
+    call("coskad_commute_fwd_f32", ptr(U_prev), ptr(in_slope), ptr(Wt), ptr(Wr), ptr(A), ptr(Tm), ptr(gamma_t), ptr(beta_t),
          ptr(gamma_r), ptr(beta_r), ptr(bias_t), ptr(bias_r), ptr(rm_t), ptr(rv_t), ptr(rm_r), ptr(rv_r), ptr(nbt_t), ptr(nbt_r),
          ctypes.c_float(momentum), ctypes.c_float(eps), ptr(YR), ptr(Zy), ptr(U), ptr(stat), ptr(ws), ctypes.c_size_t(ws.numel()),
          i32(B), i32(T), i32(V), _stream())
-    return U, (U_prev, in_slope, W4, A, Tm, YR, Zy, stat)
+    return U, (U_prev, in_slope, Wt, Wr, A, Tm, YR, Zy, stat)
 
 
 def commute_bwd(saved, dU: Tensor, into: dict):
     """-> gradient of U_prev [B, 32, T, V] (PReLU mask applied).  `into`: destinations (all overwritten) 'A' [T, V, V], 'T' [V, T, T],
     'Wt' / 'Wr' [16, 32(, 1, 1)], 'gt' 'bet' 'gr' 'ber' [16], 'in_slope' [1] (the producer's PReLU weight gradient; with in_slope)."""
-    U_prev, in_slope, W4, A, Tm, YR, Zy, stat = saved
+    U_prev, in_slope, Wt, Wr, A, Tm, YR, Zy, stat = saved
     B, Ci, T, V = U_prev.shape
     _chk(dU, "dU", (B, 16, T, V))
     for n, shp in (("A", (T, V, V)), ("T", (V, T, T)), ("gt", (16,)), ("bet", (16,)), ("gr", (16,)), ("ber", (16,))):
@@ -1036,7 +1038,7 @@ def commute_bwd(saved, dU: Tensor, into: dict):
         _chk(dsl, "into.in_slope", (1,))
     d_in = torch.empty_like(U_prev)
     ws = _commute_scratch(B, T, V, U_prev.device)
-    call("coskad_commute_bwd_f32", ptr(U_prev), ptr(in_slope), ptr(W4), ptr(A), ptr(Tm), ptr(YR), ptr(Zy), ptr(stat), ptr(dU), ptr(d_in),
+    call("coskad_commute_bwd_f32", ptr(U_prev), ptr(in_slope), ptr(Wt), ptr(Wr), ptr(A), ptr(Tm), ptr(YR), ptr(Zy), ptr(stat), ptr(dU), ptr(d_in),
          ptr(into["A"]), ptr(into["T"]), ptr(into["Wt"]), ptr(into["Wr"]), ptr(into["gt"]), ptr(into["bet"]), ptr(into["gr"]),
          ptr(into["ber"]), ptr(dsl), ptr(ws), ctypes.c_size_t(ws.numel()), i32(B), i32(T), i32(V), _stream())
     return d_in

@@ -388,9 +388,8 @@ class _FlatStack:
                 mod = seg[1]
                 Co, Ci = mod.out_channels, mod.in_channels
                 tc, tb, rc, rb = mod.tcn[0], mod.tcn[1], mod.residual[0], mod.residual[1]
-                W4 = torch.cat([tc.weight.view(Co, Ci), rc.weight.view(Co, Ci)], 0)
                 mod.__dict__.get("_fold_cache", {}).clear()
-                u, sv = ops.commute_fwd(h, slope, W4, mod.gcn.A, mod.gcn.T, tb.weight, tb.bias, rb.weight, rb.bias, tc.bias, rc.bias,
+                u, sv = ops.commute_fwd(h, slope, tc.weight, rc.weight, mod.gcn.A, mod.gcn.T, tb.weight, tb.bias, rb.weight, rb.bias, tc.bias, rc.bias,
                                         tb.running_mean, tb.running_var, rb.running_mean, rb.running_var, tb.num_batches_tracked,
                                         rb.num_batches_tracked, tb.momentum, tb.eps)
                 saved.append(sv)

@@ -436,6 +436,28 @@ int coskad_narrow_conv_fwd_f32(const float* U, const float* in_slope, const floa
 int coskad_narrow_conv_bwd_f32(const float* U, const float* in_slope, const float* W, const float* dOut, float* dU, float* partials,
                                size_t partials_floats, int B, int Ci, int J, int TV, hipStream_t stream);
 
+/* A (32 -> 16) ST_GCNN layer in training mode by the same commutation, on its own kernels (csrc/commute_layer.hip; replaces
+ * models/graph_layers/stsgcn.py:94-116 and its autograd for such a layer on the 12 x 25 layout): Y = Wt X, R = Wr X first (X = PReLU(u_prev)),
+ * Zy = gcn(Y); both BatchNorms become per-channel affine maps of Zy and R (batch statistics = row sums); the backward is one kernel per clip
+ * behind two row-sum reductions.
+ *   ok        : 1 when (n_frames, n_joints, C_in, C_out) is built (12, 25, 32, 16)
+ *   ws_floats : floats of the scratch both entries need
+ *   fwd       : writes YR [B, 32, TV] = [Y; R], Zy [B, 16, TV], U [B, 16, TV] (the layer's pre-activation output), stat [128]; updates the
+ *               running statistics / num_batches_tracked of both BatchNorms as torch does (NULL: not tracked; momentum a number)
+ *   bwd       : dU [B, 16, TV] -> d_in [B, 32, TV] (PReLU mask of u_prev applied), dA [T, V, V], dT [V, T, T], dWt / dWr [16, 32],
+ *               dgamma / dbeta [16] of both BatchNorms, dslope [1] (the producer's PReLU weight; NULL iff in_slope NULL): all overwritten */
+int coskad_commute_ok(int T, int V, int Ci, int Co);
+size_t coskad_commute_ws_floats(int B, int T, int V);
+int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm,
+                           const float* gamma_t, const float* beta_t, const float* gamma_r, const float* beta_r, const float* bias_t,
+                           const float* bias_r, float* rm_t, float* rv_t, float* rm_r, float* rv_r, long long* nbt_t, long long* nbt_r,
+                           float momentum, float eps, float* YR, float* Zy, float* U, float* stat, float* ws, size_t ws_floats, int B,
+                           int T, int V, hipStream_t stream);
+int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm,
+                           const float* YR, const float* Zy, const float* stat, const float* dU, float* d_in, float* dA, float* dT,
+                           float* dWt, float* dWr, float* dgamma_t, float* dbeta_t, float* dgamma_r, float* dbeta_r, float* dslope,
+                           float* ws, size_t ws_floats, int B, int T, int V, hipStream_t stream);
+
 /* The spherical VAE's latent head between the raw outputs of fc_mean / fc_var and the decoder's input (models/sts/vae.py:79-91,
  * 104-118; loss terms of models/spherical_vae.py:86-94; PowerSpherical of the un-vendored `power_spherical` package, restated in
  * coskad_amd/models/sts/vae.py).  Rows are clips; mean_raw [B, L] and var_raw [B] are addressed with row strides ld_* (floats), so both

@@ -48,8 +48,7 @@ def test_commuted_layer_matches_the_layer_formula(B, with_slope):
     rm_r, rv_r = torch.zeros(16, device=dev), torch.ones(16, device=dev)
     nbt_t = torch.zeros((), dtype=torch.int64, device=dev)
     nbt_r = torch.zeros((), dtype=torch.int64, device=dev)
-    W4 = torch.cat([p["Wt"], p["Wr"]], 0).contiguous()
-    U, saved = ops.commute_fwd(U_prev, slope, W4, p["A"], p["Tm"], p["gt"], p["bet"], p["gr"], p["ber"], p["bt"], p["br"], rm_t, rv_t,
+    U, saved = ops.commute_fwd(U_prev, slope, p["Wt"], p["Wr"], p["A"], p["Tm"], p["gt"], p["bet"], p["gr"], p["ber"], p["bt"], p["br"], rm_t, rv_t,
                                rm_r, rv_r, nbt_t, nbt_r, mom, eps)
     into = {"A": torch.empty_like(p["A"]), "T": torch.empty_like(p["Tm"]), "Wt": torch.empty(16, 32, device=dev),
             "Wr": torch.empty(16, 32, device=dev), "gt": torch.empty(16, device=dev), "bet": torch.empty(16, device=dev),

@@ -11,7 +11,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g, device=dev)
 U_prev, dU = r(B, 32, T, V), r(B, 16, T, V)
 slope = torch.tensor([0.25], device=dev)
-W4, A, Tm = r(32, 32) * 0.2, r(T, V, V) * 0.3, r(V, T, T) * 0.3
+Wt, Wr, A, Tm = r(16, 32) * 0.2, r(16, 32) * 0.2, r(T, V, V) * 0.3, r(V, T, T) * 0.3
 gt, bet, gr, ber, bt, br = (r(16) for _ in range(6))
 rm, rv = torch.zeros(16, device=dev), torch.ones(16, device=dev)
 nbt = torch.zeros((), dtype=torch.int64, device=dev)
@@ -21,7 +21,7 @@ into = {"A": torch.empty_like(A), "T": torch.empty_like(Tm), "Wt": torch.empty(1
 
 
 def fwd():
-    return ops.commute_fwd(U_prev, slope, W4, A, Tm, gt, bet, gr, ber, bt, br, rm, rv, rm.clone(), rv.clone(), nbt, nbt.clone(), 0.1, 1e-5)
+    return ops.commute_fwd(U_prev, slope, Wt, Wr, A, Tm, gt, bet, gr, ber, bt, br, rm, rv, rm.clone(), rv.clone(), nbt, nbt.clone(), 0.1, 1e-5)
 
 
 def timeit(f, n=20):
