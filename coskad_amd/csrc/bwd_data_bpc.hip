@@ -102,7 +102,14 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
   float da = 0.f;
   // (FP) sums over all the workgroup's clips, and a 16-row half of the layer input as the threads own it
   constexpr int H4 = 16 * R4, HL = (H4 + 255) / 256;
-  f32x4 accA[FP ? MAXF : 1][NTV][NTV], accT[FP ? MAXJ : 1];
+  // (32 input channels: the dT sums live in LDS behind the image -- 14.4 KB, two workgroups still fit a CU -- the 28 registers they
+  //  took were the ones that spilled)
+  constexpr bool TL = FP && CT == 2;
+  float* dts = r1 + 32 * LDg;
+  if constexpr (TL) {
+    for (int e = tid; e < V * T * T; e += 256) dts[e] = 0.f;
+  }
+  f32x4 accA[FP ? MAXF : 1][NTV][NTV], accT[FP && !TL ? MAXJ : 1];
 #pragma unroll
   for (int a = 0; a < (FP ? MAXF : 1); ++a)
 #pragma unroll
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
 #pragma unroll
       for (int c = 0; c < NTV; ++c) accA[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < (FP ? MAXJ : 1); ++k) accT[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < (FP && !TL ? MAXJ : 1); ++k) accT[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto hload = [&](int clip_, int h, float4 (&dst)[HL]) {
     int tl = tid;
     asm volatile("" : "+v"(tl));
@@ -366,12 +373,20 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
         for (int k = 0; k < MAXJ; ++k) {
           const int v = wave + 4 * k;
           if (v < V) {
+            f32x4 acc = TL ? f32x4{0.f, 0.f, 0.f, 0.f} : accT[TL ? 0 : k];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
               const int row = 4 * s + L.q;
               const float a = L.j < T ? r2[row * LDg + L.j * V + v] : 0.f;
               const float b = L.j < T ? r1[(16 * h + row) * LDg + L.j * V + v] : 0.f;
-              accT[k] = mfma(a, b, accT[k]);
+              acc = mfma(a, b, acc);
+            }
+            if constexpr (TL) {                          // (this wave's joint: nobody else touches its 144 sums)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (4 * L.q + r < T && L.j < T) dts[(v * T + 4 * L.q + r) * T + L.j] += acc[r];
+            } else {
+              accT[k] = acc;
             }
           }
         }
@@ -458,14 +473,19 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
             if (v < V && w < V) dstA[(t * V + v) * V + w] = accA[tt][ta][tb2][r];
           }
     }
+    if constexpr (TL) {
+      __syncthreads();
+      for (int e = tid; e < V * T * T; e += 256) dstT[e] = dts[e];
+    } else {
 #pragma unroll
-    for (int k = 0; k < MAXJ; ++k) {
-      const int v = wave + 4 * k;
-      if (v < V) {
+      for (int k = 0; k < MAXJ; ++k) {
+        const int v = wave + 4 * k;
+        if (v < V) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int t1 = 4 * L.q + r, t2 = L.j;
-          if (t1 < T && t2 < T) dstT[(v * T + t1) * T + t2] = accT[k][r];
+          for (int r = 0; r < 4; ++r) {
+            const int t1 = 4 * L.q + r, t2 = L.j;
+            if (t1 < T && t2 < T) dstT[(v * T + t1) * T + t2] = accT[TL ? 0 : k][r];
+          }
         }
       }
     }
@@ -493,11 +513,13 @@ int launch_bwd_data_bpc(const float* in, const float* Zg, const float* dU, const
   if (!bwd_data_bpc_ok(T_, V_, Ci, Co) || !Zg || !dIn || !(dZout || gpart))
     return fail(COSKAD_ERR_SHAPE, "bwd_data_bpc: built for 12 x 25, 16 / 32 -> 16 / 32 / 64 channels, stored Z");
   constexpr int V = 25;
-  const size_t lds = (size_t)(16 * bd::window_stride(12 * V) + 32 * (12 * V + 2)) * sizeof(float);
+  const size_t lds = (size_t)(16 * bd::window_stride(12 * V) + 32 * (12 * V + 2) + (gpart && Ci == 32 ? V * 12 * 12 : 0)) * sizeof(float);
   const int grid = B < 512 ? B : 512;
   *rows_out = grid;
 #define LAUNCH_BD(CT, OT)                                                                                        \
   do {                                                                                                           \
+    if (gpart && lds > 64 * 1024)                                                                                \
+      (void)hipFuncSetAttribute((const void*)bd::k_bwd_data_bpc<V, CT, OT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (gpart)                                                                                                   \
       hipLaunchKernelGGL((bd::k_bwd_data_bpc<V, CT, OT, true>), dim3(grid), dim3(256), lds, st, in, Zg, dU, Aw, Tw, coef, in_slope, \
                          dIn, dZout, dap, B, gpart);                                                             \

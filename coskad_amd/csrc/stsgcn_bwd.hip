@@ -1548,12 +1548,11 @@ static int launch_layer_bwd(const float* in, const float* dU, const float* Aw, c
   const float* dap_sum = nullptr;   // block partials of the producer's slope gradient (summed by stage 4's reduce)
   if (Zg && dIn && !dz_ext && bwd_data_bpc_ok(T, V, Ci, Co)) {
     // the 25-joint layout, stored Z: one clip per four-wave workgroup (bwd_data_bpc.hip)
-    // 16 input channels: dA / dT in the same kernel (dZ never leaves the CU: 226 -> 207 us at 16 -> 32, B = 4096).  At 32 channels the
-    // 76 accumulator registers of the sums do not fit beside the two K-pass accumulator sets (116 B of scratch per lane, the next
-    // clip's first group no longer carried: 480 us against 325 + 146 for the two kernels), so that shape keeps the dZ round trip.
-    // COSKAD_V25_SPLIT=1 / =0 force the two-kernel / the one-kernel form (A/B)
+    // dA / dT in the same kernel (dZ never leaves the CU): 16 -> 32 226 -> 207 us, 32 -> 64 471 -> 457 us at B = 4096 (32 channels: the dT
+    // sums in LDS, the next clip's first group no longer carried -- with all 76 sum registers beside the two K-pass accumulator sets the
+    // kernel spilled 116 B per lane and ran 480 us).  COSKAD_V25_SPLIT=1: the two-kernel form with the dZ round trip (A/B)
     static const int force = [] { const char* e = getenv("COSKAD_V25_SPLIT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    const bool split = force >= 0 ? force == 1 : Ci != 16;
+    const bool split = force == 1;
     float* dap = (dslope_in && in_slope) ? w.dap : nullptr;
     {
       ProbeScope probe(KID_BWD_DATA, Ci, Co, st);
