@@ -259,6 +259,11 @@ int launch_layer_apply_m(const float* in, float* out, const float* Aw, const flo
                          const float* bias, const float* in_slope, const float* out_slope, int B, int Ci,
                          int Co, hipStream_t st, const float* Zg);  // stsgcn_fwd_mfma.hip
 
+// eval_layer_bpc.hip: the 25-joint layout, 16 / 32 input channels, one clip per four-wave workgroup
+bool eval_layer_bpc_ok(int T_, int V_, int Ci, int Co);
+int launch_eval_layer_bpc(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold, const float* bias,
+                          const float* in_slope, const float* out_slope, int B, int Ci, int Co, int T_, int V_, hipStream_t st);
+
 static int use_mfma() {
 #ifdef COSKAD_ABLATE   // A/B builds only: the product library always takes the MFMA kernel when the tile fits LDS
   static int v = -1;
@@ -278,6 +283,10 @@ static int launch_layer_apply(const float* in, float* out, const float* Aw, cons
                               const float* out_slope, int B, int Ci, int Co, hipStream_t st) {
   constexpr int kBlock = Geo<T, V>::Block;   // threads per block of this geometry
   constexpr int LD = Geo<T, V>::LD;
+  // COSKAD_EVAL_TILE=1: the round-1 LDS-table kernel at these shapes too (A/B)
+  static const bool tile_only = [] { const char* e = getenv("COSKAD_EVAL_TILE"); return e && e[0] == '1'; }();
+  if (!tile_only && eval_layer_bpc_ok(T, V, Ci, Co))
+    return launch_eval_layer_bpc(in, out, Aw, Tw, wfold, bias, in_slope, out_slope, B, Ci, Co, T, V, st);
   if (use_mfma()) {
     const int rc = launch_layer_apply_m<T, V>(in, out, Aw, Tw, wfold, bias, in_slope, out_slope, B, Ci, Co, st, nullptr);
     if (rc <= 0) return rc;   // 1 = does not fit in LDS: VALU kernel below
