@@ -1,5 +1,5 @@
 // One ST_GCNN layer with BatchNorm folded (eval mode, or any caller that hands over folded weights; reference
-// models/graph_layers/stsgcn.py:56-80 the mixing, 94-116 the layer) on the 25-joint layout, ONE CLIP PER WORKGROUP OF FOUR WAVES, nothing
+// models/graph_layers/stsgcn.py:56-80 the mixing, 94-116 the layer), 17 or 25 joints, ONE CLIP PER WORKGROUP OF FOUR WAVES, nothing
 // but the layer's input and output in HBM:
 //     U = Wz . gcn(X) + Wx . X + b          X = PReLU(in) (in_slope), optional PReLU on the way out (out_slope)
 // k_layer_apply_m (stsgcn_fwd_mfma.hip, round 1) keeps the clip image, both mixing tables (44 KB at 25 joints) and the folded weights
@@ -218,13 +218,12 @@ __global__ __launch_bounds__(256, (OT == 4 || (CT == 2 && OT == 2) ? 2 : 3)) voi
 }  // namespace ev
 
 bool eval_layer_bpc_ok(int T_, int V_, int Ci, int Co) {
-  return T_ == 12 && V_ == 25 && (Ci == 16 || Ci == 32) && (Co == 16 || Co == 32 || Co == 64);
+  return T_ == 12 && (V_ == 25 || V_ == 17) && (Ci == 16 || Ci == 32) && (Co == 16 || Co == 32 || Co == 64);
 }
 
-int launch_eval_layer_bpc(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold, const float* bias,
-                          const float* in_slope, const float* out_slope, int B, int Ci, int Co, int T_, int V_, hipStream_t st) {
-  if (!eval_layer_bpc_ok(T_, V_, Ci, Co)) return fail(COSKAD_ERR_SHAPE, "eval_layer_bpc: built for 12 x 25, 16 / 32 -> 16 / 32 / 64 channels");
-  constexpr int V = 25;
+template <int V>
+static int launch_eval_layer_v(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold, const float* bias,
+                               const float* in_slope, const float* out_slope, int B, int Ci, int Co, hipStream_t st) {
   const size_t lds = (size_t)(Co == 64 ? 64 : 32) * (12 * V + 2) * sizeof(float);    // (the flush needs min(C_out, 64) rows)
   const int per_cu = (Co == 64 || (Ci == 32 && Co == 32)) ? 2 : 3;
   const int grid = B < 256 * per_cu ? B : 256 * per_cu;
@@ -247,5 +246,12 @@ int launch_eval_layer_bpc(const float* in, float* out, const float* Aw, const fl
   return check_launch("eval_layer_bpc");
 }
 
-}  // namespace coskad
+int launch_eval_layer_bpc(const float* in, float* out, const float* Aw, const float* Tw, const float* wfold, const float* bias,
+                          const float* in_slope, const float* out_slope, int B, int Ci, int Co, int T_, int V_, hipStream_t st) {
+  if (!eval_layer_bpc_ok(T_, V_, Ci, Co))
+    return fail(COSKAD_ERR_SHAPE, "eval_layer_bpc: built for 12 x 17 / 25, 16 / 32 -> 16 / 32 / 64 channels");
+  if (V_ == 17) return launch_eval_layer_v<17>(in, out, Aw, Tw, wfold, bias, in_slope, out_slope, B, Ci, Co, st);
+  return launch_eval_layer_v<25>(in, out, Aw, Tw, wfold, bias, in_slope, out_slope, B, Ci, Co, st);
+}
 
+}  // namespace coskad
