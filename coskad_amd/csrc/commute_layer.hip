@@ -2,19 +2,21 @@
 // autograd of both; BatchNorm2d in training mode).
 //
 // The mixing acts per channel on (frame, joint), a 1x1 convolution mixes channels at one position: Wt gcn(X) = gcn(Wt X).  With
-//     Y = Wt X,  R = Wr X          X = PReLU(U_prev), 32 channels        (ONE K-ring GEMM pass: fused_apply_flat.hip, XO form)
+//     Y = Wt X,  R = Wr X          X = PReLU(U_prev), 32 channels
 // formed first, everything behind them sees 16 channels:
-//     Zy = gcn(Y)                                                         (k_commute_mix: one clip per workgroup, in place)
-//     U  = a_t Zy + a_r R + shift                                         (both BatchNorms are PER-CHANNEL affine maps of Zy and R: their
-//                                                                          batch statistics are row sums, not 32 x 32 Gram products)
+//     Zy = gcn(Y)                  (both in ONE kernel: fused_apply_flat.hip, XO form -- K-ring GEMM, then the clip's rows are mixed in the
+//                                   flush image; it also leaves the per-channel sums of Zy, Zy^2, R, R^2)
+//     U  = a_t Zy + a_r R + shift  (both BatchNorms are PER-CHANNEL affine maps of Zy and R: their batch statistics are row sums, not
+//                                   two 32 x 32 Gram products: k_commute_fold, k_commute_combine)
 // and the backward is ONE kernel per clip behind two row-sum reductions (k_commute_bsums -> k_commute_bfold):
 //     dZy = c1 dU + c2 Zy + c3,  dR = e1 dU + e2 R + e3                   (BatchNorm backward, per channel)
 //     dA[t] += Yt_t^T dZy_t      (Yt = temporal mix of Y)                 dT[v] += Y_v^T dYs_v   (dYs = spatial adjoint of dZy)
 //     dY = gcn^T(dZy);  dX = [Wt; Wr]^T [dY; dR];  dU_prev = dX PReLU'(U_prev);  d[Wt; Wr] += [dY; dR] X^T;  dslope_prev
-// By MFMA count the layer goes 742 -> 319 per clip forward and ~1 430 -> ~1 230 .. 710 backward; by bytes the backward reads
-// dU, Zy, R, Y (16 rows each) and U_prev (32) once and writes dU_prev -- against the statistics + data + dA/dT kernels of the
-// 32-channel form (dU twice, Z, X three times, dZ out and back).  Built for 12 frames x 25 joints (the layout whose layers run
-// unfused kernels; at 17 joints the chained kernels of fused_bwd.hip / fused_apply_next_bpc.hip already hold the layer on chip).
+// By bytes the backward reads dU, Zy, R, Y (16 rows each) and U_prev (32) once and writes dU_prev -- against the statistics + data +
+// dA / dT kernels of the 32-channel form (dU twice, Z, X three times, dZ out and back).  At B = 4096 on the 25-joint layout the layer
+// costs 141 us forward (191 as statistics + apply kernels on 32 channels) and 297 us backward (494).  Built for 12 frames x 25 joints,
+// the layout whose layers run unfused kernels; at 17 joints the chained kernels of fused_bwd.hip / fused_apply_next_bpc.hip already hold
+// the layer on chip and the same rewrite costs the chain more than it saves.
 #include "fused_ops.h"
 
 namespace coskad {
@@ -172,6 +174,9 @@ __global__ __launch_bounds__(1024) void k_commute_bfold(const float* __restrict_
   }
 }
 
+#ifndef CMB_SKIP   // timing-only builds (wrong results): 2 temporal mix, 4 dA, 8 spatial adjoint, 16 dT, 32 temporal adjoint, 64 dX, 128 d[Wt; Wr], 256 row pass
+#define CMB_SKIP 0
+#endif
 // ---- backward 3: everything per clip ----------------------------------------------------------------------------------------------
 template <int V>
 __global__ __launch_bounds__(256, 2) void k_commute_bwd(const float* __restrict__ Uprev, const float* __restrict__ YR,
@@ -179,7 +184,8 @@ __global__ __launch_bounds__(256, 2) void k_commute_bwd(const float* __restrict_
                                                        const float* __restrict__ coef, const float* __restrict__ Wt, const float* __restrict__ Wr,
                                                        const float* __restrict__ Aw, const float* __restrict__ Tw,
                                                        const float* __restrict__ in_slope, float* __restrict__ dIn,
-                                                       float* __restrict__ gpart, float* __restrict__ wpart, int B, int skip) {
+                                                       float* __restrict__ gpart, float* __restrict__ wpart, int B) {
+  constexpr int skip = CMB_SKIP;
   constexpr int TV = T * V, LD = TV + 2, R4 = TV / 4;
   static_assert(TV % 4 == 0, "rows are staged as float4");
   constexpr int NT = (TV + 15) / 16, MAXT = (NT + 1) / 2;
@@ -637,7 +643,7 @@ int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const flo
   auto k = cm::k_commute_bwd<V>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cm::Geo<V>::bwd_lds);
   hipLaunchKernelGGL(k, dim3(prow), dim3(256), cm::Geo<V>::bwd_lds, stream, u_prev, YR, Zy, dU, coef, wt, wr, A, Tm, in_slope, d_in, gpart,
-                     wpart, B, getenv("COSKAD_CM_SKIP") ? atoi(getenv("COSKAD_CM_SKIP")) : 0);
+                     wpart, B);
   if ((rc = check_launch("commute_bwd"))) return rc;
   const int nblk = ceil_div(nA + nT, cm::kRedCols) + ceil_div(1025, cm::kRedCols);
   hipLaunchKernelGGL(cm::k_commute_reduce, dim3(nblk), dim3(1024), 0, stream, gpart, wpart, prow, nA, nT, dA, dT, dWt, dWr, dslope);
