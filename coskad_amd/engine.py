@@ -152,6 +152,12 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
             for k in range(0, len(nxt), 4):
                 grp = nxt[k:k + 4]
                 ops.build_ftabs([layers[i].A for i in grp], [layers[i].T for i in grp], [ftab[i] for i in grp])
+    # the same fusion on the 25-joint layout (csrc/fused_apply_flat.hip, NX form): no operand tables, the next layer's A / T directly
+    fuse_flat = [False] * n
+    if all(batch_stats) and STORE_Z and FUSE_NEXT and sync is None:
+        for i in range(n - 1):
+            fuse_flat[i] = (not fuse[i] and layers[i + 1].Ci == layers[i].Co and layers[i].Wr is not None
+                            and ops.layer_apply_next_flat_ok(layers[i].Ci, layers[i].Co, T, V))
     pending = None              # (Z, partials, rows) of THIS layer, written by the previous layer's apply
     for i, L in enumerate(layers):
         if h.shape[1] != L.Ci:
@@ -199,6 +205,9 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
             rows_max = ops.layer_apply_next_rows(B, h.shape[1], L.Co)
             partials = torch.empty(rows_max * 2 * (L.Co * L.Co + L.Co), device=x.device, dtype=torch.float32)
             u, Zn, rows = ops.layer_apply_next(Z, h, wfold, bias, L.Co, slope, L.slope, ftab[i + 1], partials, T, V)
+            pending = (Zn, partials, rows)
+        elif fuse_flat[i] and Z is not None:
+            u, Zn, partials, rows = ops.layer_apply_next_flat(Z, h, wfold, bias, L.Co, slope, L.slope, layers[i + 1].A, layers[i + 1].T)
             pending = (Zn, partials, rows)
         elif Z is not None:
             u = ops.layer_apply_z(Z, h, L.A, L.T, wfold, bias, L.Co, in_slope=slope)

@@ -274,6 +274,28 @@ def layer_apply_next(Z, x, wfold, bias, Co, in_slope, out_slope, ftab_next, part
     return out, Z_next, rows
 
 
+def layer_apply_next_flat_ok(Ci: int, Co: int, T: int, V: int) -> bool:
+    """apply + the next layer's statistics in one kernel on the 25-joint layout (csrc/fused_apply_flat.hip, NX form)"""
+    return bool(_lib.lib().coskad_layer_apply_next_flat_ok(i32(Ci), i32(Co), i32(T), i32(V)))
+
+
+def layer_apply_next_flat(Z, x, wfold, bias, Co, in_slope, out_slope, A_next, T_next):
+    """U = Wz.Z + Wx.PReLU(x) + b  AND  the next layer's Z_next = gcn_next(PReLU_out(U)) + its moment partials.
+    -> (U, Z_next, partials, rows)"""
+    B, Ci, T, V = x.shape
+    _chk(x, "x"); _chk(Z, "Z", (B, Ci, T, V)); _chk(wfold, "wfold", (2 * Ci, cop(Co))); _chk(bias, "bias", (cop(Co),))
+    _chk(in_slope, "in_slope", (1,), optional=True); _chk(out_slope, "out_slope", (1,))
+    _chk(A_next, "A_next", (T, V, V)); _chk(T_next, "T_next", (V, T, T))
+    rows = int(_lib.lib().coskad_layer_apply_next_flat_rows(i32(B)))
+    out = torch.empty(B, Co, T, V, device=x.device, dtype=torch.float32)
+    Zn = torch.empty(B, Co, T, V, device=x.device, dtype=torch.float32)
+    partials = torch.empty(rows * 2 * (Co * Co + Co), device=x.device, dtype=torch.float32)
+    call("coskad_layer_apply_next_flat_f32", ptr(Z), ptr(x), ptr(out), ptr(wfold), ptr(bias), ptr(in_slope), ptr(out_slope), ptr(A_next),
+         ptr(T_next), ptr(Zn), ptr(partials), ctypes.c_size_t(_bytes(partials)), i32(B), i32(Ci), i32(Co), i32(T), i32(V), _stream(),
+         tag=(Ci, Co))
+    return out, Zn, partials, rows
+
+
 def layer_train_fold(partials, rows, B, T, V, Wt, bt, gt, bet, rm_t, rv_t, nbt_t, Wr, br, gr, ber, rm_r, rv_r, nbt_r, ws,
                      momentum: float = 0.1):
     """The statistics of a layer from moment partials a previous layer_apply_next wrote -> (wfold, bias, stat)."""

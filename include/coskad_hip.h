@@ -436,6 +436,18 @@ int coskad_narrow_conv_fwd_f32(const float* U, const float* in_slope, const floa
 int coskad_narrow_conv_bwd_f32(const float* U, const float* in_slope, const float* W, const float* dOut, float* dU, float* partials,
                                size_t partials_floats, int B, int Ci, int J, int TV, hipStream_t stream);
 
+/* coskad_layer_apply_z_f32 AND the next layer's statistics pass in one kernel on the 25-joint layout (what coskad_layer_apply_next_f32 is
+ * at 17 joints; csrc/fused_apply_flat.hip): U = Wz.Z + Wx.PReLU_in(in) + b -> out; Z_next = gcn_next(PReLU_out(U)) [B, Co, T, V]; partials:
+ * coskad_layer_apply_next_flat_rows(B) rows of [sum x x^T][sum x][sum z z^T][sum z] (2 (Co^2 + Co) floats) for
+ * coskad_layer_train_fold_f32 (models/graph_layers/stsgcn.py:94-116 of layer i; 56-80 + the batch statistics of layer i + 1's
+ * BatchNorms).  ok: 1 for 12 x 25, 16 / 32 -> 16 / 32 channels. */
+int coskad_layer_apply_next_flat_ok(int Ci, int Co, int T, int V);
+int coskad_layer_apply_next_flat_rows(int B);
+int coskad_layer_apply_next_flat_f32(const float* Z, const float* in, float* out, const float* wfold, const float* bias,
+                                     const float* in_slope, const float* out_slope, const float* A_next, const float* T_next,
+                                     float* Z_next, float* partials, size_t partials_bytes, int B, int Ci, int Co, int T, int V,
+                                     hipStream_t stream);
+
 /* A (32 -> 16) ST_GCNN layer in training mode by the same commutation, on its own kernels (csrc/commute_layer.hip; replaces
  * models/graph_layers/stsgcn.py:94-116 and its autograd for such a layer on the 12 x 25 layout): Y = Wt X, R = Wr X first (X = PReLU(u_prev)),
  * Zy = gcn(Y); both BatchNorms become per-channel affine maps of Zy and R (batch statistics = row sums); the backward is one kernel per clip

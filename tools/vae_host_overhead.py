@@ -5,9 +5,10 @@ from coskad_amd.models.sts.vae import STSVAE
 from coskad_amd.trainer import STSAETrainStep
 from coskad_amd.utils.synthetic import synthetic_clips
 torch.manual_seed(0)
-m = STSVAE(2, [32, 16, 32], 64, 8, 12, 25, 'sts_gcn', 'mlp', 'euclidean', 0.0, distribution='ps')
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+m = STSVAE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', 'mlp', 'euclidean', 0.0, distribution='ps')
 eng = STSAETrainStep(m.cuda().train(), mode='vae', lr=1e-4, alpha=1e-6, phi=1.0, beta=1e-3, gamma=1e-2)
-x = synthetic_clips(4096, 2, 12, 25, seed=1).cuda()
+x = synthetic_clips(4096, 2, 12, V, seed=1).cuda()
 for _ in range(10): eng.step(x)
 torch.cuda.synchronize()
 pipe, host = [], []
