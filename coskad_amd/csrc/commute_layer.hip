@@ -25,6 +25,10 @@ namespace coskad {
 int launch_commute_apply_mix(const float* in, float* out, const float* wt, const float* wr, const float* in_slope, const float* Aw,
                              const float* Tw, float* zy, float* mixpart, int B, int Ci, int Jo, int TV_, hipStream_t st, int* rows_out);
 
+// fwd_moments_bpc.hip: the next layer's statistics pass with this layer's combine formed on the way in
+int launch_combine_moments_bpc(const float* Zy, const float* YR, const float* stat, float* U, const float* Aw, const float* Tw,
+                               const float* slope, float* partials, int B, int T_, int V_, float* Zout, hipStream_t st, int* rows_out);
+
 namespace cm {
 
 using ff::f32x4;
@@ -594,12 +598,18 @@ size_t coskad_commute_ws_floats(int B, int T_, int V_) {
 /* Forward of a (32 -> 16) layer in training mode.  u_prev [B, 32, T, V] (in_slope NULL: already activated), wt / wr [16, 32] the two
  * convolutions' weights; YR [B, 32, TV] = [Wt X; Wr X], Zy [B, 16, TV] = gcn(Wt X), U [B, 16, TV] (pre-activation output) and stat [128]
  * are written and kept for the backward.  Running statistics are updated as torch.nn.BatchNorm2d does (NULL: not tracked); momentum
- * must be a number (cumulative averaging is not built here). */
+ * must be a number (cumulative averaging is not built here).
+ * A_next != NULL: the NEXT layer's (16 input channels) statistics pass rides on the combine -- Z_next [B, 16, TV] = gcn_next(PReLU(U))
+ * with slope_out = this layer's PReLU weight, partials_next: *rows_next (<= 768) rows of 2 (16^2 + 16) floats for
+ * coskad_layer_train_fold_f32. */
 int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm,
                            const float* gamma_t, const float* beta_t, const float* gamma_r, const float* beta_r, const float* bias_t,
                            const float* bias_r, float* rm_t, float* rv_t, float* rm_r, float* rv_r, long long* nbt_t, long long* nbt_r,
-                           float momentum, float eps, float* YR, float* Zy, float* U, float* stat, float* ws, size_t ws_floats, int B,
-                           int T_, int V_, hipStream_t stream) {
+                           float momentum, float eps, float* YR, float* Zy, float* U, float* stat, float* ws, size_t ws_floats,
+                           const float* A_next, const float* T_next, const float* slope_out, float* Z_next, float* partials_next,
+                           int* rows_next, int B, int T_, int V_, hipStream_t stream) {
+  if (A_next && (!T_next || !slope_out || !Z_next || !partials_next || !rows_next))
+    return fail(COSKAD_ERR_ARG, "commute_fwd: the next layer's statistics need T_next, slope_out, Z_next, partials_next, rows_next");
   if (!u_prev || !wt || !wr || !A || !Tm || !gamma_t || !beta_t || !gamma_r || !beta_r || !YR || !Zy || !U || !stat || !ws)
     return fail(COSKAD_ERR_ARG, "commute_fwd: null pointer");
   if (B <= 0 || !coskad_commute_ok(T_, V_, 32, 16)) return fail(COSKAD_ERR_SHAPE, "commute_fwd: built for 12 x 25, 32 -> 16");
@@ -611,6 +621,7 @@ int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const flo
   cm::FoldArgs fa{gamma_t, beta_t, gamma_r, beta_r, bias_t, bias_r, rm_t, rv_t, rm_r, rv_r, nbt_t, nbt_r, momentum, eps};
   hipLaunchKernelGGL(cm::k_commute_fold, dim3(1), dim3(1024), 0, stream, ws, rows, (double)B * TV, fa, stat);
   if ((rc = check_launch("commute_fold"))) return rc;
+  if (A_next) return launch_combine_moments_bpc(Zy, YR, stat, U, A_next, T_next, slope_out, partials_next, B, T_, V_, Z_next, stream, rows_next);
   hipLaunchKernelGGL(cm::k_commute_combine, dim3(B < 2048 ? B : 2048), dim3(256), 0, stream, YR, Zy, stat, U, B, TV / 4);
   return check_launch("commute_combine");
 }

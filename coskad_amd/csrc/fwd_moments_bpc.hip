@@ -19,12 +19,20 @@ using ff::mfma;
 using ff::prelu;
 using ff::quad_sum;
 
-// CT: 16-row groups of the input
-template <int V, int CT>
+// CT: 16-row groups of the input; COMB (16 channels): the input is formed on the way in from the two branches of a commuted layer
+// (commute_layer.hip): U = a_t Zy + a_r R + shift per channel (`in` = Zy [B, 16, TV], `Rr` = the R rows of [B, 32, TV], `stat` = a_t | a_r |
+// shift), stored to `Uout` for the layer's other readers -- the commuted layer's element-wise combine pass and this pass's read of it gone
+template <int V, int CT, bool COMB = false>
 __global__ __launch_bounds__(256, (CT == 1 ? 3 : 2)) void k_fwd_moments_bpc(const float* __restrict__ in, const float* __restrict__ Aw,
                                                            const float* __restrict__ Tw, const float* __restrict__ in_slope,
                                                            float* __restrict__ partials, int B, int need_x,
-                                                           float* __restrict__ Zout) {
+                                                           float* __restrict__ Zout, const float* __restrict__ Rr,
+                                                           const float* __restrict__ stat, float* __restrict__ Uout) {
+  static_assert(!COMB || CT == 1, "the commuted layers have 16 output channels");
+  __shared__ float cst[COMB ? 48 : 1];
+  if constexpr (COMB) {
+    if (threadIdx.x < 48) cst[threadIdx.x] = stat[threadIdx.x];
+  }
   constexpr int T = 12, TV = T * V, LD = TV + 2, R4 = TV / 4, Ci = 16 * CT;
   static_assert(TV % 4 == 0, "rows are staged as float4");
   constexpr int N4 = Ci * R4, XL = (N4 + 255) / 256;
@@ -90,13 +98,21 @@ __global__ __launch_bounds__(256, (CT == 1 ? 3 : 2)) void k_fwd_moments_bpc(cons
       }
     }
   };
-  float4 px[XL];
+  float4 px[XL], pr[COMB ? XL : 1];
   auto xload = [&](int clip) {
     const float4* g4 = reinterpret_cast<const float4*>(in + (size_t)(clip < B ? clip : 0) * Ci * TV);
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int e = tid + 256 * i;
       px[i] = (e < N4 && clip < B) ? g4[e] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (COMB) {
+      const float4* r4 = reinterpret_cast<const float4*>(Rr + (size_t)(clip < B ? clip : 0) * 2 * Ci * TV);
+#pragma unroll
+      for (int i = 0; i < XL; ++i) {
+        const int e = tid + 256 * i;
+        pr[i] = (e < N4 && clip < B) ? r4[e] : float4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   int clip = blockIdx.x;
@@ -109,6 +125,13 @@ __global__ __launch_bounds__(256, (CT == 1 ? 3 : 2)) void k_fwd_moments_bpc(cons
       if (e < N4) {
         const int row = e / R4, col = 4 * (e - row * R4);
         float4 v = px[i];
+        if constexpr (COMB) {
+          const float at = cst[row], ar = cst[16 + row], sh = cst[32 + row];
+          const float4 r = pr[i];
+          v = float4{fmaf(at, v.x, fmaf(ar, r.x, sh)), fmaf(at, v.y, fmaf(ar, r.y, sh)), fmaf(at, v.z, fmaf(ar, r.z, sh)),
+                     fmaf(at, v.w, fmaf(ar, r.w, sh))};
+          reinterpret_cast<float4*>(Uout + (size_t)clip * Ci * TV)[e] = v;
+        }
         if (pre) { v.x = prelu(v.x, a_in); v.y = prelu(v.y, a_in); v.z = prelu(v.z, a_in); v.w = prelu(v.w, a_in); }
         *reinterpret_cast<float2*>(img + row * LD + col) = float2{v.x, v.y};
         *reinterpret_cast<float2*>(img + row * LD + col + 2) = float2{v.z, v.w};
@@ -233,9 +256,27 @@ int launch_fwd_moments_bpc(const float* in, const float* Aw, const float* Tw, co
   const int per_cu = Ci == 16 ? 3 : 2;                   // (32 channels: 80 B of scratch at three waves per SIMD)
   const int grid = B < 256 * per_cu ? B : 256 * per_cu;
   *rows_out = grid;
-  if (Ci == 16) hipLaunchKernelGGL((fm::k_fwd_moments_bpc<V, 1>), dim3(grid), dim3(256), lds, st, in, Aw, Tw, in_slope, partials, B, need_x, Zout);
-  else hipLaunchKernelGGL((fm::k_fwd_moments_bpc<V, 2>), dim3(grid), dim3(256), lds, st, in, Aw, Tw, in_slope, partials, B, need_x, Zout);
+  if (Ci == 16)
+    hipLaunchKernelGGL((fm::k_fwd_moments_bpc<V, 1>), dim3(grid), dim3(256), lds, st, in, Aw, Tw, in_slope, partials, B, need_x, Zout,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((fm::k_fwd_moments_bpc<V, 2>), dim3(grid), dim3(256), lds, st, in, Aw, Tw, in_slope, partials, B, need_x, Zout,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
   return check_launch("fwd_moments_bpc");
+}
+
+// the statistics pass of the layer BEHIND a commuted (32 -> 16) layer, with that layer's combine U = a_t Zy + a_r R + shift formed on the
+// way in: YR [B, 32, TV] (rows 16 .. 31 = R), Zy [B, 16, TV], stat (a_t | a_r | shift) -> U [B, 16, TV], Zout = gcn(PReLU(U)), partials
+int launch_combine_moments_bpc(const float* Zy, const float* YR, const float* stat, float* U, const float* Aw, const float* Tw,
+                               const float* slope, float* partials, int B, int T_, int V_, float* Zout, hipStream_t st, int* rows_out) {
+  if (!fwd_moments_bpc_ok(T_, V_, 16) || !Zout || !slope) return fail(COSKAD_ERR_SHAPE, "combine_moments_bpc: built for 12 x 25, 16 channels");
+  constexpr int V = 25;
+  const size_t lds = (size_t)32 * (12 * V + 2) * sizeof(float);
+  const int grid = B < 768 ? B : 768;
+  *rows_out = grid;
+  hipLaunchKernelGGL((fm::k_fwd_moments_bpc<V, 1, true>), dim3(grid), dim3(256), lds, st, Zy, Aw, Tw, slope, partials, B, 1, Zout,
+                     YR + 16 * 12 * V, stat, U);
+  return check_launch("combine_moments_bpc");
 }
 
 }  // namespace coskad

@@ -119,10 +119,11 @@ class ChainCtx:
 
 
 def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Workspace,
-                  in_slope: Optional[Tensor] = None, want_ctx: bool = False, sync=None):
+                  in_slope: Optional[Tensor] = None, want_ctx: bool = False, sync=None, pending0=None):
     """-> (U_last, ctx).  U_last is the last layer's PRE-activation; apply layers[-1].slope to it.
     sync: a torch.distributed process group -> SyncBN (optional; the reference trains with per-rank statistics,
-    train_COSKAD.py:75-78): every BatchNorm boundary adds the other ranks' fp64 moment sums before the fold."""
+    train_COSKAD.py:75-78): every BatchNorm boundary adds the other ranks' fp64 moment sums before the fold.
+    pending0: (Z, partials, rows) of layers[0] when the producer of x ran its statistics pass (ops.commute_fwd)."""
     B, C, T, V = x.shape
     ctx = ChainCtx(in_slope=in_slope) if want_ctx else None
     sync_count = None
@@ -158,7 +159,9 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
         for i in range(n - 1):
             fuse_flat[i] = (not fuse[i] and layers[i + 1].Ci == layers[i].Co and layers[i].Wr is not None
                             and ops.layer_apply_next_flat_ok(layers[i].Ci, layers[i].Co, T, V))
-    pending = None              # (Z, partials, rows) of THIS layer, written by the previous layer's apply
+    pending = pending0          # (Z, partials, rows) of THIS layer, written by the previous layer's apply (or by x's producer)
+    if pending0 is not None and not (batch_stats[0] and STORE_Z and sync is None):
+        raise ValueError("chain_forward: pending0 is for the stored-Z training path without SyncBN")
     for i, L in enumerate(layers):
         if h.shape[1] != L.Ci:
             raise ValueError(f"layer expects {L.Ci} input channels, got {h.shape[1]}")

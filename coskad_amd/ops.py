@@ -1015,10 +1015,12 @@ def _commute_scratch(B: int, T: int, V: int, dev) -> Tensor:
 def commute_fwd(U_prev: Tensor, in_slope: Optional[Tensor], Wt: Tensor, Wr: Tensor, A: Tensor, Tm: Tensor, gamma_t: Tensor, beta_t: Tensor,
                 gamma_r: Tensor, beta_r: Tensor, bias_t: Optional[Tensor], bias_r: Optional[Tensor], rm_t: Optional[Tensor],
                 rv_t: Optional[Tensor], rm_r: Optional[Tensor], rv_r: Optional[Tensor], nbt_t: Optional[Tensor],
-                nbt_r: Optional[Tensor], momentum: float, eps: float):
+                nbt_r: Optional[Tensor], momentum: float, eps: float, next_layer=None, slope_out: Optional[Tensor] = None):
     """Training-mode forward of a 32 -> 16 ST_GCNN layer by commutation (csrc/commute_layer.hip; reference
     models/graph_layers/stsgcn.py:94-116): U_prev [B, 32, T, V] (pre-activation when in_slope is given), Wt / Wr [16, 32(, 1, 1)] the
-    two convolutions' weights -> (U [B, 16, T, V] pre-activation output, saved)."""
+    two convolutions' weights -> (U [B, 16, T, V] pre-activation output, saved, pending).  next_layer = (A, T) of the layer behind
+    (16 input channels) with slope_out = this layer's PReLU weight: its statistics pass rides on the last kernel and pending =
+    (Z_next, partials, rows) is what engine.chain_forward takes as `pending0`; else pending is None."""
     B, Ci, T, V = U_prev.shape
     _chk(U_prev, "U_prev"); _chk(in_slope, "in_slope", (1,), optional=True)
     for n, t in (("Wt", Wt), ("Wr", Wr)):
@@ -1036,11 +1038,20 @@ def commute_fwd(U_prev: Tensor, in_slope: Optional[Tensor], Wt: Tensor, Wr: Tens
     U = torch.empty(B, 16, T, V, device=dev, dtype=torch.float32)
     stat = torch.empty(128, device=dev, dtype=torch.float32)
     ws = _commute_scratch(B, T, V, dev)
+    An = Tn = Zn = pn = None
+    rows = ctypes.c_int(0)
+    if next_layer is not None:
+        An, Tn = next_layer
+        _chk(An, "A_next", (T, V, V)); _chk(Tn, "T_next", (V, T, T)); _chk(slope_out, "slope_out", (1,))
+        Zn = torch.empty(B, 16, T, V, device=dev, dtype=torch.float32)
+        pn = torch.empty(768 * 2 * (16 * 16 + 16), device=dev, dtype=torch.float32)
     call("coskad_commute_fwd_f32", ptr(U_prev), ptr(in_slope), ptr(Wt), ptr(Wr), ptr(A), ptr(Tm), ptr(gamma_t), ptr(beta_t),
          ptr(gamma_r), ptr(beta_r), ptr(bias_t), ptr(bias_r), ptr(rm_t), ptr(rv_t), ptr(rm_r), ptr(rv_r), ptr(nbt_t), ptr(nbt_r),
          ctypes.c_float(momentum), ctypes.c_float(eps), ptr(YR), ptr(Zy), ptr(U), ptr(stat), ptr(ws), ctypes.c_size_t(ws.numel()),
+         ptr(An), ptr(Tn), ptr(slope_out if next_layer is not None else None), ptr(Zn), ptr(pn), ctypes.byref(rows),
          i32(B), i32(T), i32(V), _stream())
-    return U, (U_prev, in_slope, Wt, Wr, A, Tm, YR, Zy, stat)
+    pending = (Zn, pn, int(rows.value)) if next_layer is not None else None
+    return U, (U_prev, in_slope, Wt, Wr, A, Tm, YR, Zy, stat), pending
 
 
 def commute_bwd(saved, dU: Tensor, into: dict):

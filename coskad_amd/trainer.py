@@ -294,6 +294,7 @@ def _is_narrow(m) -> bool:
 # Layers with fewer output than input channels (32 -> 16 on the 25-joint layout) by commutation as well, on their own kernels
 # (csrc/commute_layer.hip): convolutions first, mixing / BatchNorm statistics / both adjoints / dA, dT on 16 channels.
 COMMUTE = True
+COMMUTE_NEXT = True      # ... and the statistics pass of the layer behind them rides on their last kernel
 
 
 def _is_commute(m) -> bool:
@@ -370,9 +371,11 @@ class _FlatStack:
         """x: the stack's input, activated (in_slope None) or a pre-activation whose PReLU weight is `in_slope`
         -> (h, slope, saved): apply PReLU(slope) to h for the stack's output (slope None: done)."""
         h, slope, saved = x, in_slope, []
-        for seg in self.segs:
+        pend = None                    # the next tile run's first-layer statistics, when the commuted layer in front of it formed them
+        for k, seg in enumerate(self.segs):
             if seg[0] == 'tile':
-                u, ctx = engine.chain_forward(h, seg[1], True, ws, in_slope=slope, want_ctx=True)
+                u, ctx = engine.chain_forward(h, seg[1], True, ws, in_slope=slope, want_ctx=True, pending0=pend)
+                pend = None
                 saved.append(ctx)
                 h, slope = u, seg[1][-1].slope
             elif seg[0] == 'narrow':
@@ -389,9 +392,14 @@ class _FlatStack:
                 Co, Ci = mod.out_channels, mod.in_channels
                 tc, tb, rc, rb = mod.tcn[0], mod.tcn[1], mod.residual[0], mod.residual[1]
                 mod.__dict__.get("_fold_cache", {}).clear()
-                u, sv = ops.commute_fwd(h, slope, tc.weight, rc.weight, mod.gcn.A, mod.gcn.T, tb.weight, tb.bias, rb.weight, rb.bias, tc.bias, rc.bias,
-                                        tb.running_mean, tb.running_var, rb.running_mean, rb.running_var, tb.num_batches_tracked,
-                                        rb.num_batches_tracked, tb.momentum, tb.eps)
+                # a tile run behind this layer: its first layer's statistics pass rides on this layer's last kernel
+                nxt = self.segs[k + 1][1][0] if (COMMUTE_NEXT and k + 1 < len(self.segs) and self.segs[k + 1][0] == 'tile') else None
+                if nxt is not None and (nxt.Ci != Co or nxt.rm_t is None or not engine.STORE_Z):
+                    nxt = None
+                u, sv, pend = ops.commute_fwd(h, slope, tc.weight, rc.weight, mod.gcn.A, mod.gcn.T, tb.weight, tb.bias, rb.weight, rb.bias,
+                                              tc.bias, rc.bias, tb.running_mean, tb.running_var, rb.running_mean, rb.running_var,
+                                              tb.num_batches_tracked, rb.num_batches_tracked, tb.momentum, tb.eps,
+                                              next_layer=(nxt.A, nxt.T) if nxt is not None else None, slope_out=mod.prelu.weight)
                 saved.append(sv)
                 h, slope = u, mod.prelu.weight
             else:

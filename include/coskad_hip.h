@@ -455,7 +455,9 @@ int coskad_layer_apply_next_flat_f32(const float* Z, const float* in, float* out
  *   ok        : 1 when (n_frames, n_joints, C_in, C_out) is built (12, 25, 32, 16)
  *   ws_floats : floats of the scratch both entries need
  *   fwd       : writes YR [B, 32, TV] = [Y; R], Zy [B, 16, TV], U [B, 16, TV] (the layer's pre-activation output), stat [128]; updates the
- *               running statistics / num_batches_tracked of both BatchNorms as torch does (NULL: not tracked; momentum a number)
+ *               running statistics / num_batches_tracked of both BatchNorms as torch does (NULL: not tracked; momentum a number);
+ *               A_next != NULL: the next layer's statistics pass in the same launches (Z_next = gcn_next(PReLU(U)), *rows_next rows of
+ *               moment partials for coskad_layer_train_fold_f32; slope_out = this layer's PReLU weight)
  *   bwd       : dU [B, 16, TV] -> d_in [B, 32, TV] (PReLU mask of u_prev applied), dA [T, V, V], dT [V, T, T], dWt / dWr [16, 32],
  *               dgamma / dbeta [16] of both BatchNorms, dslope [1] (the producer's PReLU weight; NULL iff in_slope NULL): all overwritten */
 int coskad_commute_ok(int T, int V, int Ci, int Co);
@@ -463,8 +465,9 @@ size_t coskad_commute_ws_floats(int B, int T, int V);
 int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm,
                            const float* gamma_t, const float* beta_t, const float* gamma_r, const float* beta_r, const float* bias_t,
                            const float* bias_r, float* rm_t, float* rv_t, float* rm_r, float* rv_r, long long* nbt_t, long long* nbt_r,
-                           float momentum, float eps, float* YR, float* Zy, float* U, float* stat, float* ws, size_t ws_floats, int B,
-                           int T, int V, hipStream_t stream);
+                           float momentum, float eps, float* YR, float* Zy, float* U, float* stat, float* ws, size_t ws_floats,
+                           const float* A_next, const float* T_next, const float* slope_out, float* Z_next, float* partials_next,
+                           int* rows_next, int B, int T, int V, hipStream_t stream);
 int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm,
                            const float* YR, const float* Zy, const float* stat, const float* dU, float* d_in, float* dA, float* dT,
                            float* dWt, float* dWr, float* dgamma_t, float* dbeta_t, float* dgamma_r, float* dbeta_r, float* dslope,

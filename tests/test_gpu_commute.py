@@ -48,7 +48,7 @@ def test_commuted_layer_matches_the_layer_formula(B, with_slope):
     rm_r, rv_r = torch.zeros(16, device=dev), torch.ones(16, device=dev)
     nbt_t = torch.zeros((), dtype=torch.int64, device=dev)
     nbt_r = torch.zeros((), dtype=torch.int64, device=dev)
-    U, saved = ops.commute_fwd(U_prev, slope, p["Wt"], p["Wr"], p["A"], p["Tm"], p["gt"], p["bet"], p["gr"], p["ber"], p["bt"], p["br"], rm_t, rv_t,
+    U, saved, _ = ops.commute_fwd(U_prev, slope, p["Wt"], p["Wr"], p["A"], p["Tm"], p["gt"], p["bet"], p["gr"], p["ber"], p["bt"], p["br"], rm_t, rv_t,
                                rm_r, rv_r, nbt_t, nbt_r, mom, eps)
     into = {"A": torch.empty_like(p["A"]), "T": torch.empty_like(p["Tm"]), "Wt": torch.empty(16, 32, device=dev),
             "Wr": torch.empty(16, 32, device=dev), "gt": torch.empty(16, device=dev), "bet": torch.empty(16, device=dev),
@@ -135,9 +135,10 @@ def test_autoencoder_step_with_commuted_layers_equals_the_layer_kernels(monkeypa
     _compare(res[False][2:], res[True][2:])
 
 
-def test_encoder_step_with_a_commuted_layer_equals_the_chain(monkeypatch):
+@pytest.mark.parametrize("ride", [True, False])
+def test_encoder_step_with_a_commuted_layer_equals_the_chain(ride, monkeypatch):
     """STSETrainStep at 25 joints: the encoder as a _FlatStack with layer 2 commuted vs the plain chain; then three optimiser steps
-    stay together (loss curve)."""
+    stay together (loss curve).  ride: layer 3's statistics pass on the commuted layer's last kernel, or as its own launch."""
     import numpy as np
     from coskad_amd import trainer
     from coskad_amd.models.sts.ae import STSE
@@ -148,6 +149,7 @@ def test_encoder_step_with_a_commuted_layer_equals_the_chain(monkeypatch):
     st = {k: v.detach().clone() for k, v in proto.state_dict().items()}
     x = R.synthetic_clips(53, 2, 12, V, seed=22).cuda()
     res = {}
+    monkeypatch.setattr(trainer, "COMMUTE_NEXT", ride)
     for on in (False, True):
         monkeypatch.setattr(trainer, "COMMUTE", on)
         m = STSE(2, [32, 16, 32], 64, 8, 12, V, 'sts_gcn', 'linear', 'euclidean', 0.0)

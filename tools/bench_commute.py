@@ -37,5 +37,5 @@ def timeit(f, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-U, saved = fwd()
+U, saved, _ = fwd()
 print(f"B={B}  forward {timeit(fwd):.1f} us   backward {timeit(lambda: ops.commute_bwd(saved, dU, into)):.1f} us")
