@@ -42,6 +42,7 @@ constexpr int kCoef = 6 * C;         // c1 c2 c3 e1 e2 e3
 constexpr int kMixCols = 4 * C;      // sum z, sum z^2, sum r, sum r^2
 constexpr int kSumCols = 3 * C;      // sum dU, sum dU Zy, sum dU R
 constexpr int kWCols = 32 * 32 + 16; // d[Wt; Wr] (32 x 32) + the slope partial (padded to a float4 multiple)
+constexpr int kBelowCols = 2 * 32 * 2 + 32;   // [P 32 x 2][Q 32 x 2][sdU 32] of a 2-channel layer below
 
 constexpr int window_stride(int tv) {
   int l = (tv + 3) / 4 * 4;
@@ -182,13 +183,19 @@ __global__ __launch_bounds__(1024) void k_commute_bfold(const float* __restrict_
 #define CMB_SKIP 0
 #endif
 // ---- backward 3: everything per clip ----------------------------------------------------------------------------------------------
-template <int V>
+// NS: the batch reductions of the (2-channel) layer BELOW -- P = sum dU_prev Z_below^T, Q = sum dU_prev X_below^T, sdU (stage 1 of ITS
+// backward: k_first_stats) -- are formed here from the dU_prev rows the row pass has just produced (the backward chain of fused_bwd.hip):
+// a re-read of dU_prev and a launch fewer.  below_z / below_x [B, 2, TV] (X_below is the network input: no PReLU), `bpart` [grid][160]
+// partial rows [P 32 x 2][Q 32 x 2][sdU 32] as k_bwd_fold reads their sums.
+template <int V, bool NS>
 __global__ __launch_bounds__(256, 2) void k_commute_bwd(const float* __restrict__ Uprev, const float* __restrict__ YR,
                                                        const float* __restrict__ Zy, const float* __restrict__ dU,
                                                        const float* __restrict__ coef, const float* __restrict__ Wt, const float* __restrict__ Wr,
                                                        const float* __restrict__ Aw, const float* __restrict__ Tw,
                                                        const float* __restrict__ in_slope, float* __restrict__ dIn,
-                                                       float* __restrict__ gpart, float* __restrict__ wpart, int B) {
+                                                       float* __restrict__ gpart, float* __restrict__ wpart, int B,
+                                                       const float* __restrict__ below_z, const float* __restrict__ below_x,
+                                                       float* __restrict__ bpart) {
   constexpr int skip = CMB_SKIP;
   constexpr int TV = T * V, LD = TV + 2, R4 = TV / 4;
   static_assert(TV % 4 == 0, "rows are staged as float4");
@@ -236,6 +243,10 @@ __global__ __launch_bounds__(256, 2) void k_commute_bwd(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < 4; ++k) accW[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   float da = 0.f;
+  f32x4 nsb[NS ? 2 : 1];             // (NS) [dU_prev rows 16 c ..][Z0 Z1 X0 X1]: this wave's share of the k-steps
+  float nss[NS ? 2 : 1];
+#pragma unroll
+  for (int c = 0; c < (NS ? 2 : 1); ++c) { nsb[c] = f32x4{0.f, 0.f, 0.f, 0.f}; nss[c] = 0.f; }
   auto pos_of = [&](int t) {
     const int p = 16 * (t0 + (t < nt ? t : 0)) + L.j;
     return p < TV ? p : TV - 1;
@@ -490,6 +501,43 @@ __global__ __launch_bounds__(256, 2) void k_commute_bwd(const float* __restrict_
               }
             }
             g4[e] = float4{g[0], g[1], g[2], g[3]};
+            if constexpr (NS) {                          // the image keeps dU_prev for the reductions below
+              float* pw = img + (16 * h + row) * LD + col;
+              *reinterpret_cast<float2*>(pw) = float2{g[0], g[1]};
+              *reinterpret_cast<float2*>(pw + 2) = float2{g[2], g[3]};
+            }
+          }
+        }
+      }
+      if constexpr (NS) {
+        // ---- the layer below: [P | Q] += dU_prev (image rows) x (Z0 Z1 X0 X1)^T (window rows 0 .. 3), k-steps dealt to the waves ------
+        {
+          const bool fst = tid < 2 * R4;
+          const float4 vz = fst ? reinterpret_cast<const float4*>(below_z + (size_t)clip * 2 * TV)[tid] : float4{0.f, 0.f, 0.f, 0.f};
+          const float4 vx = fst ? reinterpret_cast<const float4*>(below_x + (size_t)clip * 2 * TV)[tid] : float4{0.f, 0.f, 0.f, 0.f};
+          if (fst) {
+            const int frow = tid / R4, fcol = 4 * (tid - frow * R4);
+            *reinterpret_cast<float2*>(win + frow * LD + fcol) = float2{vz.x, vz.y};
+            *reinterpret_cast<float2*>(win + frow * LD + fcol + 2) = float2{vz.z, vz.w};
+            *reinterpret_cast<float2*>(win + (2 + frow) * LD + fcol) = float2{vx.x, vx.y};
+            *reinterpret_cast<float2*>(win + (2 + frow) * LD + fcol + 2) = float2{vx.z, vx.w};
+          }
+        }
+        __syncthreads();                                 // the image holds dU_prev, the window the four rows
+        L = geo();
+        const float* pb = win + (L.j & 3) * LD + 2 * L.q;
+        const float* pa = img + L.j * LD + 2 * L.q;
+        for (int m = wave; m < NM; m += 4) {
+          float2 b = *reinterpret_cast<const float2*>(pb + 8 * m);
+          const bool aok = 8 * m + 2 * L.q < TV, ok = aok && L.j < 4;
+          b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            float2 a = *reinterpret_cast<const float2*>(pa + 16 * c * LD + 8 * m);
+            a.x = aok ? a.x : 0.f; a.y = aok ? a.y : 0.f;
+            nsb[c] = mfma(a.x, b.x, nsb[c]);
+            nsb[c] = mfma(a.y, b.y, nsb[c]);
+            nss[c] += a.x + a.y;
           }
         }
       }
@@ -540,20 +588,52 @@ __global__ __launch_bounds__(256, 2) void k_commute_bwd(const float* __restrict_
             p[0] = (w ? p[0] : 0.f) + accW[2 * dh + h][r];
           }
       if (lane == 0) row[1024] = (w ? row[1024] : 0.f) + da;
+      if constexpr (NS) {                                // [o][Z0 Z1 X0 X1] -> [P 32 x 2][Q 32 x 2][sdU 32] behind the weight sums
+        float* ex = row + kWCols;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 16 * c + 4 * L.q + r;
+            if (L.j < 4) {
+              float* p = ex + (L.j < 2 ? o * 2 + L.j : 64 + o * 2 + (L.j - 2));
+              p[0] = (w ? p[0] : 0.f) + nsb[c][r];
+            }
+          }
+          const float t = ff::quad_sum(nss[c]);
+          if (L.q == 0) {
+            float* p = ex + 128 + 16 * c + L.j;
+            p[0] = (w ? p[0] : 0.f) + t;
+          }
+        }
+      }
     }
     __syncthreads();
   }
   float* dstW = wpart + (size_t)blockIdx.x * kWCols;
   for (int e = tid; e < 1025; e += 256) dstW[e] = row[e];
+  if constexpr (NS) {
+    float* dstB = bpart + (size_t)blockIdx.x * kBelowCols;
+    for (int e = tid; e < kBelowCols; e += 256) dstB[e] = row[kWCols + e];
+  }
 }
 
 // dA, dT, d[Wt; Wr] and the producer's slope gradient from the workgroups' partial rows, in ONE launch (fp64, fixed order)
 constexpr int kRedCols = 32;
 __global__ __launch_bounds__(1024) void k_commute_reduce(const float* __restrict__ gpart, const float* __restrict__ wpart, int P, int nA,
                                                         int nT, float* __restrict__ dA, float* __restrict__ dT,
-                                                        float* __restrict__ dWt, float* __restrict__ dWr, float* __restrict__ dslope) {
+                                                        float* __restrict__ dWt, float* __restrict__ dWr, float* __restrict__ dslope,
+                                                        const float* __restrict__ bpart, double* __restrict__ bout) {
   __shared__ double sh[1024];
   const int E = nA + nT, nblk = (E + kRedCols - 1) / kRedCols;
+  constexpr int nwb = (1025 + kRedCols - 1) / kRedCols;
+  if ((int)blockIdx.x >= nblk + nwb) {                   // the layer below's chain rows -> fp64 sums (k_bwd_fold reads them)
+    const int e = ((int)blockIdx.x - nblk - nwb) * kRedCols + (threadIdx.x % kRedCols);
+    const bool ok = e < kBelowCols;
+    const double t = column_sum_f64<kRedCols>(bpart, P, (size_t)kBelowCols, e, ok, sh);
+    if ((int)threadIdx.x < kRedCols && ok) bout[e] = t;
+    return;
+  }
   if ((int)blockIdx.x < nblk) {
     const int e = blockIdx.x * kRedCols + (threadIdx.x % kRedCols);
     const double t = column_sum_f64<kRedCols>(gpart, P, (size_t)E, e, e < E, sh);
@@ -627,11 +707,19 @@ int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const flo
 }
 
 /* Backward: dU [B, 16, TV] -> d_in [B, 32, TV] (gradient of u_prev, PReLU mask applied), dA [T, V, V], dT [V, T, T], dWt / dWr [16, 32],
- * dgamma / dbeta [16] of both BatchNorms, dslope [1] (NULL with in_slope NULL): all OVERWRITTEN. */
+ * dgamma / dbeta [16] of both BatchNorms, dslope [1] (NULL with in_slope NULL): all OVERWRITTEN.
+ * below_stats != NULL: the layer below has 2 input channels (the first layer; below_x [B, 2, TV] its input, below_z its stored Z) and its
+ * batch reductions are formed here: below_stats = a chain buffer of coskad_commute_below_floats(B) floats (8-byte aligned) that
+ * coskad_layer_bwd_chain_f32 takes as `stats_in` with stats_in_rows = coskad_commute_below_rows(B). */
+int coskad_commute_below_rows(int B) { return cm::bwd_rows(B); }
+size_t coskad_commute_below_floats(int B) { return ((size_t)cm::bwd_rows(B) * cm::kBelowCols + 1) / 2 * 2 + 2 * (size_t)cm::kBelowCols; }
 int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm, const float* YR,
                            const float* Zy, const float* stat, const float* dU, float* d_in, float* dA, float* dT, float* dWt, float* dWr,
                            float* dgamma_t, float* dbeta_t, float* dgamma_r, float* dbeta_r, float* dslope, float* ws, size_t ws_floats,
-                           int B, int T_, int V_, hipStream_t stream) {
+                           const float* below_x, const float* below_z, float* below_stats, size_t below_stats_floats, int B, int T_,
+                           int V_, hipStream_t stream) {
+  if (below_stats && (!below_x || !below_z || ((size_t)below_stats & 7) || below_stats_floats < coskad_commute_below_floats(B)))
+    return fail(COSKAD_ERR_ARG, "commute_bwd: below_stats needs below_x, below_z, 8-byte alignment and coskad_commute_below_floats(B) floats");
   if (!u_prev || !wt || !wr || !A || !Tm || !YR || !Zy || !stat || !dU || !d_in || !dA || !dT || !dWt || !dWr || !dgamma_t || !dbeta_t ||
       !dgamma_r || !dbeta_r || !ws)
     return fail(COSKAD_ERR_ARG, "commute_bwd: null pointer");
@@ -651,13 +739,15 @@ int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const flo
   hipLaunchKernelGGL(cm::k_commute_bfold, dim3(1), dim3(1024), 0, stream, spart, srow, (double)B * TV, stat, coef, dgamma_t, dbeta_t,
                      dgamma_r, dbeta_r);
   if ((rc = check_launch("commute_bfold"))) return rc;
-  auto k = cm::k_commute_bwd<V>;
+  auto k = below_stats ? cm::k_commute_bwd<V, true> : cm::k_commute_bwd<V, false>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cm::Geo<V>::bwd_lds);
   hipLaunchKernelGGL(k, dim3(prow), dim3(256), cm::Geo<V>::bwd_lds, stream, u_prev, YR, Zy, dU, coef, wt, wr, A, Tm, in_slope, d_in, gpart,
-                     wpart, B);
+                     wpart, B, below_z, below_x, below_stats);
   if ((rc = check_launch("commute_bwd"))) return rc;
-  const int nblk = ceil_div(nA + nT, cm::kRedCols) + ceil_div(1025, cm::kRedCols);
-  hipLaunchKernelGGL(cm::k_commute_reduce, dim3(nblk), dim3(1024), 0, stream, gpart, wpart, prow, nA, nT, dA, dT, dWt, dWr, dslope);
+  const int nblk = ceil_div(nA + nT, cm::kRedCols) + ceil_div(1025, cm::kRedCols) + (below_stats ? ceil_div(cm::kBelowCols, cm::kRedCols) : 0);
+  double* bout = below_stats ? reinterpret_cast<double*>(below_stats + ((size_t)prow * cm::kBelowCols + 1) / 2 * 2) : nullptr;
+  hipLaunchKernelGGL(cm::k_commute_reduce, dim3(nblk), dim3(1024), 0, stream, gpart, wpart, prow, nA, nT, dA, dT, dWt, dWr, dslope,
+                     below_stats, bout);
   return check_launch("commute_reduce");
 }
 

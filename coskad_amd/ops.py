@@ -1054,8 +1054,10 @@ def commute_fwd(U_prev: Tensor, in_slope: Optional[Tensor], Wt: Tensor, Wr: Tens
     return U, (U_prev, in_slope, Wt, Wr, A, Tm, YR, Zy, stat), pending
 
 
-def commute_bwd(saved, dU: Tensor, into: dict):
-    """-> gradient of U_prev [B, 32, T, V] (PReLU mask applied).  `into`: destinations (all overwritten) 'A' [T, V, V], 'T' [V, T, T],
+def commute_bwd(saved, dU: Tensor, into: dict, below=None):
+    """-> (gradient of U_prev [B, 32, T, V] (PReLU mask applied), chain).  below = (x_below [B, 2, T, V], Z_below) of a 2-channel layer
+    in front (the first layer, fed by the network input): its batch reductions are formed by the same kernel and chain = (buffer, rows) is
+    what engine.chain_backward takes as `stats_in`; else chain is None.  `into`: destinations (all overwritten) 'A' [T, V, V], 'T' [V, T, T],
     'Wt' / 'Wr' [16, 32(, 1, 1)], 'gt' 'bet' 'gr' 'ber' [16], 'in_slope' [1] (the producer's PReLU weight gradient; with in_slope)."""
     U_prev, in_slope, Wt, Wr, A, Tm, YR, Zy, stat = saved
     B, Ci, T, V = U_prev.shape
@@ -1071,10 +1073,20 @@ def commute_bwd(saved, dU: Tensor, into: dict):
         _chk(dsl, "into.in_slope", (1,))
     d_in = torch.empty_like(U_prev)
     ws = _commute_scratch(B, T, V, U_prev.device)
+    bx = bz = buf = None
+    rows = 0
+    if below is not None:
+        bx, bz = below
+        _chk(bx, "below.x", (B, 2, T, V)); _chk(bz, "below.Z", (B, 2, T, V))
+        lib = _lib.lib()
+        lib.coskad_commute_below_floats.restype = ctypes.c_size_t
+        rows = int(lib.coskad_commute_below_rows(i32(B)))
+        buf = torch.empty(int(lib.coskad_commute_below_floats(i32(B))), device=U_prev.device, dtype=torch.float32)
     call("coskad_commute_bwd_f32", ptr(U_prev), ptr(in_slope), ptr(Wt), ptr(Wr), ptr(A), ptr(Tm), ptr(YR), ptr(Zy), ptr(stat), ptr(dU), ptr(d_in),
          ptr(into["A"]), ptr(into["T"]), ptr(into["Wt"]), ptr(into["Wr"]), ptr(into["gt"]), ptr(into["bet"]), ptr(into["gr"]),
-         ptr(into["ber"]), ptr(dsl), ptr(ws), ctypes.c_size_t(ws.numel()), i32(B), i32(T), i32(V), _stream())
-    return d_in
+         ptr(into["ber"]), ptr(dsl), ptr(ws), ctypes.c_size_t(ws.numel()), ptr(bx), ptr(bz), ptr(buf),
+         ctypes.c_size_t(buf.numel() if buf is not None else 0), i32(B), i32(T), i32(V), _stream())
+    return d_in, ((buf, rows) if below is not None else None)
 
 
 def _rows(t: Tensor, name: str, cols: int):

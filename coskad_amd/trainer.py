@@ -436,12 +436,13 @@ class _FlatStack:
                 return self.fp.gviews[below[2] + "prelu.weight"]
             return None
 
+        chained = None                 # batch reductions of the tile run below, formed by the commuted layer's backward kernel
         for k in range(len(self.segs) - 1, -1, -1):
             seg, sv = self.segs[k], saved[k]
             first = k == 0
             if seg[0] == 'tile':
                 d = engine.chain_backward(sv, seg[1], d, ws, seg[2], need_dx=need_dx or not first,
-                                          stats_in=top_stats if k == len(self.segs) - 1 else None,
+                                          stats_in=top_stats if k == len(self.segs) - 1 else chained,
                                           in_slope_grad=below_slope_grad(k) if (first or self.segs[k - 1][0] == 'commute') else None)
             elif seg[0] == 'commute':
                 prefix, gv = seg[2], self.fp.gviews
@@ -452,7 +453,14 @@ class _FlatStack:
                     into["in_slope"] = below_slope_grad(k)
                     if into["in_slope"] is None:
                         raise RuntimeError("commuted layer: nowhere to put the gradient of its input's PReLU weight")
-                d = ops.commute_bwd(sv, d.contiguous(), into)
+                # a tile run in front that ends in a 2-channel layer fed by the network input: its batch reductions ride on this kernel
+                below = None
+                if COMMUTE_NEXT and k > 0 and self.segs[k - 1][0] == 'tile':
+                    bl, bctx = self.segs[k - 1][1][-1], saved[k - 1]
+                    if (bl.Ci == 2 and bl.Co == 32 and bl.Wr is not None and len(self.segs[k - 1][1]) == 1 and bctx.in_slope is None
+                            and bctx.zs and bctx.zs[-1] is not None and bctx.sync is None):
+                        below = (bctx.inputs[-1], bctx.zs[-1])
+                d, chained = ops.commute_bwd(sv, d.contiguous(), into, below=below)
                 if not (need_dx or not first):
                     d = None
             elif seg[0] == 'narrow':

@@ -459,7 +459,10 @@ int coskad_layer_apply_next_flat_f32(const float* Z, const float* in, float* out
  *               A_next != NULL: the next layer's statistics pass in the same launches (Z_next = gcn_next(PReLU(U)), *rows_next rows of
  *               moment partials for coskad_layer_train_fold_f32; slope_out = this layer's PReLU weight)
  *   bwd       : dU [B, 16, TV] -> d_in [B, 32, TV] (PReLU mask of u_prev applied), dA [T, V, V], dT [V, T, T], dWt / dWr [16, 32],
- *               dgamma / dbeta [16] of both BatchNorms, dslope [1] (the producer's PReLU weight; NULL iff in_slope NULL): all overwritten */
+ *               dgamma / dbeta [16] of both BatchNorms, dslope [1] (the producer's PReLU weight; NULL iff in_slope NULL): all overwritten;
+ *               below_stats != NULL (a 2-channel layer in front, fed by the network input below_x, stored Z below_z): that layer's batch
+ *               reductions too, as the chain buffer coskad_layer_bwd_chain_f32 takes (stats_in, coskad_commute_below_rows(B) rows,
+ *               coskad_commute_below_floats(B) floats) */
 int coskad_commute_ok(int T, int V, int Ci, int Co);
 size_t coskad_commute_ws_floats(int B, int T, int V);
 int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm,
@@ -471,7 +474,10 @@ int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const flo
 int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const float* wt, const float* wr, const float* A, const float* Tm,
                            const float* YR, const float* Zy, const float* stat, const float* dU, float* d_in, float* dA, float* dT,
                            float* dWt, float* dWr, float* dgamma_t, float* dbeta_t, float* dgamma_r, float* dbeta_r, float* dslope,
-                           float* ws, size_t ws_floats, int B, int T, int V, hipStream_t stream);
+                           float* ws, size_t ws_floats, const float* below_x, const float* below_z, float* below_stats,
+                           size_t below_stats_floats, int B, int T, int V, hipStream_t stream);
+int coskad_commute_below_rows(int B);
+size_t coskad_commute_below_floats(int B);
 
 /* The spherical VAE's latent head between the raw outputs of fc_mean / fc_var and the decoder's input (models/sts/vae.py:79-91,
  * 104-118; loss terms of models/spherical_vae.py:86-94; PowerSpherical of the un-vendored `power_spherical` package, restated in
