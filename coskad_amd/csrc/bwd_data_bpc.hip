@@ -14,6 +14,9 @@
 // block per CU, every phase behind a block-wide barrier (385 / 273 / 171 us per call at B = 4096).
 #include "fused_ops.h"
 
+#ifndef BDB_SKIP   // timing-only builds (wrong results; tools/bd_phases.sh): 1 K-pass products, 2 dA (+ X halves, temporal mix), 4 spatial adjoint, 8 dT,
+#define BDB_SKIP 0 // 16 temporal adjoint, 32 row pass.  32 -> 64 at B = 4096: 145 / 66 / 53 / 66 / 26 / 7 us on a 124 us floor of streaming + barriers
+#endif
 namespace coskad {
 namespace bd {
 
@@ -213,11 +216,11 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
         }
         if (g < OT + CT) {
 #pragma unroll
-          for (int t = 0; t < MAXT; ++t) acc1[t] = mfma(wa[g & 1][s], b[t], acc1[t]);
+          for (int t = 0; t < ((BDB_SKIP & 1) ? 0 : MAXT); ++t) acc1[t] = mfma(wa[g & 1][s], b[t], acc1[t]);
         }
         if (g < OT || g >= OT + CT) {
 #pragma unroll
-          for (int t = 0; t < MAXT; ++t) acc2[t] = mfma(wb[g & 1][s], b[t], acc2[t]);
+          for (int t = 0; t < ((BDB_SKIP & 1) ? 0 : MAXT); ++t) acc2[t] = mfma(wb[g & 1][s], b[t], acc2[t]);
         }
         if (s + 1 < 4 || g + 1 < NG) {
           const int sn = (s + 1) & 3;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
         for (int s = 0; s < 3; ++s) tf[k][s] = (v < V && L.j < T) ? Twc[(v * T + 4 * s + L.q) * T + L.j] : 0.f;
       }
 #pragma unroll
-      for (int h = 0; h < CT; ++h) {
+      for (int h = 0; h < ((BDB_SKIP & 2) ? 0 : CT); ++h) {
         hstore(xh);
         if (h + 1 < CT) hload(clip, h + 1, xh);
         __syncthreads();                                 // the window holds X rows 16 h ..
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
     if constexpr (!FP) __syncthreads();                  // the rows have left: the image may be mixed in place
     // ---- dY = spatial adjoint of dZ, in place: frames t = wave, wave + 4, wave + 8 (a frame is touched by its owner only) -------
 #pragma unroll
-    for (int tt = 0; tt < MAXF; ++tt) {
+    for (int tt = 0; tt < ((BDB_SKIP & 4) ? 0 : MAXF); ++tt) {
       const int t = wave + 4 * tt;
 #pragma unroll
       for (int rt = 0; rt < CT; ++rt) {
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
     if constexpr (FP) {
       // ---- dT[v] += X_v^T dYs_v for this wave's joints: X halves through the window ---------------------------------------------
 #pragma unroll
-      for (int h = 0; h < CT; ++h) {
+      for (int h = 0; h < ((BDB_SKIP & 8) ? 0 : CT); ++h) {
         hstore(xh);
         if (h + 1 < CT) hload(clip, h + 1, xh);
         __syncthreads();
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
     }
     // ---- temporal adjoint, in place: joints v = wave, wave + 4, .. ---------------------------------------------------------------
 #pragma unroll
-    for (int k = 0; k < MAXJ; ++k) {
+    for (int k = 0; k < ((BDB_SKIP & 16) ? 0 : MAXJ); ++k) {
       const int v = wave + 4 * k;
       if (v < V) {
 #pragma unroll
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
     {
       float4* g4 = reinterpret_cast<float4*>(dIn + (size_t)clip * Ci * TVg);
 #pragma unroll
-      for (int i = 0; i < XL; ++i) {
+      for (int i = 0; i < ((BDB_SKIP & 32) ? 0 : XL); ++i) {
         const int e = tid + 256 * i;
         if (e < N4) {
           const int row = e / R4, col = 4 * (e - row * R4);
