@@ -44,12 +44,6 @@ constexpr int kSumCols = 3 * C;      // sum dU, sum dU Zy, sum dU R
 constexpr int kWCols = 32 * 32 + 16; // d[Wt; Wr] (32 x 32) + the slope partial (padded to a float4 multiple)
 constexpr int kBelowCols = 2 * 32 * 2 + 32;   // [P 32 x 2][Q 32 x 2][sdU 32] of a 2-channel layer below
 
-constexpr int window_stride(int tv) {
-  int l = (tv + 3) / 4 * 4;
-  while (l % 64 != 16 && l % 64 != 48) l += 4;
-  return l;
-}
-
 // sums the P partial rows of `cols` (<= 64) columns in fp64 (fixed order; common.h: 64 columns x 16 row slices, eight loads in flight)
 __device__ __forceinline__ void sum_rows_f64(const float* __restrict__ rows, int P, int cols, double* out, double* sh) {
   const int col = threadIdx.x & 63;
