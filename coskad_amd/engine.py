@@ -118,6 +118,10 @@ class ChainCtx:
     sync_count: float = 0.0                              # ... and the positions of the global batch
 
 
+# eval-mode forwards run the first two layers in one kernel where it is built (csrc/eval_layer_bpc.hip, FIRST form); tests flip it
+EVAL_FIRST_PAIR = True
+
+
 def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Workspace,
                   in_slope: Optional[Tensor] = None, want_ctx: bool = False, sync=None, pending0=None):
     """-> (U_last, ctx).  U_last is the last layer's PRE-activation; apply layers[-1].slope to it.
@@ -159,10 +163,22 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
         for i in range(n - 1):
             fuse_flat[i] = (not fuse[i] and layers[i + 1].Ci == layers[i].Co and layers[i].Wr is not None
                             and ops.layer_apply_next_flat_ok(layers[i].Ci, layers[i].Co, T, V))
+    def eval_fold(L):
+        key = L.fold_key() if L.cache is not None else None
+        if key is not None and L.cache.get("key") == key:
+            return L.cache["fold"]                         # weights unchanged since the last eval forward
+        wb = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
+        if key is not None:
+            L.cache["key"], L.cache["fold"] = key, wb
+        return wb
+
+    skip = -1
     pending = pending0          # (Z, partials, rows) of THIS layer, written by the previous layer's apply (or by x's producer)
     if pending0 is not None and not (batch_stats[0] and STORE_Z and sync is None):
         raise ValueError("chain_forward: pending0 is for the stored-Z training path without SyncBN")
     for i, L in enumerate(layers):
+        if i == skip:
+            continue
         if h.shape[1] != L.Ci:
             raise ValueError(f"layer expects {L.Ci} input channels, got {h.shape[1]}")
         Z = None
@@ -194,15 +210,18 @@ def chain_forward(x: Tensor, layers: List[LayerTensors], training: bool, ws: Wor
                     h, L.A, L.T, slope, L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t, L.nbt_t,
                     L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r, L.nbt_r, buf, momentum=L.step_momentum(), Z=Z)
         else:
-            key = L.fold_key() if L.cache is not None else None
-            if key is not None and L.cache.get("key") == key:
-                wfold, bias = L.cache["fold"]              # weights unchanged since the last eval forward
-            else:
-                wfold, bias = ops.bn_fold(L.w2(L.Wt), L.bt, L.gt, L.bet, L.rm_t, L.rv_t,
-                                          L.w2(L.Wr), L.br, L.gr, L.ber, L.rm_r, L.rv_r)
-                if key is not None:
-                    L.cache["key"], L.cache["fold"] = key, (wfold, bias)
+            wfold, bias = eval_fold(L)
             stat = None
+            # the first layer of a stack fed by the network input runs inside the second layer's kernel where nobody asks for its output
+            if (EVAL_FIRST_PAIR and i == 0 and ctx is None and slope is None and n > 1 and not batch_stats[1] and layers[1].Ci == L.Co
+                    and L.Wr is not None and wfold.shape[1] == L.Co
+                    and ops.layer_first_pair_ok(L.Ci, L.Co, layers[1].Co, T, V)):
+                N = layers[1]
+                wf2, b2 = eval_fold(N)
+                if wf2.shape[1] == N.Co:
+                    h = ops.layer_first_pair_apply(h, L.A, L.T, wfold, bias, N.A, N.T, wf2, b2, L.Co, N.Co, L.slope)
+                    slope, skip = N.slope, 1
+                    continue
         pending = None
         if fuse[i]:
             rows_max = ops.layer_apply_next_rows(B, h.shape[1], L.Co)

@@ -123,7 +123,8 @@ class _ChainFn(torch.autograd.Function):
         layers, training, ws = meta
         x = x.contiguous()
         with torch.no_grad():
-            u, cctx = engine.chain_forward(x, layers, training, ws, in_slope=in_slope, want_ctx=True)
+            # (an eval-mode chain has no backward: no context, so layers may run fused without their intermediates in HBM)
+            u, cctx = engine.chain_forward(x, layers, training, ws, in_slope=in_slope, want_ctx=training)
         ctx.layers, ctx.cctx, ctx.ws, ctx.training = layers, cctx, ws, training
         return u
 

@@ -86,6 +86,25 @@ def layer_apply(x: Tensor, A: Tensor, Tm: Tensor, wfold: Tensor, bias: Tensor, C
     return out
 
 
+def layer_first_pair_ok(Ci: int, Cm: int, Co: int, T: int, V: int) -> bool:
+    """the first layer (2 -> Cm) and the layer behind it (Cm -> Co), folded, in one pass (csrc/eval_layer_bpc.hip, FIRST form)"""
+    return bool(_lib.lib().coskad_layer_first_pair_ok(i32(T), i32(V), i32(Ci), i32(Cm), i32(Co)))
+
+
+def layer_first_pair_apply(x: Tensor, A1: Tensor, T1: Tensor, wfold1: Tensor, bias1: Tensor, A2: Tensor, T2: Tensor, wfold2: Tensor,
+                           bias2: Tensor, Cm: int, Co: int, mid_slope: Tensor, out_slope: Optional[Tensor] = None) -> Tensor:
+    """layer_apply twice (folded BatchNorm: eval mode) for the first two layers of the encoder without the activation between them in
+    HBM: x [B, 2, T, V] (the network input) -> [B, Co, T, V]; `mid_slope`: the first layer's PReLU weight."""
+    B, Ci, T, V = x.shape
+    _chk(x, "x", (B, 2, T, V)); _chk(A1, "A1", (T, V, V)); _chk(T1, "T1", (V, T, T)); _chk(A2, "A2", (T, V, V)); _chk(T2, "T2", (V, T, T))
+    _chk(wfold1, "wfold1", (4, Cm)); _chk(bias1, "bias1", (Cm,)); _chk(wfold2, "wfold2", (2 * Cm, Co)); _chk(bias2, "bias2", (Co,))
+    _chk(mid_slope, "mid_slope", (1,)); _chk(out_slope, "out_slope", (1,), optional=True)
+    out = torch.empty(B, Co, T, V, device=x.device, dtype=torch.float32)
+    call("coskad_layer_first_pair_apply_f32", ptr(x), ptr(out), ptr(A1), ptr(T1), ptr(wfold1), ptr(bias1), ptr(A2), ptr(T2), ptr(wfold2),
+         ptr(bias2), ptr(mid_slope), ptr(out_slope), i32(B), i32(Cm), i32(Co), i32(T), i32(V), _stream())
+    return out
+
+
 def layer_fits(Ci: int, Co: int, T: int, V: int) -> bool:
     """Do the LDS-resident tile kernels take a (Ci -> Co) layer at this geometry?  (pure host arithmetic)"""
     fn = _lib.lib().coskad_layer_fits

@@ -448,6 +448,17 @@ int coskad_layer_apply_next_flat_f32(const float* Z, const float* in, float* out
                                      float* Z_next, float* partials, size_t partials_bytes, int B, int Ci, int Co, int T, int V,
                                      hipStream_t stream);
 
+/* The FIRST two ST_GCNN layers of the encoder with folded BatchNorm (coskad_layer_apply_f32 twice: models/graph_layers/stsgcn.py:94-116
+ * in eval mode, entries 0 and 1 of the nn.Sequential of models/common/components.py:94-105) in ONE pass -- x [B, 2, T, V] is the network
+ * input, the first layer (2 -> 32) is formed per clip on the VALU inside the second layer's kernel and its output never reaches HBM
+ * (csrc/eval_layer_bpc.hip).  ok: 1 when (n_frames, n_joints, C_in, C_mid, C_out) is built (12, 17 | 25, 2, 32, 16 | 32 | 64).
+ * wfold1 [4, 32] / bias1, wfold2 [64, Co] / bias2 from coskad_bn_fold_f32; mid_slope: the first layer's PReLU weight; out_slope NULL:
+ * pre-activation output. */
+int coskad_layer_first_pair_ok(int T, int V, int Ci, int Cm, int Co);
+int coskad_layer_first_pair_apply_f32(const float* x, float* out, const float* A1, const float* T1, const float* wfold1, const float* bias1,
+                                      const float* A2, const float* T2, const float* wfold2, const float* bias2, const float* mid_slope,
+                                      const float* out_slope, int B, int Cm, int Co, int T, int V, hipStream_t stream);
+
 /* A (32 -> 16) ST_GCNN layer in training mode by the same commutation, on its own kernels (csrc/commute_layer.hip; replaces
  * models/graph_layers/stsgcn.py:94-116 and its autograd for such a layer on the 12 x 25 layout): Y = Wt X, R = Wr X first (X = PReLU(u_prev)),
  * Zy = gcn(Y); both BatchNorms become per-channel affine maps of Zy and R (batch statistics = row sums); the backward is one kernel per clip

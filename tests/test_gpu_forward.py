@@ -268,3 +268,36 @@ def test_chain_forward_fused_next_vs_separate(golden, name, B):
         np.testing.assert_allclose(c1.stats[i].cpu().numpy(), c0.stats[i].cpu().numpy(), rtol=1e-3, atol=1e-4, err_msg=f"stat {i}")
     for k in s0:
         np.testing.assert_allclose(s1[k].cpu().numpy(), s0[k].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,B", [(25, 3), (25, 1030), (17, 37)])
+def test_eval_first_layer_inside_the_second_layers_kernel(V, B, monkeypatch):
+    """Eval mode: layer 1 (2 -> 32) formed on the VALU inside layer 2's kernel (csrc/eval_layer_bpc.hip, FIRST form) against the same
+    stack run layer by layer (17 joints: a non-default stack, the default one runs the fused encoder)."""
+    import numpy as np
+    from coskad_amd import engine, ops
+    from coskad_amd.models.sts.ae import STSE
+    from oracle import ref_cpu as R
+    torch.manual_seed(7)
+    chans = [32, 16, 32] if V == 25 else [32, 32]
+    m = STSE(2, chans, 64, 16, 12, V, 'sts_gcn', 'linear', 'euclidean', 0.0).cuda()
+    with torch.no_grad():
+        for mod in m.modules():                                # non-trivial running statistics / PReLU weights
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0.0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+            if isinstance(mod, torch.nn.PReLU):
+                mod.weight.fill_(0.2)
+    m.eval()
+    x = R.synthetic_clips(B, 2, 12, V, seed=B).cuda()
+    calls = []
+    real = ops.layer_first_pair_apply
+    monkeypatch.setattr(ops, "layer_first_pair_apply", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(engine, "EVAL_FIRST_PAIR", on)
+        with torch.no_grad():
+            outs[on] = m(x).cpu().numpy()
+    assert len(calls) == 1                                     # the pair kernel ran, in the first pass only
+    np.testing.assert_allclose(outs[True], outs[False], rtol=2e-4, atol=2e-5)
