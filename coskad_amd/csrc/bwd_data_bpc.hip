@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
                                                         const float* __restrict__ in_slope, float* __restrict__ dIn,
                                                         float* __restrict__ dZout, float* __restrict__ dap, int B,
                                                         float* __restrict__ gpart) {
-  constexpr int T = 12, TVg = T * V, Ci = 16 * CT, Co = 16 * OT, CiP = Ci, NG = OT + 2 * CT;
+  constexpr int T = 12, TVg = T * V, Ci = 16 * CT, Co = 16 * OT, CiP = Ci;
+  // K-pass groups: dU rows, Z rows, the layer input's rows -- FP: the input's rows are staged for dT anyway, Kr.X rides on that staging
+  // (fused_bwd.hip does the same) and the K pass is 2 CT groups = 8 CT barriers shorter
+  constexpr int NG = FP ? OT + CT : OT + 2 * CT;
   static_assert(TVg % 4 == 0, "rows are staged as float4");
   constexpr int KT0 = (Co + Ci) * CiP, DX0 = KT0 + CiP, KR0 = DX0 + (Co + Ci) * CiP;
   constexpr int R4 = TVg / 4, LDg = TVg + 2, LDWg = window_stride(TVg);
@@ -371,7 +374,18 @@ __global__ __launch_bounds__(256, 2) void k_bwd_data_bpc(const float* __restrict
       for (int h = 0; h < ((BDB_SKIP & 8) ? 0 : CT); ++h) {
         hstore(xh);
         if (h + 1 < CT) hload(clip, h + 1, xh);
+        float wk[4];                                     // Kr rows of this half for the wave's channel tile
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wk[s] = buf_load1(cres, lq, (DX0 + (Co + 16 * h + 4 * s) * CiP) * 4);
         __syncthreads();
+#pragma unroll
+        for (int s = 0; s < ((BDB_SKIP & 1) ? 0 : 4); ++s) {  // + Kr.X: the staged half IS the K pass's last group
+          float bx[MAXT];
+#pragma unroll
+          for (int t = 0; t < MAXT; ++t) bx[t] = r2[(4 * s + L.q) * LDg + pos_of(t)];
+#pragma unroll
+          for (int t = 0; t < MAXT; ++t) acc2[t] = mfma(wk[s], bx[t], acc2[t]);
+        }
 #pragma unroll
         for (int k = 0; k < MAXJ; ++k) {
           const int v = wave + 4 * k;
