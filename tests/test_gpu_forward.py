@@ -270,6 +270,41 @@ def test_chain_forward_fused_next_vs_separate(golden, name, B):
         np.testing.assert_allclose(s1[k].cpu().numpy(), s0[k].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("B", [5, 1037])
+def test_chain_forward_fused_next_vs_separate_25_joints(B):
+    """The same on the 25-joint layout (csrc/fused_apply_flat.hip, NX form: the next layer's statistics pass on the apply kernel of
+    layers 2 and 3; the first layer's apply and the 64-channel layer keep their own passes): activations, stat blocks, stored Z, buffers."""
+    from coskad_amd import engine
+    from coskad_amd.models.sts.ae import STSE
+    from coskad_amd.models.graph_layers.stsgcn import layer_tensors
+    torch.manual_seed(3)
+    proto = STSE(2, [32, 16, 32], 64, 16, 12, 25, 'sts_gcn', 'linear', 'euclidean', 0.0)
+    st = {k: v.detach().clone() for k, v in proto.state_dict().items()}
+    x = R.synthetic_clips(B, 2, 12, 25, seed=B)
+    res = []
+    for fuse in (True, False):
+        m = STSE(2, [32, 16, 32], 64, 16, 12, 25, 'sts_gcn', 'linear', 'euclidean', 0.0)
+        m.load_state_dict(st, strict=True)
+        m.cuda().train()
+        layers = [layer_tensors(l) for l in m.encoder.model]
+        old = engine.FUSE_NEXT
+        engine.FUSE_NEXT = fuse
+        try:
+            u, ctx = engine.chain_forward(x.cuda(), layers, True, engine.Workspace(), want_ctx=True)
+        finally:
+            engine.FUSE_NEXT = old
+        torch.cuda.synchronize()
+        res.append((u, ctx, {k: v.clone() for k, v in m.state_dict().items()}))
+    (u1, c1, s1), (u0, c0, s0) = res
+    np.testing.assert_allclose(u1.cpu().numpy(), u0.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    for i in range(4):
+        np.testing.assert_allclose(c1.inputs[i].cpu().numpy(), c0.inputs[i].cpu().numpy(), rtol=1e-4, atol=1e-4, err_msg=f"input {i}")
+        np.testing.assert_allclose(c1.zs[i].cpu().numpy(), c0.zs[i].cpu().numpy(), rtol=1e-4, atol=1e-4, err_msg=f"Z {i}")
+        np.testing.assert_allclose(c1.stats[i].cpu().numpy(), c0.stats[i].cpu().numpy(), rtol=1e-3, atol=1e-4, err_msg=f"stat {i}")
+    for k in s0:
+        np.testing.assert_allclose(s1[k].cpu().numpy(), s0[k].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("V,B", [(25, 3), (25, 1030), (17, 37)])
 def test_eval_first_layer_inside_the_second_layers_kernel(V, B, monkeypatch):
