@@ -659,7 +659,7 @@ inline int bwd_rows(int B) { return B < 512 ? B : 512; }
 extern "C" {
 
 /* 1: coskad_commute_fwd_f32 / _bwd_f32 take this layer (n_frames x n_joints, C_in -> C_out) */
-int coskad_commute_ok(int T_, int V_, int Ci, int Co) { return T_ == 12 && V_ == 25 && Ci == 32 && Co == 16; }
+int coskad_commute_ok(int T_, int V_, int Ci, int Co) { return T_ == 12 && (V_ == 25 || V_ == 17) && Ci == 32 && Co == 16; }
 
 /* floats of the scratch both entries need (partial rows of every kernel of the call) */
 size_t coskad_commute_ws_floats(int B, int T_, int V_) {
@@ -686,7 +686,7 @@ int coskad_commute_fwd_f32(const float* u_prev, const float* in_slope, const flo
     return fail(COSKAD_ERR_ARG, "commute_fwd: the next layer's statistics need T_next, slope_out, Z_next, partials_next, rows_next");
   if (!u_prev || !wt || !wr || !A || !Tm || !gamma_t || !beta_t || !gamma_r || !beta_r || !YR || !Zy || !U || !stat || !ws)
     return fail(COSKAD_ERR_ARG, "commute_fwd: null pointer");
-  if (B <= 0 || !coskad_commute_ok(T_, V_, 32, 16)) return fail(COSKAD_ERR_SHAPE, "commute_fwd: built for 12 x 25, 32 -> 16");
+  if (B <= 0 || !coskad_commute_ok(T_, V_, 32, 16)) return fail(COSKAD_ERR_SHAPE, "commute_fwd: built for 12 x 17 / 25, 32 -> 16");
   if (ws_floats < coskad_commute_ws_floats(B, T_, V_)) return fail(COSKAD_ERR_WORKSPACE, "commute_fwd: scratch too small");
   const int TV = T_ * V_;
   int rows = 0;
@@ -717,10 +717,10 @@ int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const flo
   if (!u_prev || !wt || !wr || !A || !Tm || !YR || !Zy || !stat || !dU || !d_in || !dA || !dT || !dWt || !dWr || !dgamma_t || !dbeta_t ||
       !dgamma_r || !dbeta_r || !ws)
     return fail(COSKAD_ERR_ARG, "commute_bwd: null pointer");
-  if (B <= 0 || !coskad_commute_ok(T_, V_, 32, 16)) return fail(COSKAD_ERR_SHAPE, "commute_bwd: built for 12 x 25, 32 -> 16");
+  if (B <= 0 || !coskad_commute_ok(T_, V_, 32, 16)) return fail(COSKAD_ERR_SHAPE, "commute_bwd: built for 12 x 17 / 25, 32 -> 16");
   if (ws_floats < coskad_commute_ws_floats(B, T_, V_)) return fail(COSKAD_ERR_WORKSPACE, "commute_bwd: scratch too small");
   if ((in_slope != nullptr) != (dslope != nullptr)) return fail(COSKAD_ERR_ARG, "commute_bwd: dslope goes with in_slope");
-  constexpr int V = 25;
+  const int V = V_;
   const int TV = 12 * V, nA = 12 * V * V, nT = V * 12 * 12;
   const int prow = cm::bwd_rows(B), srow = cm::sum_rows(B);
   float* gpart = ws;
@@ -733,10 +733,15 @@ int coskad_commute_bwd_f32(const float* u_prev, const float* in_slope, const flo
   hipLaunchKernelGGL(cm::k_commute_bfold, dim3(1), dim3(1024), 0, stream, spart, srow, (double)B * TV, stat, coef, dgamma_t, dbeta_t,
                      dgamma_r, dbeta_r);
   if ((rc = check_launch("commute_bfold"))) return rc;
-  auto k = below_stats ? cm::k_commute_bwd<V, true> : cm::k_commute_bwd<V, false>;
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cm::Geo<V>::bwd_lds);
-  hipLaunchKernelGGL(k, dim3(prow), dim3(256), cm::Geo<V>::bwd_lds, stream, u_prev, YR, Zy, dU, coef, wt, wr, A, Tm, in_slope, d_in, gpart,
-                     wpart, B, below_z, below_x, below_stats);
+#define LAUNCH_CB(V__)                                                                                                          \
+  do {                                                                                                                          \
+    auto k = below_stats ? cm::k_commute_bwd<V__, true> : cm::k_commute_bwd<V__, false>;                                        \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cm::Geo<V__>::bwd_lds);          \
+    hipLaunchKernelGGL(k, dim3(prow), dim3(256), cm::Geo<V__>::bwd_lds, stream, u_prev, YR, Zy, dU, coef, wt, wr, A, Tm, in_slope, d_in, \
+                       gpart, wpart, B, below_z, below_x, below_stats);                                                         \
+  } while (0)
+  if (V == 17) LAUNCH_CB(17); else LAUNCH_CB(25);
+#undef LAUNCH_CB
   if ((rc = check_launch("commute_bwd"))) return rc;
   const int nblk = ceil_div(nA + nT, cm::kRedCols) + ceil_div(1025, cm::kRedCols) + (below_stats ? ceil_div(cm::kBelowCols, cm::kRedCols) : 0);
   double* bout = below_stats ? reinterpret_cast<double*>(below_stats + ((size_t)prow * cm::kBelowCols + 1) / 2 * 2) : nullptr;

@@ -520,10 +520,9 @@ int launch_layer_apply_flat_next(const float* Z, const float* in, float* out, co
 
 // [Y; R] = [Wt; Wr] . PReLU(in [B, 32, TV]) -> out [B, 32, TV]; Zy = gcn(Y) -> zy [B, 16, TV]; row sums -> mixpart [*rows_out][64]: the
 // forward of a commuted 32 -> 16 layer up to its BatchNorm statistics (csrc/commute_layer.hip) on the K-ring GEMM above
-int launch_commute_apply_mix(const float* in, float* out, const float* wt, const float* wr, const float* in_slope, const float* Aw,
-                             const float* Tw, float* zy, float* mixpart, int B, int Ci, int Jo, int TV_, hipStream_t st, int* rows_out) {
-  if (TV_ != 300 || Ci != 32 || Jo != 32) return fail(COSKAD_ERR_SHAPE, "commute_apply_mix: built for 300 positions, 32 -> 16 + 16 (%d, %d -> %d)", TV_, Ci, Jo);
-  constexpr int TVg = 300;
+template <int TVg>
+static int launch_commute_apply_mix_tv(const float* in, float* out, const float* wt, const float* wr, const float* in_slope, const float* Aw,
+                                       const float* Tw, float* zy, float* mixpart, int B, hipStream_t st, int* rows_out) {
   const size_t lds = (size_t)(16 * fpf::window_stride(TVg) + 32 * (TVg + 2)) * sizeof(float);
   const int grid = B < 512 ? B : 512;
   *rows_out = grid;
@@ -531,6 +530,14 @@ int launch_commute_apply_mix(const float* in, float* out, const float* wt, const
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, in, wr, wt, (const float*)nullptr, in_slope, out, B, Aw, Tw, zy, mixpart,
                      (const float*)nullptr);
   return check_launch("commute_apply_mix");
+}
+
+int launch_commute_apply_mix(const float* in, float* out, const float* wt, const float* wr, const float* in_slope, const float* Aw,
+                             const float* Tw, float* zy, float* mixpart, int B, int Ci, int Jo, int TV_, hipStream_t st, int* rows_out) {
+  if ((TV_ != 300 && TV_ != 204) || Ci != 32 || Jo != 32)
+    return fail(COSKAD_ERR_SHAPE, "commute_apply_mix: built for 204 / 300 positions, 32 -> 16 + 16 (%d, %d -> %d)", TV_, Ci, Jo);
+  if (TV_ == 204) return launch_commute_apply_mix_tv<204>(in, out, wt, wr, in_slope, Aw, Tw, zy, mixpart, B, st, rows_out);
+  return launch_commute_apply_mix_tv<300>(in, out, wt, wr, in_slope, Aw, Tw, zy, mixpart, B, st, rows_out);
 }
 
 extern "C" {

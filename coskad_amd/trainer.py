@@ -297,8 +297,14 @@ COMMUTE = True
 COMMUTE_NEXT = True      # ... and the statistics pass of the layer behind them rides on their last kernel
 
 
-def _is_commute(m) -> bool:
+def _is_commute(m, decoder: bool = False) -> bool:
+    """decoder: the layer sits in a decoder stack.  At 17 joints the encoder's chained kernels (apply + next statistics, backward +
+    reductions of the layer below) already hold a 32 -> 16 layer on chip and the commuted form costs the chain more than it saves; the
+    decoder's 32 -> 16 layer stands alone between the folded first layer and the narrow last one (a statistics pass, an apply, a
+    reduction pass and a backward kernel of its own), and there the commuted kernels win."""
     tb, rb = m.tcn[1], (m.residual[1] if not isinstance(m.residual, torch.nn.Identity) else None)
+    if m.joints_dim == 17 and not decoder:
+        return False
     return (COMMUTE and not m.is_wide and rb is not None and ops.commute_ok(m.time_dim, m.joints_dim, m.in_channels, m.out_channels)
             and all(b.momentum is not None and b.affine and b.track_running_stats for b in (tb, rb)) and tb.eps == rb.eps
             and tb.momentum == rb.momentum)
@@ -344,6 +350,7 @@ class _FlatStack:
     def __init__(self, modules, fp: "FlatParams", prefix: str, first: int = 0) -> None:
         """modules: the layers first, first + 1, .. of the nn.Sequential whose parameters are named `{prefix}{index}.`"""
         self.segs = []                 # ('tile', [LayerTensors], [grad dicts]) | ('wide', module, names)
+        dec = prefix.startswith("decoder")
         i, n = 0, len(modules)
         while i < n:
             if modules[i].is_wide:
@@ -353,12 +360,12 @@ class _FlatStack:
                 pre = f"{prefix}{first + i}."
                 self.segs.append(('narrow', modules[i], pre) + _virtual_narrow_layer(modules[i], fp, pre))
                 i += 1
-            elif _is_commute(modules[i]):
+            elif _is_commute(modules[i], dec):
                 self.segs.append(('commute', modules[i], f"{prefix}{first + i}."))
                 i += 1
             else:
                 j = i
-                while j < n and not modules[j].is_wide and not _is_narrow(modules[j]) and not _is_commute(modules[j]):
+                while j < n and not modules[j].is_wide and not _is_narrow(modules[j]) and not _is_commute(modules[j], dec):
                     j += 1
                 self.segs.append(('tile', [layer_tensors(m) for m in modules[i:j]],
                                   [_layer_grad_views(fp, f"{prefix}{first + k}.") for k in range(i, j)]))
@@ -394,7 +401,8 @@ class _FlatStack:
                 mod.__dict__.get("_fold_cache", {}).clear()
                 # a tile run behind this layer: its first layer's statistics pass rides on this layer's last kernel
                 nxt = self.segs[k + 1][1][0] if (COMMUTE_NEXT and k + 1 < len(self.segs) and self.segs[k + 1][0] == 'tile') else None
-                if nxt is not None and (nxt.Ci != Co or nxt.rm_t is None or not engine.STORE_Z):
+                # (25 joints: at 17 the tile kernels' own 16-channel statistics pass is the faster one -- 2.746 vs 2.754 ms on the VAE step)
+                if nxt is not None and (nxt.Ci != Co or nxt.rm_t is None or not engine.STORE_Z or mod.joints_dim != 25):
                     nxt = None
                 u, sv, pend = ops.commute_fwd(h, slope, tc.weight, rc.weight, mod.gcn.A, mod.gcn.T, tb.weight, tb.bias, rb.weight, rb.bias,
                                               tc.bias, rc.bias, tb.running_mean, tb.running_var, rb.running_mean, rb.running_var,
